@@ -1,0 +1,448 @@
+"""CPU oracle: a restatement of PySparseLP's Chambolle-Pock and ADMM solvers.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``pysparselp_amd/`` imports this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and there only as the checker or as the timed CPU
+baseline -- never as the product path.
+
+Parity: PINNED.  ``tests/golden/make_golden.py`` (run in the build container,
+where the reference can be imported from /root/reference) checks every
+function below bit-for-bit against the reference's own iterates, and
+``tests/test_oracle_golden.py`` re-checks it on every run against the
+committed fixtures and against the reference's golden curves
+(tests/netlib_curves_SC105.json, tests/test_pott_segmentation_curves.json,
+tests/test_kmedians.py:14, tests/test_l1_svm_results.json).
+
+All arithmetic goes through ``oracle/slp_oracle.c`` (plain C, no FMA) or
+elementwise numpy; no scipy.sparse arithmetic is used here, so the oracle does
+not depend on the scipy version of the machine it runs on.  Matrices are the
+three raw CSR arrays, entries kept in the order they are given (the reference
+never sorts rows on this path except where stated below).
+
+Reference citations are ``file:line`` under /root/reference/pysparselp/.
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "oracle/liboracle.so missing: run `make -C oracle` (or __graft_entry__.build())"
+            )
+        lib = ctypes.CDLL(path)
+        i64, dbl, vp = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+        lib.orc_csr_matvec.argtypes = [i64, vp, vp, vp, vp, vp]
+        lib.orc_csr_rmatvec.argtypes = [i64, i64, vp, vp, vp, vp, vp]
+        lib.orc_bounded_gauss_seidel.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int, dbl]
+        lib.orc_csr_to_csc.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp]
+        lib.orc_normal_matrix.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, dbl, dbl, vp, vp, vp]
+        lib.orc_normal_matrix.restype = i64
+        lib.orc_row_scale_l2.argtypes = [i64, vp, vp, vp]
+        for f in (lib.orc_csr_matvec, lib.orc_csr_rmatvec, lib.orc_bounded_gauss_seidel,
+                  lib.orc_csr_to_csc, lib.orc_row_scale_l2):
+            f.restype = None
+        _LIB = lib
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Csr:
+    """Raw CSR triple (int64 indptr, int32 indices, float64 data) + shape."""
+
+    def __init__(self, indptr, indices, data, shape):
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.data = _f64(data)
+        self.shape = (int(shape[0]), int(shape[1]))
+        assert self.indptr.size == self.shape[0] + 1
+        assert self.indices.size == self.data.size == int(self.indptr[-1])
+
+    @property
+    def nnz(self):
+        return int(self.indptr[-1])
+
+    def copy(self):
+        return Csr(self.indptr.copy(), self.indices.copy(), self.data.copy(), self.shape)
+
+    def toscipy(self):
+        import scipy.sparse
+
+        return scipy.sparse.csr_matrix(
+            (self.data.copy(), self.indices.copy(), self.indptr.copy()), shape=self.shape
+        )
+
+
+def as_csr(a):
+    """Accept a Csr, a scipy CSR matrix or None; entry order is preserved."""
+    if a is None or isinstance(a, Csr):
+        return a
+    return Csr(a.indptr, a.indices, a.data, a.shape)
+
+
+# --------------------------------------------------------------------------
+# kernels (scipy.sparse._sparsetools semantics, see slp_oracle.c)
+# --------------------------------------------------------------------------
+def matvec(a, x):
+    """``a * x`` (csr_matvec)."""
+    x = _f64(x)
+    assert x.size == a.shape[1]
+    y = np.empty(a.shape[0])
+    _lib().orc_csr_matvec(a.shape[0], _p(a.indptr), _p(a.indices), _p(a.data), _p(x), _p(y))
+    return y
+
+
+def rmatvec(a, y):
+    """``y * a`` for a CSR ``a`` (csc_matvec over the transposed view)."""
+    y = _f64(y)
+    assert y.size == a.shape[0]
+    out = np.empty(a.shape[1])
+    _lib().orc_csr_rmatvec(a.shape[0], a.shape[1], _p(a.indptr), _p(a.indices), _p(a.data), _p(y), _p(out))
+    return out
+
+
+def to_csc(a):
+    """CSC arrays of ``a`` (rows increasing inside every column)."""
+    cptr = np.empty(a.shape[1] + 1, dtype=np.int64)
+    crow = np.empty(a.nnz, dtype=np.int32)
+    cdata = np.empty(a.nnz)
+    _lib().orc_csr_to_csc(a.shape[0], a.shape[1], _p(a.indptr), _p(a.indices), _p(a.data), _p(cptr), _p(crow), _p(cdata))
+    return cptr, crow, cdata
+
+
+def normal_matrix(a, gamma_eq, gamma_ineq):
+    """``(gamma_eq * a.T * a + gamma_ineq * I).tocsr()`` (ADMM.py:93-101)."""
+    cptr, crow, cdata = to_csc(a)
+    n = a.shape[1]
+    args = (a.shape[0], n, _p(a.indptr), _p(a.indices), _p(a.data), _p(cptr), _p(crow), _p(cdata),
+            float(gamma_eq), float(gamma_ineq))
+    nnz = _lib().orc_normal_matrix(*args, None, None, None)
+    mp = np.empty(n + 1, dtype=np.int64)
+    mj = np.empty(nnz, dtype=np.int32)
+    mx = np.empty(nnz)
+    _lib().orc_normal_matrix(*args, _p(mp), _p(mj), _p(mx))
+    return Csr(mp, mj, mx, (n, n))
+
+
+def diagonal(m):
+    """``m.diagonal()`` of a CSR matrix without duplicate entries."""
+    d = np.zeros(m.shape[0])
+    rows = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
+    on = m.indices == rows
+    d[rows[on]] = m.data[on]
+    return d
+
+
+class BoundedGaussSeidel:
+    """gaussSiedel.pyx:83-153 ``boundedGaussSeidelClass``."""
+
+    def __init__(self, m):
+        self.m = as_csr(m)
+        self.invD = 1 / diagonal(self.m)  # gaussSiedel.pyx:91-92
+
+    def solve(self, b, lower_bounds, upper_bounds, x, maxiter=3, w=1, order=None):
+        assert x.dtype == np.float64 and x.flags.c_contiguous
+        m = self.m
+        _lib().orc_bounded_gauss_seidel(
+            m.shape[0], _p(m.indptr), _p(m.indices), _p(m.data), _p(self.invD),
+            _p(_f64(b)), _p(_f64(lower_bounds)), _p(_f64(upper_bounds)), _p(x), int(maxiter), float(w))
+        return x
+
+
+# --------------------------------------------------------------------------
+# problem transforms (tools.py)
+# --------------------------------------------------------------------------
+def precondition_constraints(a, b, b2=None):
+    """tools.py:272-290 with alpha=2 (the only value used: ADMM.py:77,82,91).
+
+    ``sigma * a`` is a sparse-sparse product (SMMP), whose output lists every
+    row in the REVERSE of the order in which its columns were first touched;
+    with one term per entry that is the reverse of the input row.  The values
+    are ``sigma_i * a_ik`` (one rounding).  ``sigma * b`` is a csr_matvec over
+    a diagonal: ``sigma_i * b_i`` (+-inf stays +-inf).
+    """
+    a = as_csr(a)
+    inv_s = np.empty(a.shape[0])
+    _lib().orc_row_scale_l2(a.shape[0], _p(a.indptr), _p(a.data), _p(inv_s))
+    rows = np.repeat(np.arange(a.shape[0]), np.diff(a.indptr))
+    scaled = inv_s[rows] * a.data
+    # reverse every row segment: position p in row r maps to start+end-1-p
+    pos = np.arange(a.nnz)
+    rev = a.indptr[rows] + a.indptr[rows + 1] - 1 - pos
+    a_p = Csr(a.indptr.copy(), a.indices[rev], scaled[rev], a.shape)
+    keep = a_p.data != 0  # SMMP drops entries whose value is exactly 0
+    if not np.all(keep):
+        counts = np.bincount(rows[keep], minlength=a.shape[0])
+        a_p = Csr(np.concatenate(([0], np.cumsum(counts))), a_p.indices[keep], a_p.data[keep], a.shape)
+    bp = inv_s * _f64(b) if b is not None else None
+    if b2 is None:
+        return a_p, bp
+    return a_p, bp, inv_s * _f64(b2)
+
+
+def _sorted_rows(indptr, indices, data, shape):
+    """COO->CSR as scipy does it for hstack/vstack results: columns sorted
+    inside every row, duplicates summed in that order."""
+    rows = np.repeat(np.arange(shape[0]), np.diff(indptr))
+    order = np.lexsort((indices, rows))  # stable: by row, then column
+    r, j, v = rows[order], indices[order], data[order]
+    if r.size:
+        new = np.ones(r.size, dtype=bool)
+        new[1:] = (r[1:] != r[:-1]) | (j[1:] != j[:-1])
+        if not np.all(new):
+            starts = np.nonzero(new)[0]
+            v = np.add.reduceat(v, starts)
+            r, j = r[starts], j[starts]
+    ptr = np.zeros(shape[0] + 1, dtype=np.int64)
+    np.add.at(ptr, r + 1, 1)
+    return Csr(np.cumsum(ptr), j, v, shape)
+
+
+def convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0):
+    """tools.py:88-127: A=[[Ae,0],[Ai,-I]], b=[be;0], bounds=[lb;b_lower],[ub;b_upper],
+    x0=[x0; Ai*x0], c=[c;0].  Requires a_ineq (the reference hits an unbound
+    name otherwise, tools.py:92,127)."""
+    a_eq, a_ineq = as_csr(a_eq), as_csr(a_ineq)
+    if a_ineq is None:
+        raise UnboundLocalError("a_eq2 (reference fails the same way when a_ineq is None)")
+    ni, n = a_ineq.shape
+    ci = np.diff(a_ineq.indptr)
+    rows_i = np.repeat(np.arange(ni), ci)
+    # rows [Ai, -I]: append one (n+i, -1) entry per row, then sort each row
+    ind_i = np.concatenate((a_ineq.indices, (n + np.arange(ni)).astype(np.int32)))
+    dat_i = np.concatenate((a_ineq.data, -np.ones(ni)))
+    row_i = np.concatenate((rows_i, np.arange(ni)))
+    if a_eq is not None:
+        me = a_eq.shape[0]
+        rows_e = np.repeat(np.arange(me), np.diff(a_eq.indptr))
+        rows = np.concatenate((rows_e, me + row_i))
+        ind = np.concatenate((a_eq.indices, ind_i))
+        dat = np.concatenate((a_eq.data, dat_i))
+        b2 = np.hstack((_f64(beq), np.zeros(ni)))
+    else:
+        me = 0
+        rows, ind, dat = row_i, ind_i, dat_i
+        b2 = np.zeros(ni)
+    order = np.argsort(rows, kind="stable")
+    counts = np.bincount(rows, minlength=me + ni)
+    ptr = np.concatenate(([0], np.cumsum(counts)))
+    a2 = _sorted_rows(ptr, ind[order], dat[order], (me + ni, n + ni))
+    if b_lower is None:
+        b_lower = np.full(ni, -np.inf)
+    if b_upper is None:
+        b_upper = np.full(ni, np.inf)
+    lb2 = np.hstack((_f64(lb), _f64(b_lower)))
+    ub2 = np.hstack((_f64(ub), _f64(b_upper)))
+    x02 = np.hstack((_f64(x0), matvec(a_ineq, x0)))
+    c2 = np.hstack((_f64(c), np.zeros(ni)))
+    return c2, a2, b2, lb2, ub2, x02
+
+
+def one_sided(a_ineq, b_lower, b_upper):
+    """ChambollePockPPD.py:74-88: [Ai[upper finite]; -Ai[lower finite]]."""
+    a_ineq = as_csr(a_ineq)
+    if a_ineq is None or b_lower is None:
+        return a_ineq, b_upper
+    up = np.nonzero(b_upper != np.inf)[0]
+    lo = np.nonzero(b_lower != -np.inf)[0]
+
+    def take(rows, sign):
+        cnt = np.diff(a_ineq.indptr)[rows]
+        ptr = np.concatenate(([0], np.cumsum(cnt)))
+        src = np.repeat(a_ineq.indptr[rows], cnt) + (np.arange(ptr[-1]) - np.repeat(ptr[:-1], cnt))
+        return ptr, a_ineq.indices[src], sign * a_ineq.data[src]
+
+    if len(lo) > 0 and len(up) > 0:
+        p1, j1, v1 = take(up, 1.0)
+        p2, j2, v2 = take(lo, -1.0)
+        a = Csr(np.concatenate((p1, p1[-1] + p2[1:])), np.concatenate((j1, j2)),
+                np.concatenate((v1, v2)), (len(up) + len(lo), a_ineq.shape[1]))
+    elif len(lo) > 0:
+        a = Csr(a_ineq.indptr, a_ineq.indices, -a_ineq.data, a_ineq.shape)
+    else:
+        a = a_ineq
+    return a, np.hstack((_f64(b_upper)[up], -_f64(b_lower)[lo]))
+
+
+# --------------------------------------------------------------------------
+# Chambolle-Pock (ChambollePockPPD.py:36-346)
+# --------------------------------------------------------------------------
+def cp_setup(a_eq, a_ineq, alpha=1):
+    """Diagonal preconditioners T, Sigma_eq, Sigma_ineq (ChambollePockPPD.py:122-179)."""
+    tmp = 0
+    for a in (a_eq, a_ineq):
+        if a is not None:
+            cp = Csr(a.indptr, a.indices, np.abs(a.data) ** (2 - alpha), a.shape)
+            tmp = tmp + rmatvec(cp, np.ones(a.shape[0]))  # :134,144 column sums, row order
+    tmp[tmp == 0] = 1  # :152
+    diag_t = 1 / tmp
+
+    def sigma(a):
+        if a is None:
+            return None
+        cp = Csr(a.indptr, a.indices, np.abs(a.data) ** alpha, a.shape)
+        s = matvec(cp, np.ones(a.shape[1]))  # :161,172
+        s[s == 0] = 1
+        return 1 / s
+
+    return diag_t, sigma(a_eq), sigma(a_ineq)
+
+
+def chambolle_pock_ppd(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, alpha=1, theta=1,
+                       nb_max_iter=100, callback_func=None, max_time=None, nb_iter_plot=10,
+                       iterate_hook=None):
+    """Same contract as the reference function; ``iterate_hook(niter, x, y_eq,
+    y_ineq)`` (oracle-only) sees the state after every iteration's primal
+    update and before its dual update, i.e. exactly what a report would see."""
+    c, lb, ub = _f64(c), _f64(lb), _f64(ub)
+    start = time.perf_counter()
+    a_eq, a_ineq = as_csr(a_eq), as_csr(a_ineq)
+    if a_eq is not None and a_eq.shape[0] == 0:  # :70-72
+        a_eq, beq = None, None
+    if a_ineq is not None and a_ineq.shape[0] == 0:
+        a_ineq = None
+    if a_ineq is not None:
+        a_ineq, b_ineq = one_sided(a_ineq, b_lower, b_upper)  # :74-88
+        b_ineq = _f64(b_ineq)
+    x = _f64(x0).copy() if x0 is not None else np.zeros(c.size)  # :91-94
+    n = c.size
+    if a_eq is None and a_ineq is None:  # :147-151
+        x = np.zeros_like(lb)
+        x[c > 0] = lb[c > 0]
+        x[c < 0] = ub[c < 0]
+        return x
+    diag_t, sig_eq, sig_ineq = cp_setup(a_eq, a_ineq, alpha)
+    if a_eq is not None:
+        beq = _f64(beq)
+        y_eq = np.zeros(a_eq.shape[0])
+    else:
+        y_eq = None
+    y_ineq = np.zeros(a_ineq.shape[0]) if a_ineq is not None else None
+    x3 = x
+    niter = 0
+    while niter < nb_max_iter:  # :195
+        d = c
+        if a_eq is not None:
+            d = d + rmatvec(a_eq, y_eq)  # :206
+        if a_ineq is not None:
+            d = d + rmatvec(a_ineq, y_ineq)  # :216
+        x2 = x - diag_t * d  # :220
+        np.maximum(x2, lb, x2)
+        np.minimum(x2, ub, x2)
+        x3 = (1 + theta) * x2 - theta * x  # :226
+        x = x2
+        if a_eq is not None:
+            r_eq = matvec(a_eq, x3) - beq  # :235
+        if a_ineq is not None:
+            r_ineq = matvec(a_ineq, x3) - b_ineq  # :240
+        if iterate_hook is not None:
+            iterate_hook(niter, x, y_eq, y_ineq)
+        if niter % nb_iter_plot == 0:  # :242-329
+            elapsed = time.perf_counter() - start
+            if (max_time is not None) and elapsed > max_time:
+                break
+            energy1 = c.dot(x)
+            x4 = lb.copy()
+            x4[d < 0] = ub[d < 0]  # :260-261
+            energy2 = c.dot(x4)
+            max_violated_equality = 0
+            max_violated_inequality = 0
+            if a_eq is not None:
+                energy1 += y_eq.dot(matvec(a_eq, x) - beq)
+                energy2 += y_eq.dot(matvec(a_eq, x4) - beq)
+                max_violated_equality = np.max(np.abs(r_eq))
+            if a_ineq is not None:
+                energy1 += y_ineq.dot(matvec(a_ineq, x) - b_ineq)
+                energy2 += y_ineq.dot(matvec(a_ineq, x4) - b_ineq)
+                max_violated_inequality = np.max(r_ineq)
+            # :283 overwrites it with the violation at x itself (force_integer=False);
+            # the reference dereferences a_ineq unconditionally there.
+            if a_ineq is None:
+                raise AttributeError("'NoneType' object has no attribute (reference: ChambollePockPPD.py:283)")
+            max_violated_inequality = np.max(matvec(a_ineq, x) - b_ineq)
+            if callback_func is not None:
+                callback_func(niter, x, energy1, energy2, elapsed, max_violated_equality, max_violated_inequality)
+        if a_eq is not None:
+            y_eq = y_eq + sig_eq * r_eq  # :334
+        if a_ineq is not None:
+            y_ineq = y_ineq + sig_ineq * r_ineq  # :339-341
+            np.maximum(y_ineq, 0, y_ineq)
+        niter += 1
+    return x[:n], None
+
+
+# --------------------------------------------------------------------------
+# ADMM (ADMM.py:47-269, projected Gauss-Seidel x-step: the shipped flags :66-71)
+# --------------------------------------------------------------------------
+def admm_setup(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2, gamma_ineq=3,
+               use_preconditioning=True):
+    """ADMM.py:73-101: row scaling, standard form, second row scaling, M, Atb."""
+    c = _f64(c)
+    a_eq, a_ineq = as_csr(a_eq), as_csr(a_ineq)
+    if x0 is None:
+        x0 = np.zeros(c.size)
+    if a_eq is not None:
+        a_eq, beq = precondition_constraints(a_eq, beq)
+    if a_ineq is not None:
+        a_ineq, b_lower, b_upper = precondition_constraints(a_ineq, b_lower, b_upper)
+    c2, a, b, lb2, ub2, x = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
+    if use_preconditioning:
+        a, b = precondition_constraints(a, b)
+    m = normal_matrix(a, gamma_eq, gamma_ineq)
+    atb = rmatvec(a, b)  # :95
+    return dict(c=c2, a=a, b=b, lb=lb2, ub=ub2, x0=x, m=m, atb=atb)
+
+
+def lp_admm(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2, gamma_ineq=3, nb_iter=100,
+            callback_func=None, max_time=None, use_preconditioning=True, nb_iter_plot=10, iterate_hook=None):
+    n = np.asarray(c).size
+    s = admm_setup(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0, gamma_eq, gamma_ineq, use_preconditioning)
+    c, a, b, lb, ub, x, m, atb = (s[k] for k in ("c", "a", "b", "lb", "ub", "x0", "m", "atb"))
+    x = x.copy()
+    xp = np.maximum(x, 0)  # :98
+    lambda_eq = np.zeros(a.shape[0])
+    lambda_ineq = np.zeros(x.shape)
+    bs = BoundedGaussSeidel(m)  # :139
+
+    def energy(x, xp, lambda_eq, lambda_ineq):  # :124-132
+        r = matvec(a, x) - b
+        return (c.dot(x) + 0.5 * gamma_eq * np.sum(r ** 2) + 0.5 * gamma_ineq * np.sum((x - xp) ** 2)
+                + lambda_eq.dot(matvec(a, x) - b) + lambda_ineq.dot(x - xp))
+
+    start = time.perf_counter()
+    i = 0
+    while i <= nb_iter:  # :143 (nb_cg_iter == 1): nb_iter+1 sweeps
+        y = -c + gamma_eq * atb + gamma_ineq * xp - rmatvec(a, lambda_eq) - lambda_ineq  # :148
+        bs.solve(y, lb, ub, x, maxiter=1, w=1)  # :162
+        if iterate_hook is not None:
+            iterate_hook(i, x[0:n], x, lambda_eq)
+        if i % nb_iter_plot == 0:  # :213-248
+            elapsed = time.perf_counter() - start
+            if max_time is not None and elapsed > max_time:
+                break
+            energy1 = energy(x, xp, lambda_eq, lambda_ineq)
+            r = matvec(a, x) - b
+            max_violated_equality = np.max(np.abs(r))
+            max_violated_inequality = max(0, -np.min(x))
+            if callback_func is not None:
+                callback_func(i, x[0:n], energy1, energy1, elapsed, max_violated_equality, max_violated_inequality)
+        xp = x  # :259 (alias)
+        lambda_eq = lambda_eq + gamma_eq * (matvec(a, x) - b)  # :261-263
+        i += 1
+    return x[0:n]

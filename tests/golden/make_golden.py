@@ -1,0 +1,450 @@
+"""Generate the golden fixtures under tests/golden/ by importing the reference.
+
+Runs ONLY in the build container (needs /root/reference, Cython, gcc).  The
+reference package is copied to /tmp and its two Cython modules are built there
+unmodified; nothing of it is written into this repository -- only the arrays
+it produces (inputs and expected outputs) are saved, as .npz/.json fixtures.
+
+While generating, every fixture is also replayed through oracle/oracle.py and
+required to match the reference BIT FOR BIT (iterates) -- that is what pins
+the oracle.  Usage:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF_SRC = "/root/reference"
+REF_TMP = "/tmp/slp_reference_build"
+
+sys.path.insert(0, REPO)
+
+
+def build_reference():
+    if not os.path.exists(os.path.join(REF_TMP, "pysparselp")):
+        os.makedirs(REF_TMP, exist_ok=True)
+        for item in ("pysparselp", "setup.py", "tests"):
+            src = os.path.join(REF_SRC, item)
+            dst = os.path.join(REF_TMP, item)
+            if os.path.isdir(src):
+                shutil.copytree(src, dst)
+            else:
+                shutil.copy(src, dst)
+    import glob
+
+    if not glob.glob(os.path.join(REF_TMP, "pysparselp", "gaussSiedel*.so")):
+        subprocess.check_call([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=REF_TMP,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # randomLP.py:11 has a broken relative import; fix it in the /tmp copy only
+    p = os.path.join(REF_TMP, "pysparselp", "randomLP.py")
+    s = open(p).read()
+    s = s.replace("from . import SparseLP, solving_methods", "from .SparseLP import SparseLP, solving_methods")
+    open(p, "w").write(s)
+
+
+def install_shims():
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    time.clock = time.perf_counter  # removed in py3.8; reference calls it everywhere
+    np.float = np.float64
+    np.int = np.int64
+    sys.modules["maxflow"] = make_maxflow_standin()
+    sys.path.insert(0, REF_TMP)
+
+
+def make_maxflow_standin():
+    """PyMaxflow is absent; the Potts example only uses it for the exact
+    min-cut ground truth.  Same cut via scipy's max-flow (unique for these
+    seeds; checked against the reference's golden curve below)."""
+    import scipy.sparse
+    from scipy.sparse.csgraph import maximum_flow, breadth_first_order
+
+    mod = types.ModuleType("maxflow")
+
+    class _G:
+        def __init__(self, *a):
+            pass
+
+        def add_grid_nodes(self, shape):
+            self.shape = tuple(shape)
+            return np.arange(int(np.prod(shape))).reshape(shape)
+
+        def add_grid_edges(self, nodeids, w):
+            self.w = int(w)
+
+        def add_grid_tedges(self, nodeids, src, snk):
+            self.tr = (np.asarray(src) - np.asarray(snk)).astype(np.int64)
+
+        def maxflow(self):
+            ids = np.arange(int(np.prod(self.shape))).reshape(self.shape)
+            n = ids.size
+            s, t = n, n + 1
+            rows, cols, caps = [], [], []
+            for axis in range(2):
+                a = np.take(ids, np.arange(self.shape[axis] - 1), axis=axis).ravel()
+                b = np.take(ids, np.arange(1, self.shape[axis]), axis=axis).ravel()
+                rows += [a, b]
+                cols += [b, a]
+                caps += [np.full(a.size, self.w), np.full(a.size, self.w)]
+            tr = self.tr.ravel()
+            pos = np.nonzero(tr > 0)[0]
+            neg = np.nonzero(tr < 0)[0]
+            rows += [np.full(pos.size, s), neg]
+            cols += [pos, np.full(neg.size, t)]
+            caps += [tr[pos], -tr[neg]]
+            g = scipy.sparse.csr_matrix((np.concatenate(caps).astype(np.int32),
+                                         (np.concatenate(rows), np.concatenate(cols))), shape=(n + 2, n + 2))
+            res = maximum_flow(g, s, t)
+            residual = (g - res.flow).tocsr()
+            residual.data = (residual.data > 0).astype(np.int32)
+            residual.eliminate_zeros()
+            reach = breadth_first_order(residual, s, directed=True, return_predecessors=False)
+            self.src_side = np.zeros(n + 2, dtype=bool)
+            self.src_side[reach] = True
+
+        def get_grid_segments(self, nodeids):
+            return ~self.src_side[np.asarray(nodeids)]  # True = sink segment
+
+    class _Graph:
+        def __getitem__(self, item):
+            return _G
+
+    mod.Graph = _Graph()
+    return mod
+
+
+# ---------------------------------------------------------------------------
+def csr_parts(a):
+    if a is None:
+        return None
+    return dict(indptr=a.indptr.astype(np.int64), indices=a.indices.astype(np.int32),
+                data=a.data.astype(np.float64), shape=np.array(a.shape, dtype=np.int64))
+
+
+def lp_arrays(lp, ground_truth=None, gt_indices=None):
+    d = dict(c=lp.costsvector.copy(), lb=lp.lower_bounds.copy(), ub=lp.upper_bounds.copy(),
+             be=lp.b_equalities.copy())
+    for tag, a in (("Ae", lp.a_equalities), ("Ai", lp.a_inequalities)):
+        for k, v in csr_parts(a).items():
+            d[f"{tag}_{k}"] = v
+    d["bl"] = lp.b_lower.copy() if lp.b_lower is not None else np.zeros(0)
+    d["bl_none"] = np.array(lp.b_lower is None)
+    d["bu"] = lp.b_upper.copy()
+    if ground_truth is not None:
+        d["gt"] = np.asarray(ground_truth, dtype=np.float64)
+        d["gt_idx"] = np.asarray(gt_indices, dtype=np.int64)
+    return d
+
+
+def solver_inputs(lp):
+    """What SparseLP.solve hands to lp_admm (SparseLP.py:1004-1014,1193-1208)."""
+    a_ineq = lp.a_inequalities if lp.a_inequalities.shape[0] > 0 else None
+    a_eq = lp.a_equalities if lp.a_equalities.shape[0] > 0 else None
+    b_eq = lp.b_equalities if a_eq is not None else None
+    return (lp.costsvector, a_eq, b_eq, a_ineq, lp.b_lower, lp.b_upper, lp.lower_bounds, lp.upper_bounds)
+
+
+def capture(fn, keep):
+    rec = {"it": [], "x": [], "e1": [], "e2": [], "veq": [], "vineq": []}
+
+    def cb(niter, sol, e1, e2, dur, veq, vineq):
+        if niter in keep:
+            rec["it"].append(niter)
+            rec["x"].append(np.array(sol, dtype=np.float64, copy=True))
+            rec["e1"].append(e1)
+            rec["e2"].append(e2)
+            rec["veq"].append(veq)
+            rec["vineq"].append(vineq)
+
+    fn(cb)
+    return rec
+
+
+def run_case(name, lp, keep_iters, nb_iter, ground_truth=None, gt_indices=None, curve_iters=None):
+    """Reference iterates (nb_iter_plot=1) for both methods + oracle replay."""
+    import copy
+    import contextlib
+    import io
+    from pysparselp.ADMM import lp_admm
+    from pysparselp.ChambollePockPPD import chambolle_pock_ppd
+    from oracle import oracle
+
+    keep = set(keep_iters)
+    out = lp_arrays(lp, ground_truth, gt_indices)
+    sink = io.StringIO()
+    # --- ADMM: exactly the call of SparseLP.py:1193-1208
+    args = solver_inputs(lp)
+    with contextlib.redirect_stdout(sink):
+        rec = capture(lambda cb: lp_admm(*args, nb_iter=nb_iter, x0=None, callback_func=cb,
+                                         max_time=None, nb_iter_plot=1), keep)
+    orc = capture(lambda cb: oracle.lp_admm(*args, nb_iter=nb_iter, x0=None, callback_func=cb,
+                                            max_time=None, nb_iter_plot=1), keep)
+    assert rec["it"] == orc["it"]
+    for a, b in zip(rec["x"], orc["x"]):
+        assert np.array_equal(a, b), f"{name}: admm oracle differs from reference, max {np.max(np.abs(a-b))}"
+    assert np.allclose(rec["e1"], orc["e1"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(rec["veq"], orc["veq"]) and np.array_equal(rec["vineq"], orc["vineq"])
+    out.update(admm_it=np.array(rec["it"]), admm_x=np.array(rec["x"]), admm_e1=np.array(rec["e1"]),
+               admm_veq=np.array(rec["veq"]), admm_vineq=np.array(rec["vineq"]))
+    # --- CP: SparseLP.py:1244-1288 (remove_fixed_variables, then the solver)
+    lp_red = copy.deepcopy(lp)
+    m_change, shift = lp_red.remove_fixed_variables()
+    cargs = (lp_red.costsvector, lp_red.a_equalities, lp_red.b_equalities, lp_red.a_inequalities,
+             lp_red.b_lower, lp_red.b_upper, lp_red.lower_bounds, lp_red.upper_bounds)
+    with contextlib.redirect_stdout(sink):
+        rec = capture(lambda cb: chambolle_pock_ppd(*cargs, x0=None, alpha=1, theta=1, nb_max_iter=nb_iter,
+                                                    callback_func=cb, max_time=None, nb_iter_plot=1), keep)
+    orc = capture(lambda cb: oracle.chambolle_pock_ppd(*cargs, x0=None, alpha=1, theta=1, nb_max_iter=nb_iter,
+                                                       callback_func=cb, max_time=None, nb_iter_plot=1), keep)
+    assert rec["it"] == orc["it"]
+    for a, b in zip(rec["x"], orc["x"]):
+        assert np.array_equal(a, b), f"{name}: cp oracle differs from reference, max {np.max(np.abs(a-b))}"
+    assert np.allclose(rec["e1"], orc["e1"], rtol=1e-10, atol=1e-10)
+    assert np.allclose(rec["e2"], orc["e2"], rtol=1e-10, atol=1e-10)
+    assert np.array_equal(rec["vineq"], orc["vineq"]) and np.array_equal(rec["veq"], orc["veq"])
+    out.update(cp_it=np.array(rec["it"]), cp_x=np.array(rec["x"]), cp_e1=np.array(rec["e1"]),
+               cp_e2=np.array(rec["e2"]), cp_veq=np.array(rec["veq"], dtype=np.float64),
+               cp_vineq=np.array(rec["vineq"]), cp_free=(lp.upper_bounds > lp.lower_bounds))
+    # --- the harness: SparseLP.solve with the reference's reporting cadence
+    if curve_iters is not None:
+        for method in ("admm", "chambolle_pock_ppd"):
+            with contextlib.redirect_stdout(sink):
+                sol, _ = lp.solve(method=method, get_timing=True, nb_iter=curve_iters, max_time=None,
+                                  ground_truth=ground_truth, ground_truth_indices=gt_indices,
+                                  plot_solution=None, nb_iter_plot=500)
+            tag = "admm" if method == "admm" else "cp"
+            out[f"{tag}_curve_dist"] = np.array(lp.distance_to_ground_truth)
+            out[f"{tag}_curve_maxviol"] = np.array(lp.max_violated_constraint)
+            out[f"{tag}_curve_pobj"] = np.array(lp.pobj_curve)
+            out[f"{tag}_curve_itrn"] = np.array(lp.itrn_curve)
+            out[f"{tag}_solution"] = np.array(sol)
+    path = os.path.join(HERE, f"lp_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"  {name}: n={lp.costsvector.size} me={lp.a_equalities.shape[0]} mi={lp.a_inequalities.shape[0]}"
+          f" -> {os.path.getsize(path)/1e3:.0f} kB (oracle bit-exact on {len(out['admm_it'])}+{len(out['cp_it'])} iterates)")
+    return out
+
+
+def netlib_lp(name):
+    """tests/test_netlib.py:19-48."""
+    import copy
+    from pysparselp.SparseLP import SparseLP
+    from pysparselp.netlib import get_problem
+
+    d = get_problem(name)
+    gt = d["solution"]
+    lp = SparseLP()
+    lp.add_variables_array(len(d["cost_vector"]), lower_bounds=d["lower_bounds"],
+                           upper_bounds=np.minimum(d["upper_bounds"], np.max(gt) * 2), costs=d["cost_vector"])
+    lp.add_equality_constraints_sparse(d["a_eq"], d["b_eq"])
+    lp.add_inequality_constraints_sparse(d["a_ineq"], d["b_lower"], d["b_upper"])
+    lp2 = copy.deepcopy(lp)
+    lp2.convert_to_one_sided_inequality_system()
+    assert lp2.check_solution(gt)
+    return lp2, gt, np.arange(len(gt))
+
+
+def kernel_kats():
+    """F3/F4: isolated known-answer vectors for the native kernels."""
+    import scipy.sparse
+    from pysparselp.gaussSiedel import boundedGaussSeidelClass
+    from pysparselp.tools import precondition_constraints, convert_to_standard_form_with_bounds
+    from oracle import oracle
+
+    rng = np.random.RandomState(7)
+    out = {}
+    # -- SpMV / SpMV^T incl. empty rows/cols, unsorted rows
+    a = scipy.sparse.random(57, 43, density=0.15, random_state=rng, format="csr")
+    a.data = np.round(rng.randn(a.nnz) * 100) / 100
+    a = a.tolil()
+    a[5, :] = 0
+    a[:, 7] = 0
+    a = a.tocsr()
+    a.eliminate_zeros()
+    perm_a = a.copy()
+    for i in range(a.shape[0]):  # shuffle entries inside rows
+        s, e = a.indptr[i], a.indptr[i + 1]
+        p = rng.permutation(e - s)
+        perm_a.indices[s:e] = a.indices[s:e][p]
+        perm_a.data[s:e] = a.data[s:e][p]
+    perm_a.has_sorted_indices = False
+    x = rng.randn(43)
+    y = rng.randn(57)
+    ax = perm_a * x
+    ya = y * perm_a
+    oa = oracle.as_csr(perm_a)
+    assert np.array_equal(ax, oracle.matvec(oa, x)) and np.array_equal(ya, oracle.rmatvec(oa, y))
+    for k, v in csr_parts(perm_a).items():
+        out[f"spmv_A_{k}"] = v
+    out.update(spmv_x=x, spmv_y=y, spmv_Ax=ax, spmv_yA=ya)
+    # -- bounded Gauss-Seidel on an SPD matrix, +-inf bounds, w != 1, 3 sweeps
+    b0 = scipy.sparse.random(40, 40, density=0.1, random_state=rng, format="csr")
+    m = (b0.T * b0 + 2.5 * scipy.sparse.eye(40)).tocsr()
+    rhs = rng.randn(40)
+    lo = np.where(rng.rand(40) < 0.3, -np.inf, -0.2 * rng.rand(40))
+    hi = np.where(rng.rand(40) < 0.3, np.inf, 0.2 * rng.rand(40))
+    for tag, w, iters in (("a", 1.0, 1), ("b", 1.3, 3)):
+        xg = rng.randn(40)
+        x_in = xg.copy()
+        boundedGaussSeidelClass(m).solve(rhs, lo, hi, xg, maxiter=iters, w=w)
+        xo = x_in.copy()
+        oracle.BoundedGaussSeidel(m).solve(rhs, lo, hi, xo, maxiter=iters, w=w)
+        assert np.array_equal(xg, xo)
+        out[f"gs_{tag}_x0"] = x_in
+        out[f"gs_{tag}_x"] = xg
+        out[f"gs_{tag}_w"] = np.array(w)
+        out[f"gs_{tag}_iters"] = np.array(iters)
+    for k, v in csr_parts(m).items():
+        out[f"gs_M_{k}"] = v
+    out.update(gs_b=rhs, gs_lo=lo, gs_hi=hi)
+    # -- ADMM setup chain on a random LP: ADMM.py:76-101 evaluated with the reference's own helpers
+    ae = scipy.sparse.random(6, 30, density=0.3, random_state=rng, format="csr")
+    ae.data = np.round(rng.randn(ae.nnz) * 100) / 100
+    ai = scipy.sparse.random(25, 30, density=0.2, random_state=rng, format="csr")
+    ai.data = np.round(rng.randn(ai.nnz) * 100) / 100
+    ae.__dict__["blocks"] = []
+    ai.__dict__["blocks"] = []
+    be = rng.randn(6)
+    bl = np.where(rng.rand(25) < 0.5, -np.inf, -rng.rand(25))
+    bu = np.where(rng.rand(25) < 0.2, np.inf, rng.rand(25))
+    c = rng.randn(30)
+    lb = -rng.rand(30)
+    ub = rng.rand(30)
+    x0 = np.zeros(30)
+    ae1, be1 = precondition_constraints(ae, be, alpha=2)
+    ai1, bl1, bu1 = precondition_constraints(ai, bl, bu, alpha=2)
+    c2, a2, b2, lb2, ub2, x02 = convert_to_standard_form_with_bounds(c, ae1, be1, ai1, bl1, bu1, lb, ub, x0)
+    a3, b3 = precondition_constraints(a2, b2, alpha=2)
+    ata = a3.T * a3
+    atb = a3.T * b3
+    mm = (2 * ata + 3 * scipy.sparse.eye(a3.shape[1], a3.shape[1])).tocsr()
+    s = oracle.admm_setup(c, ae, be, ai, bl, bu, lb, ub)
+    for ref, got in ((a3, s["a"]), (mm, s["m"])):
+        assert np.array_equal(ref.indptr, got.indptr) and np.array_equal(ref.indices, got.indices)
+        assert np.array_equal(ref.data, got.data), np.max(np.abs(ref.data - got.data))
+    assert np.array_equal(b3, s["b"]) and np.array_equal(atb, s["atb"])
+    assert np.array_equal(lb2, s["lb"]) and np.array_equal(ub2, s["ub"]) and np.array_equal(c2, s["c"])
+    for tag, mat in (("Ae", ae), ("Ai", ai), ("A3", a3), ("M", mm)):
+        for k, v in csr_parts(mat).items():
+            out[f"setup_{tag}_{k}"] = v
+    out.update(setup_be=be, setup_bl=bl, setup_bu=bu, setup_c=c, setup_lb=lb, setup_ub=ub,
+               setup_b3=b3, setup_atb=atb, setup_lb2=lb2, setup_ub2=ub2, setup_c2=c2,
+               setup_invD=1 / mm.diagonal())
+    np.savez_compressed(os.path.join(HERE, "kernel_kats.npz"), **out)
+    print("  kernel_kats: spmv, gauss-seidel, admm setup chain (oracle bit-exact)")
+
+
+def known_answers():
+    """tests/test_kmedians.py:11-14 and tests/test_l1_svm.py:12-26: capture the LP each example
+    hands to SparseLP.solve, the solution the reference returns and the asserted end value."""
+    import contextlib
+    import copy
+    import io
+    from pysparselp import SparseLP as ref_mod
+    from pysparselp.examples import example_kmedians, example_l1_svm
+    from oracle import oracle
+
+    sink = io.StringIO()
+    calls = []
+    orig = ref_mod.SparseLP.solve
+
+    def spy(self, *a, **kw):
+        lp0 = copy.deepcopy(self)
+        res = orig(self, *a, **kw)
+        calls.append((lp0, kw, res))
+        return res
+
+    ref_mod.SparseLP.solve = spy
+    try:
+        with contextlib.redirect_stdout(sink):
+            cost = example_kmedians.run(display=False)
+        assert cost == 238.9849948936172
+        lp0, kw, res = calls[-1]
+        assert kw["method"] == "admm"
+        sol = res[0]
+        xo = oracle.lp_admm(*solver_inputs(lp0), nb_iter=kw["nb_iter"], nb_iter_plot=kw["nb_iter_plot"])
+        assert np.array_equal(xo, sol), np.max(np.abs(xo - sol))
+        out = lp_arrays(lp0)
+        # what the example needs to turn the solution into its asserted cost (example_kmedians.py:46-58)
+        prng = np.random.RandomState(0)
+        centers = prng.randn(5, 2)
+        gt_labels = np.floor(prng.rand(500) * 5).astype(np.int64)
+        points = 0.4 * prng.randn(500, 2) + centers[gt_labels, :]
+        out.update(solution=sol, cost=np.array(cost), nb_iter=np.array(kw["nb_iter"]),
+                   nb_iter_plot=np.array(kw["nb_iter_plot"]), points=points)
+        np.savez_compressed(os.path.join(HERE, "ka_kmedians.npz"), **out)
+        print(f"  kmedians: cost {cost!r}; oracle admm solution bit-exact")
+        calls.clear()
+        # only the two hot-path methods (the full tuple always lists "osqp", absent here: SparseLP.py:45-46);
+        # the five names run() removes must be present for its list.remove calls
+        example_l1_svm.solving_methods = ("mehrotra", "scipy_simplex", "scipy_interior_point", "dual_gradient_ascent",
+                                          "dual_coordinate_ascent", "chambolle_pock_ppd", "admm")
+        with contextlib.redirect_stdout(sink):
+            percent = example_l1_svm.run(display=False)
+        expected = json.load(open(os.path.join(REF_SRC, "tests", "test_l1_svm_results.json")))
+        out = None
+        for lp0, kw, res in calls:
+            m = kw["method"]
+            if m not in ("admm", "chambolle_pock_ppd"):
+                continue
+            assert percent[m] == expected[m]
+            if out is None:
+                out = lp_arrays(lp0)
+            tag = "admm" if m == "admm" else "cp"
+            out[f"{tag}_solution"] = res[0]
+            out[f"{tag}_percent"] = np.array(percent[m])
+            if m == "admm":
+                xo = oracle.lp_admm(*solver_inputs(lp0), nb_iter=kw["nb_iter"], nb_iter_plot=10)
+                assert np.array_equal(xo, res[0])
+        out["nb_iter"] = np.array(2000)
+        np.savez_compressed(os.path.join(HERE, "ka_l1svm.npz"), **out)
+        print(f"  l1svm: admm {percent['admm']} cp {percent['chambolle_pock_ppd']}; oracle admm solution bit-exact")
+    finally:
+        ref_mod.SparseLP.solve = orig
+
+
+def main():
+    build_reference()
+    install_shims()
+    import contextlib
+    import io
+    from pysparselp import randomLP  # noqa: F401  (import check of the patched copy)
+
+    sink = io.StringIO()
+    print("kernel KATs")
+    kernel_kats()
+    early = list(range(0, 12)) + [20, 50, 100, 200, 500, 1000, 2000]
+    print("LP fixtures")
+    for name in ("SC50A", "SC105"):
+        lp, gt, idx = netlib_lp(name)
+        run_case(name.lower(), lp, early, 2000, gt, idx, curve_iters=20000)
+    # Potts (examples/example_pott_segmentation.py:54-92)
+    from pysparselp.examples.example_pott_segmentation import build_linear_program
+    for size, nit, curve in ((8, 1000, 2000), (50, 1000, 10000)):
+        with contextlib.redirect_stdout(sink):
+            lp, gt, idx, _ = build_linear_program(size, 0.5, 500)
+        keep = [0, 1, 2, 3, 10, 100, 500, 1000] if size == 50 else early
+        run_case(f"potts{size}", lp, keep, nit, gt, idx, curve_iters=curve)
+    # random LPs (randomLP.py:29-75), three seeds
+    for seed in (0, 1, 2):
+        np.random.seed(seed)
+        lp, feas = randomLP.generate_random_lp(nbvar=60, n_eq=10, n_ineq=80, sparsity=0.2)
+        run_case(f"random{seed}", lp, early, 2000)
+    print("known answers")
+    known_answers()
+    # reference goldens kept as data (they are data files of the reference's tests)
+    for f in ("netlib_curves_SC105.json", "test_pott_segmentation_curves.json", "test_l1_svm_results.json"):
+        d = json.load(open(os.path.join(REF_SRC, "tests", f)))
+        d = {k: v for k, v in d.items() if k in ("admm", "chambolle_pock_ppd")}
+        json.dump(d, open(os.path.join(HERE, "ref_" + f), "w"))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
