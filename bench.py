@@ -1,0 +1,210 @@
+"""Headline benchmark: first-order LP iterations per second on a synthetic random sparse LP.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one solver iteration (all SpMV / SpMV^T passes, projections and
+multiplier updates of that iteration) on the synthetic random LP of
+randomLP.py:29-75, generated on the GPU and resident in HBM before the timed
+region.  N = 1 runs BASELINE.json config 3 (1e6 variables, 2e6 inequality
+rows, density 1e-3: 2e9 stored entries) -- config 4 (1e7 x 2e7 at 1e-3 =
+2.4 TB of CSR) does not fit 8 x 288 GB, see DESIGN.md.  N > 1 row-partitions
+the SAME problem over the N GPUs (strong scaling, one RCCL all-reduce of the n
+partial column sums per SpMV^T); launched by the driver as
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying
+``roofline`` (CSR SpMV kernel, algorithmic bytes / HIP-event time, against the
+8 TB/s HBM peak) and ``cpu_baseline`` (the oracle = CPU restatement of the
+reference algorithm, single thread, on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# the HIP library first: bench never needs torch on one GPU, and with N > 1 torch (gloo control
+# plane only) must find libamdhip64 already resolved to the system ROCm this library was built for
+from pysparselp_amd import _lib  # noqa: E402
+from pysparselp_amd.device import DeviceMatrix  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--n", type=int, default=1_000_000, help="variables")
+    p.add_argument("--m", type=int, default=2_000_000, help="inequality constraints")
+    p.add_argument("--density", type=float, default=1e-3)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--method", default="admm", choices=["admm", "chambolle_pock_ppd"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-n", type=int, default=100_000)
+    return p.parse_args()
+
+
+def spmv_bytes(nnz, rows, cols):
+    """algorithmic bytes of y = A x (fp64 values, int32 columns, int64 row pointer)."""
+    return 12 * nnz + 8 * (rows + 1) + 8 * cols + 8 * rows
+
+
+def cp_iter_bytes(nnz, m, n):
+    return 24 * nnz + 8 * (m + 1) + 8 * (n + 1) + 8 * (8 * n + 5 * m)
+
+
+def cpu_baseline(args, method):
+    """Oracle (port of the reference algorithm, 1 thread) on a bounded sample of the same workload:
+    the same generator at n/10 x m/10 (1/100 of the stored entries), a few iterations."""
+    from oracle import oracle
+
+    scale = max(1, args.n // args.cpu_sample_n)
+    n, m = args.n // scale, args.m // scale
+    a = DeviceMatrix.random(m, n, args.density, args.seed)
+    xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed)
+    s = a.download()
+    a.close()
+    iters = 8
+    t0 = time.perf_counter()
+    if method == "chambolle_pock_ppd":
+        oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9)
+    else:
+        oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
+    dt = time.perf_counter() - t0
+    its = iters / dt
+    full_nnz = args.n * args.m * args.density
+    return {
+        "value": its * (s.nnz / full_nnz),
+        "unit": "it/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"same generator at {n} x {m}, density {args.density} ({s.nnz} stored entries), {iters} iterations incl. setup: "
+                  f"{its:.3f} it/s measured; value = that rate scaled by the stored-entry ratio to the full problem",
+        "measured_it_per_s_on_sample": its,
+        "host_cores_present": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    lib = _lib.lib(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # gloo, CPU: control plane only (RCCL id exchange)
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import ctypes
+
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.slp_comm_unique_id(uid))
+        box = [uid.raw]
+        dist.broadcast_object_list(box, src=0)
+        _lib.check(lib.slp_comm_init(world, rank, ctypes.create_string_buffer(box[0], 128)))
+
+    # ---- the workload: this rank's row block, generated in HBM
+    rows_per = (args.m + world - 1) // world
+    r0 = min(rank * rows_per, args.m)
+    rows = min(rows_per, args.m - r0)
+    t_gen = time.perf_counter()
+    a = DeviceMatrix.random(rows, args.n, args.density, args.seed, r0)
+    xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed, r0)
+    nnz_local = a.nnz
+    from pysparselp_amd.scale import make_solver
+
+    solver = make_solver(args.method, a, b, c, lb, ub)
+    _lib.check(lib.slp_synchronize())
+    t_gen = time.perf_counter() - t_gen
+
+    # ---- timed region: W warm-up steps, then exactly K steps between two barriers
+    solver.iterate(args.warmup)
+    _lib.check(lib.slp_comm_barrier())
+    t0 = time.perf_counter()
+    solver.iterate(args.steps)
+    _lib.check(lib.slp_comm_barrier())
+    dt = time.perf_counter() - t0
+    tmax = np.array([dt])
+    _lib.check(lib.slp_comm_allreduce_host(_lib.ptr(tmax), 1, 1))
+    dt = float(tmax[0])
+
+    nnz = np.array([float(nnz_local)])
+    _lib.check(lib.slp_comm_allreduce_host(_lib.ptr(nnz), 1, 0))
+    nnz_total = int(nnz[0])
+    obj = solver.objective()
+
+    if rank == 0:
+        ms_step = 1e3 * dt / args.steps
+        # dominant kernel: the CSR SpMV (both orientations stream 12 B per stored entry)
+        reps = 5
+        ms_ax = a.bench_spmv(False, reps=reps)
+        ms_aty = a.bench_spmv(True, reps=reps)
+        b_ax = spmv_bytes(nnz_local, rows, args.n)
+        b_aty = spmv_bytes(nnz_local, args.n, rows)
+        gbs_ax = b_ax / (ms_ax * 1e-3) / 1e9
+        gbs_aty = b_aty / (ms_aty * 1e-3) / 1e9
+        passes = solver.matrix_passes_per_iteration()
+        out = {
+            "metric": f"{'admm' if args.method == 'admm' else 'chambolle_pock'}_iterations_per_sec",
+            "value": args.steps / dt,
+            "unit": "it/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"randomLP synthetic: {args.n} vars, {args.m} inequality rows, density {args.density}, "
+                            f"{nnz_total} stored entries, method {args.method} ({solver.describe()}), "
+                            f"rows partitioned over {world} GPU(s)",
+                "n": args.n, "m": args.m, "density": args.density, "seed": args.seed, "nnz": nnz_total,
+                "method": args.method, "matrix_passes_per_iteration": passes,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_spmv (CSR SpMV y = A x, rank 0's row block)",
+                "achieved": gbs_ax,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": gbs_ax / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": b_ax,
+                "ms_per_launch": ms_ax,
+                "spmv_transposed": {"achieved": gbs_aty, "frac": gbs_aty / HBM_PEAK_GBS, "ms_per_launch": ms_aty,
+                                    "algorithmic_bytes_per_launch": b_aty},
+                "iteration": {"algorithmic_bytes": passes * 12 * nnz_total,
+                              "achieved": passes * 12 * nnz_total / dt * args.steps / 1e9,
+                              "frac_of_all_gpus": passes * 12 * nnz_total / dt * args.steps / 1e9 / (HBM_PEAK_GBS * world)},
+            },
+            "objective_after_run": obj,
+            "setup_seconds": t_gen,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.method)
+        print(json.dumps(out), flush=True)
+    solver.close()
+    a.close()
+    if world > 1:
+        _lib.check(lib.slp_comm_barrier())
+        _lib.check(lib.slp_comm_finalize())
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

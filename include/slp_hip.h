@@ -1,0 +1,186 @@
+/*
+ * slp_hip.h -- C ABI of libslp_hip.so: the MI355X (gfx950) device side of the
+ * first-order sparse-LP hot path of PySparseLP (Chambolle-Pock and ADMM behind
+ * SparseLP.solve(method=...)).
+ *
+ * Plain pointers and sizes only; the library copies what it is given to the
+ * GPU and never keeps a host pointer after a call returns.  One host thread
+ * per handle, one HIP stream per process (slp_init).  Every function that
+ * returns int returns 0 on success; a function that returns a handle returns
+ * NULL on failure; slp_last_error() then describes the failure (including
+ * "no HIP device": there is no CPU fallback anywhere in the library).
+ *
+ * Reference citations are file:line under the reference tree's pysparselp/.
+ * All values are IEEE double, column indices int32, row pointers int64.
+ * Matrices are CSR; entries inside a row are used in the order given (the
+ * reference never sorts them on this path).
+ */
+#ifndef SLP_HIP_H
+#define SLP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Summation order of the per-row / per-column dot products.
+ * SLP_ORDER_SEQUENTIAL: one thread walks a row in storage order, one rounding
+ *   per multiply and per add -- bit-identical to scipy's csr_matvec /
+ *   csc_matvec as called by the reference.
+ * SLP_ORDER_TREE: a row is spread over 2..64 lanes of a wavefront and reduced
+ *   with cross-lane shuffles -- same terms, different association (fp64
+ *   rounding differences only).
+ * SLP_ORDER_AUTO: SEQUENTIAL while the mean row length is <= 16, else TREE. */
+enum { SLP_ORDER_AUTO = 0, SLP_ORDER_SEQUENTIAL = 1, SLP_ORDER_TREE = 2 };
+
+/* ---- library / device -------------------------------------------------- */
+int slp_version(void);
+/* Number of HIP devices visible, or -1 (see slp_last_error). */
+int slp_device_count(void);
+/* Bind this process to `device` and create the library's stream. */
+int slp_init(int device);
+int slp_synchronize(void);
+const char *slp_last_error(void);
+/* Milliseconds the GPU spent between the two most recent slp_timer_start /
+ * slp_timer_stop marks on the library's stream (HIP events). */
+int slp_timer_start(void);
+int slp_timer_stop(double *ms);
+
+/* ---- sparse matrix: replaces the scipy.sparse.csr_matrix operands ------- *
+ * `a * x`  -> scipy csr_matvec (ChambollePockPPD.py:235,240 ; ADMM.py:220,262)
+ * `y * a`  -> scipy csc_matvec over a.T (ChambollePockPPD.py:206,216 ;
+ *             ADMM.py:95,148).  The transposed copy is built on the device. */
+typedef struct slp_matrix slp_matrix;
+slp_matrix *slp_matrix_create(int64_t nrow, int64_t ncol, const int64_t *indptr,
+                              const int32_t *indices, const double *data);
+void slp_matrix_destroy(slp_matrix *a);
+int64_t slp_matrix_nnz(const slp_matrix *a);
+/* y[nrow] = A x[ncol]   (host vectors in, host vector out) */
+int slp_matrix_spmv(slp_matrix *a, const double *x, double *y, int order);
+/* out[ncol] = A^T y[nrow] */
+int slp_matrix_spmv_t(slp_matrix *a, const double *y, double *out, int order);
+/* Copies of the device arrays: CSR (transposed = 0) or the device-built
+ * transposed CSR, i.e. CSC of A (transposed = 1).  Any pointer may be NULL. */
+int slp_matrix_download(slp_matrix *a, int transposed, int64_t *indptr,
+                        int32_t *indices, double *data);
+/* Device-resident benchmark kernels: `reps` back-to-back launches on resident
+ * vectors, no host traffic; *ms = average GPU time per launch (HIP events). */
+int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, double *ms);
+
+/* ---- Chambolle-Pock: replaces chambolle_pock_ppd's loop ----------------- *
+ * ChambollePockPPD.py:122-179 (preconditioners T, Sigma) and :195-343 (loop).
+ * K = [A_eq; A_ineq] stacked by rows (m_eq rows first), b = [b_eq; b_ineq]
+ * with the inequalities already one-sided (K_ineq x <= b_ineq, :74-88).
+ * State: x = x0 (zeros if NULL), y = 0.  One iteration:
+ *   d = (c + A_eq^T y_eq) + A_ineq^T y_ineq ; x+ = clip(x - T d, lb, ub)
+ *   z = (1+theta) x+ - theta x ; x = x+
+ *   y_eq += S_eq (A_eq z - b_eq) ; y_ineq = max(y_ineq + S_ineq (A_ineq z - b_ineq), 0) */
+typedef struct slp_cp slp_cp;
+slp_cp *slp_cp_create(int64_t n, int64_t m_eq, int64_t m_ineq, const int64_t *indptr,
+                      const int32_t *indices, const double *data, const double *b,
+                      const double *c, const double *lb, const double *ub,
+                      const double *x0, double alpha, double theta, int order);
+void slp_cp_destroy(slp_cp *s);
+/* k whole iterations, enqueued without host synchronisation. */
+int slp_cp_iterate(slp_cp *s, int64_t k);
+/* The two halves of one iteration, for the iterations on which the reference
+ * reports (:242-329 sits between the residual :231-240 and the dual update
+ * :333-342): primal_step, then slp_cp_report, then dual_step. */
+int slp_cp_primal_step(slp_cp *s);
+int slp_cp_dual_step(slp_cp *s);
+/* out[0] energy1 (:248,267,271)  out[1] energy2 (:260-272)
+ * out[2] max |A_eq z - b_eq| (:269; 0 without equalities)
+ * out[3] max (A_ineq x - b_ineq) (:283; -inf without inequalities)
+ * out[4] max |A_eq x - b_eq| (:280; 0 without equalities) */
+int slp_cp_report(slp_cp *s, double out[5]);
+int slp_cp_get_x(slp_cp *s, double *x);                 /* n  */
+int slp_cp_get_y(slp_cp *s, double *y);                 /* m_eq + m_ineq */
+int slp_cp_get_preconditioners(slp_cp *s, double *t, double *sigma); /* n, m */
+/* Average GPU milliseconds per iteration over `k` iterations (HIP events on
+ * the library stream) and per kernel: ms[0] iteration, ms[1] primal kernel
+ * (SpMV^T + update), ms[2] dual kernel (SpMV + update). */
+int slp_cp_bench(slp_cp *s, int64_t k, double ms[3]);
+
+/* ---- projected Gauss-Seidel: replaces gaussSiedel.pyx ------------------- *
+ * boundedGaussSeidelClass.__init__ (gaussSiedel.pyx:87-92) and .solve
+ * (:95-153).  The sweep keeps the reference's lexicographic data dependence
+ * (row i sees rows < i updated, rows > i not yet) through a level schedule, so
+ * x is bit-identical to the sequential sweep. */
+typedef struct slp_gs slp_gs;
+slp_gs *slp_gs_create(int64_t n, const int64_t *indptr, const int32_t *indices,
+                      const double *data);
+void slp_gs_destroy(slp_gs *g);
+int64_t slp_gs_num_levels(const slp_gs *g);
+/* x[n] is updated in place (host buffer), maxiter sweeps, relaxation w;
+ * lower/upper may hold -inf/+inf. */
+int slp_gs_solve(slp_gs *g, const double *b, const double *lower, const double *upper,
+                 double *x, int maxiter, double w);
+
+/* ---- ADMM: replaces lp_admm's loop (ADMM.py:143-268) -------------------- *
+ * Inputs are the standard-form, row-normalised problem of ADMM.py:76-101:
+ * A (m x N), b, c, lb, ub, x0 (all length N resp. m), M = gamma_eq A^T A +
+ * gamma_ineq I (N x N, CSR).  One iteration:
+ *   y = -c + gamma_eq A^T b + gamma_ineq xp - A^T lambda      (:148)
+ *   one projected Gauss-Seidel sweep of M x = y, in place on x (:162)
+ *   xp = x (alias, :259) ; lambda += gamma_eq (A x - b)        (:261-263) */
+typedef struct slp_admm slp_admm;
+slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr,
+                          const int32_t *a_indices, const double *a_data,
+                          const double *b, const double *c, const double *lb,
+                          const double *ub, const double *x0, const int64_t *m_indptr,
+                          const int32_t *m_indices, const double *m_data,
+                          double gamma_eq, double gamma_ineq, int order);
+void slp_admm_destroy(slp_admm *s);
+int slp_admm_iterate(slp_admm *s, int64_t k);
+/* Halves of one iteration around the reference's report (:213-248). */
+int slp_admm_sweep_step(slp_admm *s);
+int slp_admm_multiplier_step(slp_admm *s);
+/* out[0] augmented-Lagrangian energy (:124-132)  out[1] max |A x - b| (:221)
+ * out[2] max(0, -min x) (:222) */
+int slp_admm_report(slp_admm *s, double out[3]);
+int slp_admm_get_x(slp_admm *s, double *x, int64_t count); /* first `count` entries */
+int slp_admm_get_lambda(slp_admm *s, double *lam);          /* m */
+int64_t slp_admm_num_levels(const slp_admm *s);
+int slp_admm_bench(slp_admm *s, int64_t k, double *ms);
+
+/* ---- synthetic random LP on the device (randomLP.py:14-75) -------------- *
+ * Row r of A_ineq (global row index row_offset + r): every entry is non-zero
+ * with probability `density`, value round(N(0,1)*100)/100, exact zeros
+ * dropped (:14-26).  Counter-based generator keyed by (seed, global row), so
+ * any row block can be regenerated on any GPU.  Rows come out sorted by
+ * column. */
+slp_matrix *slp_matrix_random(int64_t nrow, int64_t ncol, double density,
+                              uint64_t seed, int64_t row_offset);
+/* The vectors of the same LP, keyed by (seed, global index):
+ * feasible_x, c, lb, ub of length n (:33,51-55) and, for the local rows of
+ * `a`, b_upper = ceil((A feasible_x + |rand_sparse|) * 1000) / 1000 (:43-46).
+ * Host output buffers; any may be NULL. */
+int slp_random_lp_vectors(slp_matrix *a, double density, uint64_t seed, int64_t row_offset,
+                          double *feasible_x, double *c, double *lb, double *ub,
+                          double *b_upper);
+/* Chambolle-Pock state over a device-resident matrix (no host copy of A):
+ * all rows are inequalities; takes ownership of nothing (a must outlive it). */
+slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const double *c,
+                         const double *lb, const double *ub, const double *x0,
+                         double alpha, double theta, int order);
+
+/* ---- multi-GPU: constraint rows partitioned over the GPUs of one node --- *
+ * No counterpart in the reference (single process).  Each rank owns a row
+ * block of K and the matching slices of b, y, Sigma; x, z, c, T, lb, ub are
+ * replicated.  Per iteration one RCCL sum-all-reduce of the n partial column
+ * sums K_g^T y_g; the preconditioner T needs one all-reduce at setup; report
+ * scalars are reduced with sum/max all-reduces.  RCCL is loaded with dlopen on
+ * first use, so single-GPU use does not depend on it. */
+int slp_comm_unique_id(char id[128]);
+int slp_comm_init(int nranks, int rank, const char id[128]);
+int slp_comm_finalize(void);
+/* In-place all-reduce of a small host vector (op: 0 sum, 1 max) through the
+ * device, for bench timing and report scalars. */
+int slp_comm_allreduce_host(double *v, int64_t count, int op);
+int slp_comm_barrier(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLP_HIP_H */

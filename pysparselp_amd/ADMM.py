@@ -1,0 +1,134 @@
+"""ADMM LP solver: host driver over the HIP kernels.
+
+Drop-in for ``pysparselp.ADMM.lp_admm`` (reference ADMM.py:47-269) as shipped,
+i.e. with the x-step solved by ONE sweep of box-projected Gauss-Seidel on the
+explicit ``M = gamma_eq A^T A + gamma_ineq I`` (flags at ADMM.py:66-71).  Same
+signature, callback contract and return value (the first ``n`` entries of the
+standard-form iterate).
+
+Setup (row normalisation, slack standard form, ``M``) is done once on the host,
+like in the reference (tools.py of this package); the loop -- right-hand side
+with ``A^T lambda``, the level-scheduled Gauss-Seidel sweep, the multiplier
+update with ``A x`` and the report reductions -- runs on the GPU
+(pysparselp_amd/csrc/slp_admm.hip).
+"""
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import ORDER_AUTO
+from .tools import convert_to_standard_form_with_bounds, normal_matrix, precondition_constraints
+
+
+class ADMMState:
+    """Device-resident ADMM state (thin RAII wrapper of ``slp_admm``)."""
+
+    def __init__(self, a, b, c, lb, ub, x0, m, gamma_eq, gamma_ineq, order=ORDER_AUTO):
+        self._l = _lib.lib()
+        self.N = a.shape[1]
+        self.m = a.shape[0]
+        b, c, lb, ub, x0 = (_lib.f64(v) for v in (b, c, lb, ub, x0))
+        assert b.size == self.m and c.size == self.N and lb.size == self.N and ub.size == self.N and x0.size == self.N
+        self._h = _lib.check_handle(self._l.slp_admm_create(
+            self.N, self.m, _lib.ptr(a.indptr), _lib.ptr(a.indices), _lib.ptr(a.data), _lib.ptr(b), _lib.ptr(c),
+            _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(x0), _lib.ptr(m.indptr), _lib.ptr(m.indices), _lib.ptr(m.data),
+            float(gamma_eq), float(gamma_ineq), int(order)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.slp_admm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def iterate(self, k):
+        _lib.check(self._l.slp_admm_iterate(self._h, int(k)))
+
+    def sweep_step(self):
+        _lib.check(self._l.slp_admm_sweep_step(self._h))
+
+    def multiplier_step(self):
+        _lib.check(self._l.slp_admm_multiplier_step(self._h))
+
+    def report(self):
+        out = np.zeros(4)
+        _lib.check(self._l.slp_admm_report(self._h, _lib.ptr(out)))
+        return out
+
+    def x(self, count=None):
+        count = self.N if count is None else int(count)
+        out = np.empty(count)
+        _lib.check(self._l.slp_admm_get_x(self._h, _lib.ptr(out), count))
+        return out
+
+    def lam(self):
+        out = np.empty(self.m)
+        _lib.check(self._l.slp_admm_get_lambda(self._h, _lib.ptr(out)))
+        return out
+
+    def num_levels(self):
+        return int(self._l.slp_admm_num_levels(self._h))
+
+    def bench(self, k):
+        ms = np.zeros(1)
+        _lib.check(self._l.slp_admm_bench(self._h, int(k), _lib.ptr(ms)))
+        return float(ms[0])
+
+
+def lp_admm(
+    c,
+    a_eq,
+    beq,
+    a_ineq,
+    b_lower,
+    b_upper,
+    lb,
+    ub,
+    x0=None,
+    gamma_eq=2,
+    gamma_ineq=3,
+    nb_iter=100,
+    callback_func=None,
+    max_time=None,
+    use_preconditioning=True,
+    nb_iter_plot=10,
+    order=ORDER_AUTO,
+):
+    """minimise c.x  s.t.  a_eq x = beq,  b_lower <= a_ineq x <= b_upper,  lb <= x <= ub."""
+    c = _lib.f64(c)
+    n = c.size
+    if x0 is None:
+        x0 = np.zeros(n)
+    # ADMM.py:76-91: scale the rows, add one slack per inequality, scale the stacked rows again
+    if a_eq is not None:
+        a_eq, beq = precondition_constraints(a_eq, beq, alpha=2)
+    if a_ineq is not None:
+        a_ineq, b_lower, b_upper = precondition_constraints(a_ineq, b_lower, b_upper, alpha=2)
+    c2, a, b, lb2, ub2, x_init = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
+    if use_preconditioning:
+        a, b = precondition_constraints(a, b, alpha=2)
+    m_mat = normal_matrix(a, gamma_eq, gamma_ineq)  # ADMM.py:93-101
+
+    state = ADMMState(a, b, c2, lb2, ub2, x_init, m_mat, gamma_eq, gamma_ineq, order)
+    try:
+        start = time.perf_counter()
+        i = 0
+        while i <= nb_iter:  # ADMM.py:143: nb_iter + 1 sweeps
+            if i % nb_iter_plot == 0:
+                state.sweep_step()
+                elapsed = time.perf_counter() - start
+                if max_time is not None and elapsed > max_time:
+                    break
+                energy1, max_violated_equality, max_violated_inequality = state.report()[:3]
+                if callback_func is not None:
+                    callback_func(i, state.x(n), energy1, energy1, elapsed, max_violated_equality, max_violated_inequality)
+                state.multiplier_step()
+                i += 1
+            else:
+                k = min(nb_iter_plot - i % nb_iter_plot, nb_iter + 1 - i)
+                state.iterate(k)
+                i += k
+        return state.x(n)
+    finally:
+        state.close()

@@ -1,0 +1,314 @@
+"""``SparseLP``: the modelling front end and the ``solve(method=...)`` dispatch.
+
+Keeps the public surface of ``pysparselp.SparseLP.SparseLP`` that the
+first-order solvers need (reference SparseLP.py:162-1383): the LP is held as
+
+    minimise costsvector . x
+    s.t.     a_equalities x = b_equalities
+             b_lower <= a_inequalities x <= b_upper
+             lower_bounds <= x <= upper_bounds
+
+with scipy CSR matrices, and ``solve`` (reference :990-1002, :1064-1093,
+:1193-1208, :1243-1288, :1378-1383) runs one of the GPU solvers and fills the
+same convergence-curve attributes.  Only the two hot-path methods exist here:
+``"admm"`` and ``"chambolle_pock_ppd"``; the other solvers of the reference
+(interior point, dual ascent, external solver bridges, rounding heuristics,
+MPS export) are out of scope.
+"""
+import copy
+import time
+
+import numpy as np
+
+import scipy.sparse
+
+from .ADMM import lp_admm
+from .ChambollePockPPD import chambolle_pock_ppd
+from ._lib import ORDER_AUTO
+
+solving_methods = ("chambolle_pock_ppd", "admm")
+
+_SCALARS = (int, float, np.integer, np.floating)
+
+
+def empty_csr_matrix(ncols=0):
+    a = scipy.sparse.csr_matrix((0, ncols), dtype=np.float64)
+    a.__dict__["blocks"] = []
+    return a
+
+
+def _append_rows(a, b):
+    """Rows of ``b`` appended under ``a`` (entry order kept); records the row block like the reference."""
+    b = scipy.sparse.csr_matrix(b)
+    ncols = max(a.shape[1], b.shape[1])
+    blocks = a.__dict__.get("blocks", [])
+    blocks.append((a.shape[0], a.shape[0] + b.shape[0] - 1))
+    out = scipy.sparse.csr_matrix(
+        (np.concatenate((a.data, b.data.astype(np.float64))),
+         np.concatenate((a.indices, b.indices)).astype(np.int32),
+         np.concatenate((a.indptr[:-1], a.indptr[-1] + b.indptr)).astype(np.int32)),
+        shape=(a.shape[0] + b.shape[0], ncols))
+    out.__dict__["blocks"] = blocks
+    return out
+
+
+def _with_ncols(a, ncols):
+    out = scipy.sparse.csr_matrix((a.data, a.indices, a.indptr), shape=(a.shape[0], ncols))
+    out.__dict__["blocks"] = a.__dict__.get("blocks", [])
+    return out
+
+
+def crd_matrix(cols, vals):
+    """CSR matrix with the same number of candidate entries in every row:
+    ``m[i, cols[i, j]] = vals[i, j]``; zero values are not stored; a variable may
+    appear only once per row."""
+    cols, vals = np.broadcast_arrays(np.asarray(cols), np.asarray(vals, dtype=np.float64))
+    assert cols.ndim == 2
+    srt = np.sort(cols, axis=1)
+    if srt.shape[1] > 1 and np.any(srt[:, 1:] == srt[:, :-1]):
+        bad = np.nonzero(np.any(srt[:, 1:] == srt[:, :-1], axis=1))[0]
+        raise ValueError(f"the same variable appears twice in {len(bad)} constraint(s): {bad}")
+    keep = vals != 0
+    indptr = np.concatenate(([0], np.cumsum(keep.sum(axis=1))))
+    ncols = int(cols.max()) + 1 if cols.size else 0
+    return scipy.sparse.csr_matrix((vals[keep], cols[keep], indptr), shape=(cols.shape[0], ncols))
+
+
+class SparseLP:
+    """Sparse linear program + first-order GPU solvers."""
+
+    def __init__(self):
+        self.nb_variables = 0
+        self.variables_dict = dict()
+        self.upper_bounds = np.empty(0, dtype=np.float64)
+        self.lower_bounds = np.empty(0, dtype=np.float64)
+        self.costsvector = np.empty(0, dtype=np.float64)
+        self.is_integer = np.empty(0, dtype=bool)
+        self.a_inequalities = empty_csr_matrix()
+        self.b_lower = np.empty(0, dtype=np.float64)
+        self.b_upper = np.empty(0, dtype=np.float64)
+        self.a_equalities = empty_csr_matrix()
+        self.b_equalities = np.empty(0, dtype=np.float64)
+        self.solution = None
+
+    # ------------------------------------------------------------------ variables
+    def _bounds_as_arrays(self, shape, lower_bounds, upper_bounds):
+        def expand(v, default):
+            if v is None:
+                return np.full(shape, default, dtype=np.float64)
+            if isinstance(v, _SCALARS):
+                return np.full(shape, float(v), dtype=np.float64)
+            v = np.asarray(v, dtype=np.float64)
+            assert v.shape == tuple(shape)
+            return v
+
+        return expand(lower_bounds, -np.inf), expand(upper_bounds, np.inf)
+
+    def add_variables_array(self, shape, lower_bounds, upper_bounds, costs=0, name=None, is_integer=False):
+        """Append ``prod(shape)`` variables; returns their indices as an array of that shape."""
+        if isinstance(shape, (int, np.integer)):
+            shape = (int(shape),)
+        shape = tuple(int(s) for s in shape)
+        count = int(np.prod(shape))
+        indices = np.arange(count).reshape(shape) + self.nb_variables
+        self.nb_variables += count
+        self.a_inequalities = _with_ncols(self.a_inequalities, self.nb_variables)
+        self.a_equalities = _with_ncols(self.a_equalities, self.nb_variables)
+        if isinstance(costs, _SCALARS):
+            costs = np.full(shape, float(costs))
+        costs = np.asarray(costs, dtype=np.float64)
+        assert costs.shape == shape
+        lo, hi = self._bounds_as_arrays(shape, lower_bounds, upper_bounds)
+        self.lower_bounds = np.append(self.lower_bounds, lo.ravel())
+        self.upper_bounds = np.append(self.upper_bounds, hi.ravel())
+        self.costsvector = np.append(self.costsvector, costs.ravel())
+        self.is_integer = np.append(self.is_integer, np.full(count, is_integer, dtype=bool))
+        if name:
+            self.variables_dict[name] = indices
+        return indices
+
+    def get_variables_indices(self, name):
+        return self.variables_dict[name]
+
+    def get_variables_bounds(self):
+        return None, self.lower_bounds, self.upper_bounds
+
+    def set_costs_variables(self, indices, costs):
+        assert np.shape(costs) == np.shape(indices)
+        self.costsvector[np.ravel(indices)] = np.ravel(costs)
+
+    def set_bounds_on_variables(self, indices, lower_bounds, upper_bounds):
+        lo, hi = self._bounds_as_arrays(np.shape(indices), lower_bounds, upper_bounds)
+        self.lower_bounds[np.ravel(indices)] = lo.ravel()
+        self.upper_bounds[np.ravel(indices)] = hi.ravel()
+
+    # ---------------------------------------------------------------- constraints
+    def nb_equality_constraints(self):
+        return self.a_equalities.shape[0]
+
+    def nb_inequality_constraints(self):
+        return self.a_inequalities.shape[0]
+
+    def add_equality_constraints_sparse(self, a, b):
+        self.a_equalities = _append_rows(self.a_equalities, a)
+        self.b_equalities = np.append(self.b_equalities, b)
+
+    def add_inequality_constraints_sparse(self, a, lower_bounds=None, upper_bounds=None):
+        """Add ``lower_bounds <= a x <= upper_bounds``; a scalar ``lower == upper`` makes equalities."""
+        rows = a.shape[0]
+        if isinstance(lower_bounds, (int, float)) and not isinstance(lower_bounds, bool) and lower_bounds == upper_bounds:
+            self.a_equalities = _append_rows(self.a_equalities, a)
+            self.b_equalities = np.append(self.b_equalities, np.full(rows, float(lower_bounds)))
+            return
+        lo, hi = self._bounds_as_arrays((rows,), lower_bounds, upper_bounds)
+        self.a_inequalities = _append_rows(self.a_inequalities, a)
+        self.b_lower = np.append(self.b_lower, lo)
+        self.b_upper = np.append(self.b_upper, hi)
+
+    def add_inequality_constraints(self, cols, vals, lower_bounds=None, upper_bounds=None):
+        """``lower[i] <= sum_j vals[i, j] x[cols[i, j]] <= upper[i]`` for every row i."""
+        self.add_inequality_constraints_sparse(crd_matrix(cols, vals), lower_bounds=lower_bounds, upper_bounds=upper_bounds)
+
+    def add_equality_constraints(self, cols, vals, b):
+        self.add_inequality_constraints(cols, vals, lower_bounds=b, upper_bounds=b)
+
+    # ------------------------------------------------------------------ transforms
+    def convert_to_one_sided_inequality_system(self):
+        """``b_lower <= A x <= b_upper`` -> ``A' x <= b_upper'`` (finite upper rows, then negated finite lower rows)."""
+        if self.a_inequalities is None or self.b_lower is None:
+            return
+        up = np.nonzero(self.b_upper != np.inf)[0]
+        lo = np.nonzero(self.b_lower != -np.inf)[0]
+        a = self.a_inequalities
+        if len(lo) > 0 and len(up) > 0:
+            a = scipy.sparse.vstack((a[up, :], -a[lo, :])).tocsr()
+        elif len(lo) > 0:
+            a = -a
+        a.__dict__["blocks"] = [(0, a.shape[0] - 1)]
+        self.a_inequalities = a
+        self.b_upper = np.hstack((self.b_upper[up], -self.b_lower[lo]))
+        self.b_lower = None
+
+    def remove_fixed_variables(self):
+        """Drop the variables with ``upper == lower`` (reference :632-674).
+
+        Returns ``(free, shift)``: the boolean mask of kept variables and the
+        vector holding the fixed values; right-hand sides are moved accordingly.
+        """
+        free = self.upper_bounds > self.lower_bounds
+        shift = np.zeros(self.nb_variables)
+        shift[~free] = self.lower_bounds[~free]
+        self.b_equalities = self.b_equalities - self.a_equalities * shift
+        if self.b_lower is not None:
+            self.b_lower = self.b_lower - self.a_inequalities * shift
+        if self.b_upper is not None:
+            self.b_upper = self.b_upper - self.a_inequalities * shift
+        for name in ("a_inequalities", "a_equalities"):
+            a = getattr(self, name)
+            blocks = a.__dict__.get("blocks", [])
+            a = a[:, free]
+            a.__dict__["blocks"] = blocks
+            setattr(self, name, a)
+        self.costsvector = self.costsvector[free]
+        self.lower_bounds = self.lower_bounds[free]
+        self.upper_bounds = self.upper_bounds[free]
+        self.nb_variables = int(np.sum(free))
+        return free, shift
+
+    # ---------------------------------------------------------------------- checks
+    def max_constraint_violation(self, solution):
+        """Largest violation of any bound or constraint of the (unscaled) LP (reference :186-204)."""
+        worst = 0
+        worst = max(worst, np.max(self.lower_bounds - solution))
+        worst = max(worst, np.max(solution - self.upper_bounds))
+        if self.a_equalities.shape[0] > 0:
+            worst = max(worst, np.max(np.abs(self.a_equalities * solution - self.b_equalities)))
+        if self.a_inequalities.shape[0] > 0:
+            ax = self.a_inequalities * solution
+            if self.b_upper is not None:
+                worst = max(worst, np.max(ax - self.b_upper))
+            if self.b_lower is not None:
+                worst = max(worst, np.max(self.b_lower - ax))
+        return worst
+
+    def check_solution(self, solution, tol=1e-6):
+        return bool(self.max_constraint_violation(solution) < tol)
+
+    # ----------------------------------------------------------------------- solve
+    def solve(
+        self,
+        method="admm",
+        get_timing=True,
+        x0=None,
+        nb_iter=10000,
+        max_time=None,
+        callback_func=None,
+        nb_iter_plot=10,
+        plot_solution=None,
+        ground_truth=None,
+        ground_truth_indices=None,
+        order=ORDER_AUTO,
+    ):
+        """Run a first-order solver on the GPU; returns ``(x, elapsed)`` or ``x``.
+
+        Fills, at every report (every ``nb_iter_plot`` iterations): ``itrn_curve,
+        opttime_curve, dopttime_curve, pobj_curve, dobj_curve,
+        max_violated_constraint, max_violated_equality, max_violated_inequality,
+        distance_to_ground_truth, distanceToGroundTruthAfterRounding``.
+        As in the reference, ``callback_func`` is accepted and unused (it is
+        shadowed by the internal bookkeeping callback, reference :997,:1064).
+        """
+        if method not in solving_methods:
+            raise ValueError(f"method {method!r} not valid; available methods: {solving_methods}")
+        a_ineq = self.a_inequalities if (self.a_inequalities is not None and self.a_inequalities.shape[0] > 0) else None
+        a_eq, b_eq = (self.a_equalities, self.b_equalities) if self.a_equalities.shape[0] > 0 else (None, None)
+        if a_ineq is not None:
+            assert a_ineq.indices.size == 0 or a_ineq.indices.max() < a_ineq.shape[1]
+        start = time.perf_counter()
+        for name in ("distance_to_ground_truth", "distanceToGroundTruthAfterRounding", "opttime_curve", "dopttime_curve",
+                     "pobj_curve", "dobj_curve", "pobjbound", "max_violated_inequality", "max_violated_equality",
+                     "max_violated_constraint", "itrn_curve"):
+            setattr(self, name, [])
+
+        def record(niter, solution, energy1, energy2, duration, max_violated_equality, max_violated_inequality):
+            if ground_truth is not None:
+                picked = solution[ground_truth_indices]
+                self.distance_to_ground_truth.append(np.mean(np.abs(ground_truth - picked)))
+                self.distanceToGroundTruthAfterRounding.append(np.mean(np.abs(ground_truth - np.round(picked))))
+            self.itrn_curve.append(niter)
+            self.opttime_curve.append(duration)
+            self.dopttime_curve.append(duration)
+            self.dobj_curve.append(energy2)
+            self.pobj_curve.append(energy1)
+            self.max_violated_constraint.append(self.max_constraint_violation(solution))
+            self.max_violated_equality.append(max_violated_equality)
+            self.max_violated_inequality.append(max_violated_inequality)
+            if plot_solution is not None:
+                plot_solution(niter, solution, is_active_variable=None)
+
+        if method == "admm":
+            x = lp_admm(self.costsvector, a_eq, b_eq, a_ineq, self.b_lower, self.b_upper, self.lower_bounds,
+                        self.upper_bounds, nb_iter=nb_iter, x0=x0, callback_func=record, max_time=max_time,
+                        nb_iter_plot=nb_iter_plot, order=order)
+        else:  # chambolle_pock_ppd: fixed variables are eliminated first (reference :1244-1248)
+            reduced = copy.deepcopy(self)
+            free, shift = reduced.remove_fixed_variables()
+            free_ids = np.nonzero(free)[0]
+
+            def expand(sol):
+                # reference :1259,:1288: x = m_change * sol - shift (note the sign it applies to the fixed values)
+                full = np.zeros(free.size)
+                full[free_ids] = sol
+                return full - shift
+
+            def record_reduced(niter, solution, *rest):
+                record(niter, expand(solution), *rest)
+
+            x, _ = chambolle_pock_ppd(reduced.costsvector, reduced.a_equalities, reduced.b_equalities,
+                                      reduced.a_inequalities, reduced.b_lower, reduced.b_upper, reduced.lower_bounds,
+                                      reduced.upper_bounds, x0=None, alpha=1, theta=1, nb_max_iter=nb_iter,
+                                      callback_func=record_reduced, max_time=max_time, nb_iter_plot=nb_iter_plot,
+                                      order=order)
+            x = expand(x)
+        elapsed = time.perf_counter() - start
+        return (x, elapsed) if get_timing else x

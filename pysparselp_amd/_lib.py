@@ -1,0 +1,154 @@
+"""ctypes binding of libslp_hip.so (include/slp_hip.h).
+
+The library is the only execution path: if it is missing, cannot be loaded, or
+finds no HIP device, every solver entry point raises -- there is no CPU
+fallback in this package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslp_hip.so")
+
+ORDER_AUTO, ORDER_SEQUENTIAL, ORDER_TREE = 0, 1, 2
+
+_lib = None
+_device = None
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+c_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/slp_hip.h one to one
+_SIGNATURES = {
+    "slp_version": (c_int, []),
+    "slp_device_count": (c_int, []),
+    "slp_init": (c_int, [c_int]),
+    "slp_synchronize": (c_int, []),
+    "slp_last_error": (ctypes.c_char_p, []),
+    "slp_timer_start": (c_int, []),
+    "slp_timer_stop": (c_int, [c_vp]),
+    "slp_matrix_create": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "slp_matrix_destroy": (None, [c_vp]),
+    "slp_matrix_nnz": (c_i64, [c_vp]),
+    "slp_matrix_spmv": (c_int, [c_vp, c_vp, c_vp, c_int]),
+    "slp_matrix_spmv_t": (c_int, [c_vp, c_vp, c_vp, c_int]),
+    "slp_matrix_download": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
+    "slp_matrix_bench_spmv": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),
+    "slp_cp_create": (c_vp, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
+    "slp_cp_create_on": (c_vp, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
+    "slp_cp_destroy": (None, [c_vp]),
+    "slp_cp_iterate": (c_int, [c_vp, c_i64]),
+    "slp_cp_primal_step": (c_int, [c_vp]),
+    "slp_cp_dual_step": (c_int, [c_vp]),
+    "slp_cp_report": (c_int, [c_vp, c_vp]),
+    "slp_cp_get_x": (c_int, [c_vp, c_vp]),
+    "slp_cp_get_y": (c_int, [c_vp, c_vp]),
+    "slp_cp_get_preconditioners": (c_int, [c_vp, c_vp, c_vp]),
+    "slp_cp_bench": (c_int, [c_vp, c_i64, c_vp]),
+    "slp_gs_create": (c_vp, [c_i64, c_vp, c_vp, c_vp]),
+    "slp_gs_destroy": (None, [c_vp]),
+    "slp_gs_num_levels": (c_i64, [c_vp]),
+    "slp_gs_solve": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_dbl]),
+    "slp_admm_create": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
+    "slp_admm_destroy": (None, [c_vp]),
+    "slp_admm_iterate": (c_int, [c_vp, c_i64]),
+    "slp_admm_sweep_step": (c_int, [c_vp]),
+    "slp_admm_multiplier_step": (c_int, [c_vp]),
+    "slp_admm_report": (c_int, [c_vp, c_vp]),
+    "slp_admm_get_x": (c_int, [c_vp, c_vp, c_i64]),
+    "slp_admm_get_lambda": (c_int, [c_vp, c_vp]),
+    "slp_admm_num_levels": (c_i64, [c_vp]),
+    "slp_admm_bench": (c_int, [c_vp, c_i64, c_vp]),
+    "slp_matrix_random": (c_vp, [c_i64, c_i64, c_dbl, ctypes.c_uint64, c_i64]),
+    "slp_random_lp_vectors": (c_int, [c_vp, c_dbl, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "slp_comm_unique_id": (c_int, [c_vp]),
+    "slp_comm_init": (c_int, [c_int, c_int, c_vp]),
+    "slp_comm_finalize": (c_int, []),
+    "slp_comm_allreduce_host": (c_int, [c_vp, c_i64, c_int]),
+    "slp_comm_barrier": (c_int, []),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class SlpError(RuntimeError):
+    """Raised for every failure reported by libslp_hip.so (and when it is absent)."""
+
+
+def load():
+    """dlopen the library and declare the prototypes (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlpError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pysparselp_amd/csrc`.  pysparselp_amd has no CPU fallback."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:
+        raise SlpError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().slp_last_error()
+    return msg.decode("utf-8", "replace") if msg else "unknown error"
+
+
+def check(rc):
+    if rc != 0:
+        raise SlpError(last_error())
+
+
+def check_handle(h):
+    if not h:
+        raise SlpError(last_error())
+    return h
+
+
+def lib(device=None):
+    """The loaded library, bound to a GPU (slp_init).  Raises SlpError when no
+    HIP device is usable."""
+    global _device
+    l = load()
+    if _device is None:
+        dev = device
+        if dev is None:
+            dev = int(os.environ.get("SLP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = l.slp_device_count()
+            if n > 0:
+                dev %= n
+        check(l.slp_init(int(dev)))
+        _device = int(dev)
+    elif device is not None and int(device) != _device:
+        raise SlpError(f"process already bound to device {_device}")
+    return l
+
+
+def ptr(a):
+    """Device-call pointer of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags.c_contiguous
+    return a.ctypes.data_as(c_vp)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def csr_arrays(a):
+    """(indptr int64, indices int32, data float64) of a scipy CSR matrix, entry order untouched."""
+    return (np.ascontiguousarray(a.indptr, dtype=np.int64), np.ascontiguousarray(a.indices, dtype=np.int32),
+            np.ascontiguousarray(a.data, dtype=np.float64))

@@ -1,0 +1,444 @@
+// slp_admm.hip -- projected Gauss-Seidel sweep and the ADMM loop on the device.
+// Replaces gaussSiedel.pyx:83-153 (boundedGaussSeidelClass) -- the reference's
+// only native code on the hot path -- and the loop of lp_admm (ADMM.py:143-268).
+//
+// The reference sweep is sequential: row i uses x[j] already updated for
+// j < i and not yet updated for j > i.  That order is kept exactly by a level
+// schedule: level(i) = 1 + max level(j) over j < i coupled to i through M or
+// M^T; rows of one level touch disjoint unknowns and run in parallel, levels
+// run one kernel after the other on the stream.  Every row is summed by one
+// thread in storage order, so x is bit-identical to the sequential sweep.
+#include <algorithm>
+
+#include "slp_common.h"
+#include "slp_kernels.h"
+
+namespace slp {
+
+// one level of one sweep; rows[] lists the rows of this level
+__global__ __launch_bounds__(kBlock) void k_gs_level(i64 count, const i32 *__restrict__ rows, const i64 *__restrict__ ptr,
+                                                     const i32 *__restrict__ idx, const double *__restrict__ val,
+                                                     const double *__restrict__ invd, const double *__restrict__ b,
+                                                     const double *__restrict__ lo, const double *__restrict__ hi,
+                                                     double *__restrict__ x, double w) {
+    const i64 t = (i64)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= count) return;
+    const i32 i = rows[t];
+    double v = 0.0;
+    for (i64 k = ptr[i]; k < ptr[i + 1]; ++k) v += x[idx[k]] * val[k];  // gaussSiedel.pyx:139-141
+    v = w * (b[i] - v) * invd[i] + x[i];                                 // :145
+    const double l = lo[i], u = hi[i];
+    if (v < l) v = l;                                                    // :148-151
+    else if (v > u) v = u;
+    x[i] = v;
+}
+
+// Small systems: the whole sweep inside ONE workgroup, levels separated by a
+// workgroup barrier instead of a kernel boundary (launch latency dominates
+// otherwise: SC105 has 41 levels of ~4 rows).
+__global__ __launch_bounds__(1024) void k_gs_sweep_one_block(i64 nlevels, const i64 *__restrict__ lptr,
+                                                             const i32 *__restrict__ rows, const i64 *__restrict__ ptr,
+                                                             const i32 *__restrict__ idx, const double *__restrict__ val,
+                                                             const double *__restrict__ invd, const double *__restrict__ b,
+                                                             const double *__restrict__ lo, const double *__restrict__ hi,
+                                                             double *__restrict__ x, double w, int sweeps) {
+    for (int s = 0; s < sweeps; ++s) {
+        for (i64 l = 0; l < nlevels; ++l) {
+            const i64 beg = lptr[l], end = lptr[l + 1];
+            for (i64 t = beg + threadIdx.x; t < end; t += blockDim.x) {
+                const i32 i = rows[t];
+                double v = 0.0;
+                for (i64 k = ptr[i]; k < ptr[i + 1]; ++k) v += __hip_atomic_load(&x[idx[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * val[k];
+                v = w * (b[i] - v) * invd[i] + x[i];
+                const double lw = lo[i], u = hi[i];
+                if (v < lw) v = lw;
+                else if (v > u) v = u;
+                x[i] = v;
+            }
+            __syncthreads();  // same CU: stores of this level are visible to the next one
+        }
+    }
+}
+
+__global__ void k_invert_diag(i64 n, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, const double *__restrict__ val,
+                              double *__restrict__ invd) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        double d = 0.0;  // A.diagonal(): 0 where no entry is stored
+        for (i64 k = ptr[i]; k < ptr[i + 1]; ++k)
+            if (idx[k] == i) d += val[k];
+        invd[i] = 1.0 / d;  // gaussSiedel.pyx:91-92
+    }
+}
+
+struct GsPlan {
+    i64 n = 0, nnz = 0, nlevels = 0, max_width = 0;
+    DevBuf<i64> ptr;
+    DevBuf<i32> idx;
+    DevBuf<double> val, invd;
+    DevBuf<i32> rows;        // rows sorted by level (stable: increasing row inside a level)
+    DevBuf<i64> lptr_dev;    // level pointer on the device (single-workgroup path)
+    std::vector<i64> lptr;   // level pointer on the host (launch sizes)
+    bool one_block = false;
+};
+
+static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, const double *data) {
+    SLP_REQUIRE(n >= 0 && indptr, "gauss-seidel: bad arguments");
+    SLP_REQUIRE(n < (i64)1 << 31, "gauss-seidel: dimension must fit int32");
+    g.n = n;
+    g.nnz = indptr[n];
+    // dependency levels over the symmetrised pattern, lower part only
+    std::vector<i32> level((size_t)n, 0);
+    // need(j): the largest level among rows i < j that READ x[j] (anti-dependence: j must wait for i)
+    std::vector<i32> need((size_t)n, 0);
+    i32 maxlev = 0;
+    for (i64 i = 0; i < n; ++i) {
+        i32 lv = need[(size_t)i];
+        for (i64 k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const i32 j = indices[k];
+            SLP_REQUIRE(j >= 0 && j < n, "gauss-seidel: column index out of range");
+            if (j < i) lv = std::max(lv, (i32)(level[(size_t)j] + 1));
+        }
+        level[(size_t)i] = lv;
+        for (i64 k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const i32 j = indices[k];
+            if (j > i) need[(size_t)j] = std::max(need[(size_t)j], (i32)(lv + 1));
+        }
+        maxlev = std::max(maxlev, lv);
+    }
+    g.nlevels = n ? (i64)maxlev + 1 : 0;
+    g.lptr.assign((size_t)g.nlevels + 1, 0);
+    for (i64 i = 0; i < n; ++i) g.lptr[(size_t)level[(size_t)i] + 1]++;
+    for (i64 l = 0; l < g.nlevels; ++l) {
+        g.max_width = std::max(g.max_width, g.lptr[(size_t)l + 1]);
+        g.lptr[(size_t)l + 1] += g.lptr[(size_t)l];
+    }
+    std::vector<i32> rows((size_t)n);
+    {
+        std::vector<i64> next(g.lptr.begin(), g.lptr.end() - (g.nlevels ? 1 : 0));
+        for (i64 i = 0; i < n; ++i) rows[(size_t)next[(size_t)level[(size_t)i]]++] = (i32)i;
+    }
+    g.ptr.upload(indptr, (size_t)n + 1);
+    g.idx.upload(indices, (size_t)g.nnz);
+    g.val.upload(data, (size_t)g.nnz);
+    g.rows.upload(rows.data(), (size_t)n);
+    g.lptr_dev.upload(g.lptr.data(), g.lptr.size());
+    g.invd.alloc((size_t)n);
+    if (n) {
+        hipLaunchKernelGGL(k_invert_diag, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, g.ptr.p, g.idx.p, g.val.p,
+                           g.invd.p);
+        SLP_HIP(hipGetLastError());
+    }
+    // a single workgroup wins while the per-level launch cost (>= ~1.5 us) exceeds the work of a level
+    g.one_block = (g.max_width <= 2048) && (g.nnz <= 200000);
+}
+
+static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const double *hi, double *x, double w, int sweeps) {
+    if (g.n == 0 || sweeps <= 0) return;
+    hipStream_t st = ctx().stream;
+    if (g.one_block) {
+        const int threads = g.max_width <= 64 ? 64 : (g.max_width <= 256 ? 256 : 1024);
+        hipLaunchKernelGGL(k_gs_sweep_one_block, dim3(1), dim3(threads), 0, st, g.nlevels, g.lptr_dev.p, g.rows.p, g.ptr.p, g.idx.p,
+                           g.val.p, g.invd.p, b, lo, hi, x, w, sweeps);
+        SLP_HIP(hipGetLastError());
+        return;
+    }
+    for (int s = 0; s < sweeps; ++s)
+        for (i64 l = 0; l < g.nlevels; ++l) {
+            const i64 beg = g.lptr[(size_t)l], cnt = g.lptr[(size_t)l + 1] - beg;
+            hipLaunchKernelGGL(k_gs_level, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cnt, g.rows.p + beg,
+                               g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
+        }
+    SLP_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// ADMM kernels
+// q_j = (-c_j) + gamma_eq * (A^T b)_j    (constant part of :148)
+__global__ void k_admm_q(i64 n, const double *__restrict__ c, const double *__restrict__ atb, double gamma_eq,
+                         double *__restrict__ q) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x)
+        q[j] = (-c[j]) + gamma_eq * atb[j];
+}
+
+// y_j = ((q_j + gamma_ineq * xp_j) - (A^T lambda)_j) - lambda_ineq_j, lambda_ineq == 0 on this branch (:148)
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_admm_rhs(i64 n, const i64 *__restrict__ tptr, const i32 *__restrict__ tidx,
+                                                     const double *__restrict__ tval, const double *__restrict__ lam,
+                                                     const double *__restrict__ q, const double *__restrict__ xp,
+                                                     double gamma_ineq, double *__restrict__ y) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 j = group; j < n; j += ngroups) {
+        const double s = row_dot<L>(tptr, tidx, tval, lam, j, sub);
+        if (sub == 0) y[j] = ((q[j] + gamma_ineq * xp[j]) - s) - 0.0;
+    }
+}
+
+// lambda_i += gamma_eq * ((A x)_i - b_i)   (:261-263)
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_admm_multiplier(i64 m, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+                                                            const double *__restrict__ val, const double *__restrict__ x,
+                                                            const double *__restrict__ b, double gamma_eq,
+                                                            double *__restrict__ lam) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 i = group; i < m; i += ngroups) {
+        const double ax = row_dot<L>(ptr, idx, val, x, i, sub);
+        if (sub == 0) lam[i] = lam[i] + gamma_eq * (ax - b[i]);
+    }
+}
+
+// report partials (:124-132,:220-222): per workgroup
+//  part[0] sum r^2  part[1] sum lambda r  part[2] max |r|      (rows,  r = A x - b)
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_admm_report_rows(i64 m, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+                                                             const double *__restrict__ val, const double *__restrict__ x,
+                                                             const double *__restrict__ b, const double *__restrict__ lam,
+                                                             double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    double s0 = 0.0, s1 = 0.0, mx = -__builtin_inf();
+    const i64 rounds = (m + ngroups - 1) / ngroups;
+    for (i64 it = 0; it < rounds; ++it) {
+        const i64 i = group + it * ngroups;
+        if (i < m) {
+            const double ax = row_dot<L>(ptr, idx, val, x, i, sub);
+            if (sub == 0) {
+                const double r = ax - b[i];
+                s0 += r * r;
+                s1 += lam[i] * r;
+                const double a = fabs(r);
+                mx = a > mx ? a : mx;
+            }
+        }
+    }
+    const double r0 = block_reduce<false>(s0, lds), r1 = block_reduce<false>(s1, lds), r2 = block_reduce<true>(mx, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = r0;
+        part[blockIdx.x * 3 + 1] = r1;
+        part[blockIdx.x * 3 + 2] = r2;
+    }
+}
+
+//  part[0] sum c x  part[1] sum (x-xp)^2  part[2] max(-x)      (columns)
+__global__ __launch_bounds__(kBlock) void k_admm_report_cols(i64 n, const double *__restrict__ c, const double *__restrict__ x,
+                                                             const double *__restrict__ xp, double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double s0 = 0.0, s1 = 0.0, mx = -__builtin_inf();
+    for (i64 j = (i64)blockIdx.x * kBlock + threadIdx.x; j < n; j += (i64)gridDim.x * kBlock) {
+        const double xj = x[j], dx = xj - xp[j];
+        s0 += c[j] * xj;
+        s1 += dx * dx;
+        mx = (-xj) > mx ? (-xj) : mx;
+    }
+    const double r0 = block_reduce<false>(s0, lds), r1 = block_reduce<false>(s1, lds), r2 = block_reduce<true>(mx, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = r0;
+        part[blockIdx.x * 3 + 1] = r1;
+        part[blockIdx.x * 3 + 2] = r2;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_admm_report_final(int nr, const double *__restrict__ rp, int nc,
+                                                              const double *__restrict__ cp, double *__restrict__ out) {
+    __shared__ double lds[kBlock / kWave];
+    double a0 = 0.0, a1 = 0.0, a2 = -__builtin_inf(), b0 = 0.0, b1 = 0.0, b2 = -__builtin_inf();
+    for (int i = threadIdx.x; i < nr; i += kBlock) {
+        a0 += rp[i * 3];
+        a1 += rp[i * 3 + 1];
+        a2 = rp[i * 3 + 2] > a2 ? rp[i * 3 + 2] : a2;
+    }
+    for (int i = threadIdx.x; i < nc; i += kBlock) {
+        b0 += cp[i * 3];
+        b1 += cp[i * 3 + 1];
+        b2 = cp[i * 3 + 2] > b2 ? cp[i * 3 + 2] : b2;
+    }
+    const double r0 = block_reduce<false>(a0, lds), r1 = block_reduce<false>(a1, lds), r2 = block_reduce<true>(a2, lds);
+    const double r3 = block_reduce<false>(b0, lds), r4 = block_reduce<false>(b1, lds), r5 = block_reduce<true>(b2, lds);
+    if (threadIdx.x == 0) {
+        out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3; out[4] = r4; out[5] = r5;
+    }
+}
+
+__global__ void k_max0(i64 n, const double *__restrict__ x, double *__restrict__ xp) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x)
+        xp[j] = (x[j] < 0.0) ? 0.0 : x[j];  // np.maximum(x, 0)  (ADMM.py:98)
+}
+
+}  // namespace slp
+
+using namespace slp;
+
+struct slp_gs {
+    GsPlan plan;
+    DevBuf<double> b, lo, hi, x;
+};
+
+struct slp_admm {
+    slp_matrix *a = nullptr;  // standard-form constraint matrix (m x N)
+    GsPlan plan;              // M
+    i64 N = 0, m = 0;
+    double gamma_eq = 2, gamma_ineq = 3;
+    int order = SLP_ORDER_AUTO, lanes_rows = 1, lanes_cols = 1;
+    bool xp_is_x = false;     // false only before the first multiplier step (:98 vs :259)
+    DevBuf<double> b, c, lb, ub, x, xp0, lam, q, y, rowparts, colparts, out;
+};
+
+namespace slp {
+constexpr int kAdmmPartials = 4096;
+
+static void admm_sweep(slp_admm *s) {
+    hipStream_t st = ctx().stream;
+    const CsrDev &at = s->a->at;
+    const double *xp = s->xp_is_x ? s->x.p : s->xp0.p;
+    const int lanes = s->lanes_cols;
+    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_admm_rhs<L>), dim3(grid_for(s->N * lanes, kBlock)), dim3(kBlock), 0, st, s->N,
+                                                 at.ptr.p, at.idx.p, at.val.p, s->lam.p, s->q.p, xp, s->gamma_ineq, s->y.p));
+    SLP_HIP(hipGetLastError());
+    gs_sweep(s->plan, s->y.p, s->lb.p, s->ub.p, s->x.p, 1.0, 1);  // :162 maxiter=1, w=1
+}
+
+static void admm_multiplier(slp_admm *s) {
+    const CsrDev &a = s->a->a;
+    s->xp_is_x = true;  // :259
+    if (s->m == 0) return;
+    const int lanes = s->lanes_rows;
+    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_admm_multiplier<L>), dim3(grid_for(s->m * lanes, kBlock)), dim3(kBlock), 0,
+                                                 ctx().stream, s->m, a.ptr.p, a.idx.p, a.val.p, s->x.p, s->b.p, s->gamma_eq,
+                                                 s->lam.p));
+    SLP_HIP(hipGetLastError());
+}
+}  // namespace slp
+
+extern "C" {
+
+slp_gs *slp_gs_create(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data) {
+    SLP_API_PTR({
+        ctx();
+        auto *g = new slp_gs();
+        try {
+            gs_plan(g->plan, n, indptr, indices, data);
+            g->b.alloc((size_t)n); g->lo.alloc((size_t)n); g->hi.alloc((size_t)n); g->x.alloc((size_t)n);
+            SLP_HIP(hipStreamSynchronize(ctx().stream));
+        } catch (...) { delete g; throw; }
+        return g;
+    })
+}
+
+void slp_gs_destroy(slp_gs *g) { delete g; }
+
+int64_t slp_gs_num_levels(const slp_gs *g) { return g ? g->plan.nlevels : -1; }
+
+int slp_gs_solve(slp_gs *g, const double *b, const double *lower, const double *upper, double *x, int maxiter, double w) {
+    SLP_API_INT({
+        SLP_REQUIRE(g && b && lower && upper && x, "slp_gs_solve: NULL argument");
+        const size_t n = (size_t)g->plan.n;
+        g->b.upload(b, n); g->lo.upload(lower, n); g->hi.upload(upper, n); g->x.upload(x, n);
+        gs_sweep(g->plan, g->b.p, g->lo.p, g->hi.p, g->x.p, w, maxiter);
+        g->x.download(x, n);
+    })
+}
+
+slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr, const int32_t *a_indices, const double *a_data,
+                          const double *b, const double *c, const double *lb, const double *ub, const double *x0,
+                          const int64_t *m_indptr, const int32_t *m_indices, const double *m_data, double gamma_eq,
+                          double gamma_ineq, int order) {
+    SLP_API_PTR({
+        SLP_REQUIRE(a_indptr && b && c && lb && ub && x0 && m_indptr, "slp_admm_create: NULL argument");
+        auto *s = new slp_admm();
+        try {
+            s->a = slp_matrix_create(m, N, a_indptr, a_indices, a_data);
+            if (!s->a) throw Error(slp_last_error());
+            build_transpose(s->a);
+            s->N = N; s->m = m; s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
+            s->lanes_rows = lanes_for(s->a->a, order);
+            s->lanes_cols = lanes_for(s->a->at, order);
+            gs_plan(s->plan, N, m_indptr, m_indices, m_data);
+            s->b.upload(b, (size_t)m); s->c.upload(c, (size_t)N); s->lb.upload(lb, (size_t)N); s->ub.upload(ub, (size_t)N);
+            s->x.upload(x0, (size_t)N);
+            s->xp0.alloc((size_t)N); s->lam.alloc((size_t)m); s->lam.zero();
+            s->q.alloc((size_t)N); s->y.alloc((size_t)N);
+            s->rowparts.alloc((size_t)kAdmmPartials * 3); s->colparts.alloc((size_t)kAdmmPartials * 3); s->out.alloc(8);
+            hipStream_t st = ctx().stream;
+            if (N) {
+                hipLaunchKernelGGL(k_max0, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, st, N, s->x.p, s->xp0.p);
+                // A^T b in the reference's accumulation order (ADMM.py:95), then q
+                launch_spmv(s->a->at, s->b.p, s->y.p, order == SLP_ORDER_AUTO ? SLP_ORDER_AUTO : order);
+                hipLaunchKernelGGL(k_admm_q, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, st, N, s->c.p, s->y.p, gamma_eq, s->q.p);
+                SLP_HIP(hipGetLastError());
+            }
+            SLP_HIP(hipStreamSynchronize(st));
+        } catch (...) { slp_admm_destroy(s); throw; }
+        return s;
+    })
+}
+
+void slp_admm_destroy(slp_admm *s) {
+    if (!s) return;
+    delete s->a;
+    delete s;
+}
+
+int slp_admm_iterate(slp_admm *s, int64_t k) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && k >= 0, "slp_admm_iterate: bad arguments");
+        for (i64 it = 0; it < k; ++it) { admm_sweep(s); admm_multiplier(s); }
+    })
+}
+
+int slp_admm_sweep_step(slp_admm *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); admm_sweep(s); }) }
+
+int slp_admm_multiplier_step(slp_admm *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); admm_multiplier(s); }) }
+
+int slp_admm_report(slp_admm *s, double out[3]) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && out, "slp_admm_report: NULL argument");
+        hipStream_t st = ctx().stream;
+        const CsrDev &a = s->a->a;
+        const double *xp = s->xp_is_x ? s->x.p : s->xp0.p;
+        int gc = std::min(grid_for(s->N, kBlock), kAdmmPartials);
+        hipLaunchKernelGGL(k_admm_report_cols, dim3(gc), dim3(kBlock), 0, st, s->N, s->c.p, s->x.p, xp, s->colparts.p);
+        const int lanes = s->lanes_rows;
+        int gr = std::min(grid_for(s->m * lanes, kBlock), kAdmmPartials);
+        SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_admm_report_rows<L>), dim3(gr), dim3(kBlock), 0, st, s->m, a.ptr.p, a.idx.p,
+                                                     a.val.p, s->x.p, s->b.p, s->lam.p, s->rowparts.p));
+        hipLaunchKernelGGL(k_admm_report_final, dim3(1), dim3(kBlock), 0, st, gr, s->rowparts.p, gc, s->colparts.p, s->out.p);
+        SLP_HIP(hipGetLastError());
+        double h[6];
+        s->out.download(h, 6);
+        // c.x + 0.5*g_eq*sum r^2 + 0.5*g_ineq*sum (x-xp)^2 + lambda.r + lambda_ineq.(x-xp)[=0]   (:124-132)
+        out[0] = h[3] + 0.5 * s->gamma_eq * h[0] + 0.5 * s->gamma_ineq * h[4] + h[1] + 0.0;
+        out[1] = h[2];                                // :221
+        out[2] = (h[5] > 0.0) ? h[5] : 0.0;           // :222 max(0, -min x)
+    })
+}
+
+int slp_admm_get_x(slp_admm *s, double *x, int64_t count) {
+    SLP_API_INT({ SLP_REQUIRE(s && x && count >= 0 && count <= s->N, "slp_admm_get_x: bad arguments"); s->x.download(x, (size_t)count); })
+}
+
+int slp_admm_get_lambda(slp_admm *s, double *lam) {
+    SLP_API_INT({ SLP_REQUIRE(s && lam, "NULL argument"); s->lam.download(lam, (size_t)s->m); })
+}
+
+int64_t slp_admm_num_levels(const slp_admm *s) { return s ? s->plan.nlevels : -1; }
+
+int slp_admm_bench(slp_admm *s, int64_t k, double *ms) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && k > 0 && ms, "slp_admm_bench: bad arguments");
+        Context &c = ctx();
+        SLP_HIP(hipEventRecord(c.ev0, c.stream));
+        for (i64 it = 0; it < k; ++it) { admm_sweep(s); admm_multiplier(s); }
+        SLP_HIP(hipEventRecord(c.ev1, c.stream));
+        SLP_HIP(hipEventSynchronize(c.ev1));
+        float f = 0.f;
+        SLP_HIP(hipEventElapsedTime(&f, c.ev0, c.ev1));
+        *ms = (double)f / (double)k;
+    })
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// slp_common.h -- shared host-side plumbing of libslp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/slp_hip.h"
+
+namespace slp {
+
+typedef int64_t i64;
+typedef int32_t i32;
+
+// ---- error plumbing: C++ exceptions inside, int/NULL + slp_last_error outside
+void set_error(const std::string &msg);
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define SLP_HIP(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            throw slp::Error(std::string(#expr) + " failed: " + hipGetErrorString(e_) +   \
+                             " (" __FILE__ ":" + std::to_string(__LINE__) + ")");         \
+    } while (0)
+
+#define SLP_REQUIRE(cond, msg)                       \
+    do {                                             \
+        if (!(cond)) throw slp::Error(std::string(msg)); \
+    } while (0)
+
+// Wraps the body of an extern "C" entry point that returns int.
+#define SLP_API_INT(...)                   \
+    try {                                  \
+        __VA_ARGS__;                       \
+        return 0;                          \
+    } catch (const std::exception &e) {    \
+        slp::set_error(e.what());          \
+        return 1;                          \
+    }
+
+#define SLP_API_PTR(...)                   \
+    try {                                  \
+        __VA_ARGS__;                       \
+    } catch (const std::exception &e) {    \
+        slp::set_error(e.what());          \
+        return nullptr;                    \
+    }
+
+// ---- process-wide context: one device, one stream
+struct Context {
+    bool ready = false;
+    int device = -1;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+Context &ctx();          // throws if slp_init has not succeeded
+Context &ctx_unchecked();
+
+// ---- device buffer
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        // never hand out a NULL device pointer for an empty vector
+        SLP_HIP(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
+    }
+    void upload(const T *host, size_t count) {
+        if (count > n || !p) alloc(count);
+        if (count) SLP_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+        SLP_HIP(hipStreamSynchronize(ctx().stream));  // host buffer may be freed by the caller
+    }
+    void download(T *host, size_t count) const {
+        if (count) SLP_HIP(hipMemcpyAsync(host, p, count * sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    void zero() {
+        if (n) SLP_HIP(hipMemsetAsync(p, 0, n * sizeof(T), ctx().stream));
+    }
+    void copy_from(const DevBuf<T> &o) {
+        if (o.n > n || !p) alloc(o.n);
+        if (o.n) SLP_HIP(hipMemcpyAsync(p, o.p, o.n * sizeof(T), hipMemcpyDeviceToDevice, ctx().stream));
+    }
+};
+
+inline int grid_for(i64 work_items, int block, int max_blocks_per_cu = 8) {
+    i64 g = (work_items + block - 1) / block;
+    i64 cap = (i64)ctx().num_cu * max_blocks_per_cu;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---- device-resident CSR in both orientations (defined in slp_matrix.hip)
+struct CsrDev {
+    i64 nrow = 0, ncol = 0, nnz = 0;
+    DevBuf<i64> ptr;
+    DevBuf<i32> idx;
+    DevBuf<double> val;
+    i64 max_row_len = 0;
+    double mean_row_len() const { return nrow ? (double)nnz / (double)nrow : 0.0; }
+};
+
+}  // namespace slp
+
+struct slp_matrix {
+    slp::CsrDev a;        // rows of A
+    slp::CsrDev at;       // rows of A^T (CSC of A), built on the device on first use
+    bool have_at = false;
+    slp::DevBuf<double> vx, vy;  // scratch vectors for the host-vector entry points
+};
+
+namespace slp {
+void build_transpose(slp_matrix *m);   // stable: rows increasing inside every column
+int lanes_for(const CsrDev &a, int order);
+void launch_spmv(const CsrDev &a, const double *x, double *y, int order);
+// two-stage deterministic reductions; result lands in out[0..k) (device), see slp_reduce.hip
+}  // namespace slp

@@ -1,0 +1,488 @@
+// slp_cp.hip -- diagonally preconditioned Chambolle-Pock on the device.
+// Replaces the setup and the loop of chambolle_pock_ppd
+// (ChambollePockPPD.py:122-179 and :195-343).  One iteration = two kernels:
+//   k_cp_primal : d = c + K^T y (walks the columns of K = rows of K^T),
+//                 x+ = clip(x - T d), z = (1+theta) x+ - theta x   [:198-228]
+//   k_cp_dual   : r = K z - b (walks the rows of K), y += Sigma r,
+//                 inequality rows clamped at 0                     [:231-240,:333-342]
+#include "slp_common.h"
+#include "slp_kernels.h"
+
+namespace slp {
+
+constexpr int kMaxPartials = 4096;
+
+// ---------------------------------------------------------------------------
+// setup: T_j = 1 / (sum_i |Ke_ij|^(2-alpha) + sum_i |Ki_ij|^(2-alpha)),  0 -> 1   (:122-153)
+//        S_i = 1 / sum_j |K_ij|^alpha, 0 -> 1                                      (:158-179)
+// numpy evaluates |a| ** p; p == 1 and p == 0 are exact, other p go through pow.
+__device__ __forceinline__ double abs_pow(double a, double p) {
+    a = fabs(a);
+    if (p == 1.0) return a;
+    if (p == 2.0) return a * a;
+    if (p == 0.0) return 1.0;
+    return pow(a, p);
+}
+
+// column sums over the transposed matrix (rows of K^T = columns of K), eq and ineq parts apart
+__global__ void k_cp_colsum(i64 n, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, const double *__restrict__ val,
+                            i32 m_eq, i64 m_ineq, double p, double *__restrict__ part_or_t, int finalize) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        double se = 0.0, si = 0.0;
+        for (i64 k = ptr[j]; k < ptr[j + 1]; ++k) {
+            const double t = abs_pow(val[k], p) * 1.0;
+            if (idx[k] < m_eq) se += t;
+            else si += t;
+        }
+        double tmp;
+        if (m_eq > 0 && m_ineq > 0) tmp = (0.0 + se) + si;
+        else if (m_eq > 0) tmp = se;
+        else tmp = si;
+        if (finalize) {
+            if (tmp == 0.0) tmp = 1.0;
+            part_or_t[j] = 1.0 / tmp;
+        } else {
+            part_or_t[j] = tmp;  // multi-GPU: summed over ranks first
+        }
+    }
+}
+
+__global__ void k_invert_or_one(i64 n, double *__restrict__ v) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        double t = v[j];
+        if (t == 0.0) t = 1.0;
+        v[j] = 1.0 / t;
+    }
+}
+
+__global__ void k_cp_rowsum(i64 m, const i64 *__restrict__ ptr, const double *__restrict__ val, double p,
+                            double *__restrict__ sigma) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (i64 k = ptr[i]; k < ptr[i + 1]; ++k) s += abs_pow(val[k], p) * 1.0;
+        if (s == 0.0) s = 1.0;
+        sigma[i] = 1.0 / s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// primal half-iteration.  `pre` (optional) holds K^T y already summed over the
+// ranks (multi-GPU); otherwise the column walk happens here.
+template <int L, bool FROM_PRE>
+__global__ __launch_bounds__(kBlock) void k_cp_primal(i64 n, const i64 *__restrict__ tptr, const i32 *__restrict__ tidx,
+                                                      const double *__restrict__ tval, const double *__restrict__ y,
+                                                      const double *__restrict__ pre, const double *__restrict__ c,
+                                                      const double *__restrict__ t, const double *__restrict__ lb,
+                                                      const double *__restrict__ ub, double *__restrict__ x,
+                                                      double *__restrict__ z, double *__restrict__ d_out, i32 m_eq,
+                                                      i64 m_ineq, double one_plus_theta, double theta) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 j = group; j < n; j += ngroups) {
+        double d;
+        if (FROM_PRE) {
+            d = c[j] + pre[j];
+        } else {
+            double se, si;
+            row_dot_split<L>(tptr, tidx, tval, y, j, sub, m_eq, &se, &si);
+            if (m_eq > 0 && m_ineq > 0) d = (c[j] + se) + si;  // :206,216
+            else if (m_eq > 0) d = c[j] + se;
+            else d = c[j] + si;
+        }
+        if (sub == 0) {
+            const double xo = x[j];
+            double x2 = xo - t[j] * d;  // :220
+            const double l = lb[j], u = ub[j];
+            x2 = (x2 < l) ? l : x2;  // np.maximum(x2, lb)
+            x2 = (x2 > u) ? u : x2;  // np.minimum(x2, ub)
+            z[j] = one_plus_theta * x2 - theta * xo;  // :226
+            x[j] = x2;
+            if (d_out) d_out[j] = d;
+        }
+    }
+}
+
+// partial K_g^T y_g only (multi-GPU), before the all-reduce
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_cp_colsum_y(i64 n, const i64 *__restrict__ tptr, const i32 *__restrict__ tidx,
+                                                        const double *__restrict__ tval, const double *__restrict__ y,
+                                                        double *__restrict__ out) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 j = group; j < n; j += ngroups) {
+        const double s = row_dot<L>(tptr, tidx, tval, y, j, sub);
+        if (sub == 0) out[j] = s;
+    }
+}
+
+// dual half-iteration
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_cp_dual(i64 m, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+                                                    const double *__restrict__ val, const double *__restrict__ z,
+                                                    const double *__restrict__ b, const double *__restrict__ sigma,
+                                                    double *__restrict__ y, i64 m_eq) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 i = group; i < m; i += ngroups) {
+        const double kz = row_dot<L>(ptr, idx, val, z, i, sub);
+        if (sub == 0) {
+            const double r = kz - b[i];          // :235,240
+            double yn = y[i] + sigma[i] * r;     // :334,339
+            if (i >= m_eq) yn = (yn < 0.0) ? 0.0 : yn;  // :341
+            y[i] = yn;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// report (:242-329).  x4_j = ub_j if d_j < 0 else lb_j (:260-261).
+// Row pass: per row three dot products (K x, K x4, K z); partial sums / maxima per workgroup:
+//   part[0] sum y_i (Kx - b)_i   part[1] sum y_i (Kx4 - b)_i
+//   part[2] max_{i<m_eq} |Kz - b|   part[3] max_{i>=m_eq} (Kx - b)   part[4] max_{i<m_eq} |Kx - b|
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_cp_report_rows(i64 m, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+                                                           const double *__restrict__ val, const double *__restrict__ x,
+                                                           const double *__restrict__ x4, const double *__restrict__ z,
+                                                           const double *__restrict__ b, const double *__restrict__ y,
+                                                           i64 m_eq, double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    double s1 = 0.0, s2 = 0.0, veq = -__builtin_inf(), vin = -__builtin_inf(), veqx = -__builtin_inf();
+    const i64 rounds = (m + ngroups - 1) / ngroups;
+    for (i64 it = 0; it < rounds; ++it) {
+        const i64 i = group + it * ngroups;
+        if (i < m) {
+            const double kx = row_dot<L>(ptr, idx, val, x, i, sub);
+            const double kx4 = row_dot<L>(ptr, idx, val, x4, i, sub);
+            const double kz = row_dot<L>(ptr, idx, val, z, i, sub);
+            if (sub == 0) {
+                const double bi = b[i], yi = y[i];
+                s1 += yi * (kx - bi);
+                s2 += yi * (kx4 - bi);
+                if (i < m_eq) {
+                    const double a = fabs(kz - bi), ax = fabs(kx - bi);
+                    veq = a > veq ? a : veq;
+                    veqx = ax > veqx ? ax : veqx;
+                } else {
+                    const double v = kx - bi;
+                    vin = v > vin ? v : vin;
+                }
+            }
+        }
+    }
+    const double r0 = block_reduce<false>(s1, lds);
+    const double r1 = block_reduce<false>(s2, lds);
+    const double r2 = block_reduce<true>(veq, lds);
+    const double r3 = block_reduce<true>(vin, lds);
+    const double r4 = block_reduce<true>(veqx, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 5 + 0] = r0;
+        part[blockIdx.x * 5 + 1] = r1;
+        part[blockIdx.x * 5 + 2] = r2;
+        part[blockIdx.x * 5 + 3] = r3;
+        part[blockIdx.x * 5 + 4] = r4;
+    }
+}
+
+// column pass: x4 and the two cost dot products; part[0] sum c x, part[1] sum c x4
+__global__ __launch_bounds__(kBlock) void k_cp_report_cols(i64 n, const double *__restrict__ c, const double *__restrict__ x,
+                                                           const double *__restrict__ d, const double *__restrict__ lb,
+                                                           const double *__restrict__ ub, double *__restrict__ x4,
+                                                           double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double s0 = 0.0, s1 = 0.0;
+    for (i64 j = (i64)blockIdx.x * kBlock + threadIdx.x; j < n; j += (i64)gridDim.x * kBlock) {
+        const double v4 = (d[j] < 0.0) ? ub[j] : lb[j];
+        x4[j] = v4;
+        s0 += c[j] * x[j];
+        s1 += c[j] * v4;
+    }
+    const double r0 = block_reduce<false>(s0, lds);
+    const double r1 = block_reduce<false>(s1, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = r0;
+        part[blockIdx.x * 2 + 1] = r1;
+    }
+}
+
+// out[0]=energy1 out[1]=energy2 out[2]=max eq out[3]=max ineq ; one workgroup, fixed order
+__global__ __launch_bounds__(kBlock) void k_cp_report_final(int nrowparts, const double *__restrict__ rp, int ncolparts,
+                                                            const double *__restrict__ cp, double *__restrict__ out) {
+    __shared__ double lds[kBlock / kWave];
+    double s1 = 0.0, s2 = 0.0, veq = -__builtin_inf(), vin = -__builtin_inf(), veqx = -__builtin_inf(), c0 = 0.0, c1 = 0.0;
+    for (int i = threadIdx.x; i < nrowparts; i += kBlock) {
+        s1 += rp[i * 5 + 0];
+        s2 += rp[i * 5 + 1];
+        veq = rp[i * 5 + 2] > veq ? rp[i * 5 + 2] : veq;
+        vin = rp[i * 5 + 3] > vin ? rp[i * 5 + 3] : vin;
+        veqx = rp[i * 5 + 4] > veqx ? rp[i * 5 + 4] : veqx;
+    }
+    for (int i = threadIdx.x; i < ncolparts; i += kBlock) {
+        c0 += cp[i * 2 + 0];
+        c1 += cp[i * 2 + 1];
+    }
+    const double r0 = block_reduce<false>(s1, lds), r1 = block_reduce<false>(s2, lds);
+    const double r2 = block_reduce<true>(veq, lds), r3 = block_reduce<true>(vin, lds);
+    const double r4 = block_reduce<false>(c0, lds), r5 = block_reduce<false>(c1, lds);
+    const double r6 = block_reduce<true>(veqx, lds);
+    if (threadIdx.x == 0) {
+        out[6] = r6;
+        out[0] = r4;  // c.x            (row sums are added on the host after the cross-rank reduction)
+        out[1] = r5;  // c.x4
+        out[2] = r0;  // y.(Kx-b)
+        out[3] = r1;  // y.(Kx4-b)
+        out[4] = r2;
+        out[5] = r3;
+    }
+}
+
+}  // namespace slp
+
+using namespace slp;
+
+// comm hooks (slp_comm.hip)
+namespace slp {
+bool comm_active();
+void comm_allreduce_dev(double *buf, i64 count, int op);  // in place, on the library stream
+}
+
+struct slp_cp {
+    slp_matrix *k = nullptr;
+    bool owns_k = false;
+    i64 n = 0, m = 0, m_eq = 0, m_ineq = 0;
+    double alpha = 1, theta = 1;
+    int order = SLP_ORDER_AUTO;
+    int lanes_rows = 1, lanes_cols = 1;
+    DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, rowparts, colparts, out;
+    bool distributed = false;
+};
+
+namespace slp {
+
+static void cp_setup(slp_cp *s) {
+    hipStream_t st = ctx().stream;
+    build_transpose(s->k);
+    const CsrDev &a = s->k->a, &at = s->k->at;
+    s->lanes_rows = lanes_for(a, s->order);
+    s->lanes_cols = lanes_for(at, s->order);
+    s->t.alloc((size_t)s->n);
+    s->sigma.alloc((size_t)s->m);
+    s->distributed = comm_active();
+    if (s->n) {
+        hipLaunchKernelGGL(k_cp_colsum, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p, at.val.p,
+                           (i32)s->m_eq, s->m_ineq, 2.0 - s->alpha, s->t.p, s->distributed ? 0 : 1);
+        SLP_HIP(hipGetLastError());
+        if (s->distributed) {
+            comm_allreduce_dev(s->t.p, s->n, 0);
+            hipLaunchKernelGGL(k_invert_or_one, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, s->t.p);
+            SLP_HIP(hipGetLastError());
+        }
+    }
+    if (s->m) {
+        hipLaunchKernelGGL(k_cp_rowsum, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, a.ptr.p, a.val.p, s->alpha,
+                           s->sigma.p);
+        SLP_HIP(hipGetLastError());
+    }
+}
+
+static void cp_primal(slp_cp *s, bool store_d) {
+    hipStream_t st = ctx().stream;
+    const CsrDev &at = s->k->at;
+    if (s->n == 0) return;
+    double *dout = store_d ? s->d.p : nullptr;
+    const double opt = 1.0 + s->theta;
+    if (s->distributed) {
+        const int lanes = s->lanes_cols;
+        const int grid = grid_for(s->n * lanes, kBlock);
+        SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_colsum_y<L>), dim3(grid), dim3(kBlock), 0, st, s->n, at.ptr.p,
+                                                     at.idx.p, at.val.p, s->y.p, s->pre.p));
+        SLP_HIP(hipGetLastError());
+        comm_allreduce_dev(s->pre.p, s->n, 0);
+        hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
+                           at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
+                           s->m_ineq, opt, s->theta);
+    } else {
+        const int lanes = s->lanes_cols;
+        const int grid = grid_for(s->n * lanes, kBlock);
+        SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_primal<L, false>), dim3(grid), dim3(kBlock), 0, st, s->n, at.ptr.p,
+                                                     at.idx.p, at.val.p, s->y.p, nullptr, s->c.p, s->t.p, s->lb.p, s->ub.p,
+                                                     s->x.p, s->z.p, dout, (i32)s->m_eq, s->m_ineq, opt, s->theta));
+    }
+    SLP_HIP(hipGetLastError());
+}
+
+static void cp_dual(slp_cp *s) {
+    if (s->m == 0) return;
+    const CsrDev &a = s->k->a;
+    const int lanes = s->lanes_rows;
+    const int grid = grid_for(s->m * lanes, kBlock);
+    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_dual<L>), dim3(grid), dim3(kBlock), 0, ctx().stream, s->m, a.ptr.p,
+                                                 a.idx.p, a.val.p, s->z.p, s->b.p, s->sigma.p, s->y.p, s->m_eq));
+    SLP_HIP(hipGetLastError());
+}
+
+static slp_cp *cp_make(slp_matrix *k, bool owns, i64 m_eq, const double *b, const double *c, const double *lb,
+                       const double *ub, const double *x0, double alpha, double theta, int order) {
+    auto *s = new slp_cp();
+    try {
+        s->k = k;
+        s->owns_k = owns;
+        s->n = k->a.ncol;
+        s->m = k->a.nrow;
+        s->m_eq = m_eq;
+        s->m_ineq = s->m - m_eq;
+        SLP_REQUIRE(m_eq >= 0 && m_eq <= s->m, "slp_cp_create: m_eq out of range");
+        s->alpha = alpha;
+        s->theta = theta;
+        s->order = order;
+        s->b.upload(b, (size_t)s->m);
+        s->c.upload(c, (size_t)s->n);
+        s->lb.upload(lb, (size_t)s->n);
+        s->ub.upload(ub, (size_t)s->n);
+        s->x.alloc((size_t)s->n);
+        if (x0) s->x.upload(x0, (size_t)s->n);
+        else s->x.zero();
+        s->z.copy_from(s->x);  // x3 = x (:190)
+        s->y.alloc((size_t)s->m);
+        s->y.zero();  // :166,177
+        s->d.alloc((size_t)s->n);
+        s->x4.alloc((size_t)s->n);
+        s->pre.alloc((size_t)s->n);
+        s->rowparts.alloc((size_t)kMaxPartials * 5);
+        s->colparts.alloc((size_t)kMaxPartials * 2);
+        s->out.alloc(8);
+        cp_setup(s);
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+    } catch (...) {
+        if (s->owns_k) delete s->k;
+        delete s;
+        throw;
+    }
+    return s;
+}
+
+}  // namespace slp
+
+extern "C" {
+
+slp_cp *slp_cp_create(int64_t n, int64_t m_eq, int64_t m_ineq, const int64_t *indptr, const int32_t *indices,
+                      const double *data, const double *b, const double *c, const double *lb, const double *ub,
+                      const double *x0, double alpha, double theta, int order) {
+    SLP_API_PTR({
+        SLP_REQUIRE(indptr && b && c && lb && ub, "slp_cp_create: NULL argument");
+        slp_matrix *k = slp_matrix_create(m_eq + m_ineq, n, indptr, indices, data);
+        if (!k) throw Error(slp_last_error());
+        return cp_make(k, true, m_eq, b, c, lb, ub, x0, alpha, theta, order);
+    })
+}
+
+slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const double *c, const double *lb,
+                         const double *ub, const double *x0, double alpha, double theta, int order) {
+    SLP_API_PTR({
+        SLP_REQUIRE(a && b && c && lb && ub, "slp_cp_create_on: NULL argument");
+        return cp_make(a, false, m_eq, b, c, lb, ub, x0, alpha, theta, order);
+    })
+}
+
+void slp_cp_destroy(slp_cp *s) {
+    if (!s) return;
+    if (s->owns_k) delete s->k;
+    delete s;
+}
+
+int slp_cp_iterate(slp_cp *s, int64_t k) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && k >= 0, "slp_cp_iterate: bad arguments");
+        for (i64 it = 0; it < k; ++it) {
+            cp_primal(s, false);
+            cp_dual(s);
+        }
+    })
+}
+
+int slp_cp_primal_step(slp_cp *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cp_primal(s, true); }) }
+
+int slp_cp_dual_step(slp_cp *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cp_dual(s); }) }
+
+int slp_cp_report(slp_cp *s, double out[5]) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && out, "slp_cp_report: NULL argument");
+        hipStream_t st = ctx().stream;
+        const CsrDev &a = s->k->a;
+        int gc = grid_for(s->n, kBlock);
+        if (gc > kMaxPartials) gc = kMaxPartials;
+        hipLaunchKernelGGL(k_cp_report_cols, dim3(gc), dim3(kBlock), 0, st, s->n, s->c.p, s->x.p, s->d.p, s->lb.p, s->ub.p,
+                           s->x4.p, s->colparts.p);
+        SLP_HIP(hipGetLastError());
+        const int lanes = s->lanes_rows;
+        int gr = grid_for(s->m * lanes, kBlock);
+        if (gr > kMaxPartials) gr = kMaxPartials;
+        SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_report_rows<L>), dim3(gr), dim3(kBlock), 0, st, s->m, a.ptr.p,
+                                                     a.idx.p, a.val.p, s->x.p, s->x4.p, s->z.p, s->b.p, s->y.p, s->m_eq,
+                                                     s->rowparts.p));
+        SLP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_cp_report_final, dim3(1), dim3(kBlock), 0, st, gr, s->rowparts.p, gc, s->colparts.p, s->out.p);
+        SLP_HIP(hipGetLastError());
+        double h[7];
+        s->out.download(h, 7);
+        if (s->distributed) {
+            // c.x and c.x4 are replicated; the row terms are summed / maxed over the ranks
+            double sums[2] = {h[2], h[3]}, maxs[3] = {h[4], h[5], h[6]};
+            SLP_REQUIRE(slp_comm_allreduce_host(sums, 2, 0) == 0, slp_last_error());
+            SLP_REQUIRE(slp_comm_allreduce_host(maxs, 3, 1) == 0, slp_last_error());
+            h[2] = sums[0]; h[3] = sums[1]; h[4] = maxs[0]; h[5] = maxs[1]; h[6] = maxs[2];
+        }
+        out[0] = h[0] + h[2];
+        out[1] = h[1] + h[3];
+        out[2] = (s->m_eq > 0 || s->distributed) ? (h[4] == -__builtin_inf() ? 0.0 : h[4]) : 0.0;
+        out[3] = h[5];
+        out[4] = (h[6] == -__builtin_inf()) ? 0.0 : h[6];
+    })
+}
+
+int slp_cp_get_x(slp_cp *s, double *x) { SLP_API_INT({ SLP_REQUIRE(s && x, "NULL argument"); s->x.download(x, (size_t)s->n); }) }
+
+int slp_cp_get_y(slp_cp *s, double *y) { SLP_API_INT({ SLP_REQUIRE(s && y, "NULL argument"); s->y.download(y, (size_t)s->m); }) }
+
+int slp_cp_get_preconditioners(slp_cp *s, double *t, double *sigma) {
+    SLP_API_INT({
+        SLP_REQUIRE(s, "NULL handle");
+        if (t) s->t.download(t, (size_t)s->n);
+        if (sigma) s->sigma.download(sigma, (size_t)s->m);
+    })
+}
+
+int slp_cp_bench(slp_cp *s, int64_t k, double ms[3]) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && k > 0 && ms, "slp_cp_bench: bad arguments");
+        Context &c = ctx();
+        float f = 0.f;
+        // whole iterations
+        SLP_HIP(hipEventRecord(c.ev0, c.stream));
+        for (i64 it = 0; it < k; ++it) { cp_primal(s, false); cp_dual(s); }
+        SLP_HIP(hipEventRecord(c.ev1, c.stream));
+        SLP_HIP(hipEventSynchronize(c.ev1));
+        SLP_HIP(hipEventElapsedTime(&f, c.ev0, c.ev1));
+        ms[0] = (double)f / (double)k;
+        // each kernel alone, back to back (state keeps evolving: the kernels are idempotent in cost)
+        SLP_HIP(hipEventRecord(c.ev0, c.stream));
+        for (i64 it = 0; it < k; ++it) cp_primal(s, false);
+        SLP_HIP(hipEventRecord(c.ev1, c.stream));
+        SLP_HIP(hipEventSynchronize(c.ev1));
+        SLP_HIP(hipEventElapsedTime(&f, c.ev0, c.ev1));
+        ms[1] = (double)f / (double)k;
+        SLP_HIP(hipEventRecord(c.ev0, c.stream));
+        for (i64 it = 0; it < k; ++it) cp_dual(s);
+        SLP_HIP(hipEventRecord(c.ev1, c.stream));
+        SLP_HIP(hipEventSynchronize(c.ev1));
+        SLP_HIP(hipEventElapsedTime(&f, c.ev0, c.ev1));
+        ms[2] = (double)f / (double)k;
+    })
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+// slp_matrix.hip -- library context, device CSR matrices (both orientations),
+// CSR SpMV / SpMV^T.  Replaces the scipy.sparse operands and
+// _sparsetools.csr_matvec / csc_matvec calls of the reference's solver loops
+// (ChambollePockPPD.py:206,216,235,240 ; ADMM.py:95,148,220,262).
+#include <cstring>
+#include <cstdlib>
+
+#include <rocprim/rocprim.hpp>
+
+#include "slp_common.h"
+#include "slp_kernels.h"
+
+namespace slp {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+static Context g_ctx;
+Context &ctx_unchecked() { return g_ctx; }
+Context &ctx() {
+    if (!g_ctx.ready)
+        throw Error("libslp_hip: slp_init() has not succeeded in this process (no HIP device bound; there is no CPU fallback)");
+    return g_ctx;
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+// y = A x.  L lanes per row; a workgroup of 256 threads covers 256/L rows per
+// step and grid-strides over the rows, so consecutive groups read consecutive
+// rows (coalesced across groups for short rows, inside a group for long ones).
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_spmv(i64 nrow, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+                                                 const double *__restrict__ val, const double *__restrict__ x,
+                                                 double *__restrict__ y) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    // all lanes of a group run the same trip count, so the shuffles inside row_dot stay convergent per group
+    for (i64 row = group; row < nrow; row += ngroups) {
+        const double s = row_dot<L>(ptr, idx, val, x, row, sub);
+        if (sub == 0) y[row] = s;
+    }
+}
+
+__global__ void k_count_cols(i64 nnz, const i32 *__restrict__ idx, unsigned long long *__restrict__ count) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (i64)gridDim.x * blockDim.x)
+        atomicAdd(&count[idx[k]], 1ull);
+}
+
+__global__ void k_iota_u32(i64 n, unsigned int *__restrict__ p) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) p[k] = (unsigned int)k;
+}
+
+// After the stable sort by column: position p of the transposed matrix holds
+// source entry perm[p]; its row in A is found by bisection in A's row pointer.
+__global__ void k_gather_transposed(i64 nnz, i64 nrow, const i64 *__restrict__ ptr, const double *__restrict__ val,
+                                    const unsigned int *__restrict__ perm, i32 *__restrict__ trow,
+                                    double *__restrict__ tval) {
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (i64)gridDim.x * blockDim.x) {
+        const i64 src = perm[p];
+        i64 lo = 0, hi = nrow;  // largest r with ptr[r] <= src
+        while (hi - lo > 1) {
+            const i64 mid = (lo + hi) >> 1;
+            if (ptr[mid] <= src) lo = mid;
+            else hi = mid;
+        }
+        trow[p] = (i32)lo;
+        tval[p] = val[src];
+    }
+}
+
+__global__ void k_max_row_len(i64 nrow, const i64 *__restrict__ ptr, unsigned long long *out) {
+    unsigned long long m = 0;
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
+        const unsigned long long l = (unsigned long long)(ptr[r + 1] - ptr[r]);
+        m = l > m ? l : m;
+    }
+    atomicMax(out, m);
+}
+
+// ---------------------------------------------------------------------------
+int lanes_for(const CsrDev &a, int order) {
+    if (order == SLP_ORDER_SEQUENTIAL) return 1;
+    const double mean = a.mean_row_len();
+    if (order == SLP_ORDER_AUTO && mean <= 16.0) return 1;
+    int l = 2;
+    while (l < 64 && (double)l * 4.0 < mean) l <<= 1;  // about >= 4 entries per lane
+    return l;
+}
+
+void launch_spmv(const CsrDev &a, const double *x, double *y, int order) {
+    if (a.nrow == 0) return;
+    const int lanes = lanes_for(a, order);
+    const int grid = grid_for(a.nrow * lanes, kBlock);
+    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_spmv<L>), dim3(grid), dim3(kBlock), 0, ctx().stream, a.nrow,
+                                                 a.ptr.p, a.idx.p, a.val.p, x, y));
+    SLP_HIP(hipGetLastError());
+}
+
+static void finish_stats(CsrDev &a) {
+    DevBuf<unsigned long long> mx(1);
+    mx.zero();
+    if (a.nrow) {
+        hipLaunchKernelGGL(k_max_row_len, dim3(grid_for(a.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, a.nrow, a.ptr.p, mx.p);
+        SLP_HIP(hipGetLastError());
+    }
+    unsigned long long h = 0;
+    mx.download(&h, 1);
+    a.max_row_len = (i64)h;
+}
+
+// Stable device transposition: a radix sort of the entry positions keyed by
+// column keeps, inside every column, the entries in storage order of A, i.e.
+// by increasing row (and storage order inside a row) -- the order in which
+// scipy's csc_matvec accumulates `y * A`.
+void build_transpose(slp_matrix *m) {
+    if (m->have_at) return;
+    const CsrDev &a = m->a;
+    CsrDev &t = m->at;
+    hipStream_t st = ctx().stream;
+    t.nrow = a.ncol;
+    t.ncol = a.nrow;
+    t.nnz = a.nnz;
+    SLP_REQUIRE(a.nnz < (i64)0xffffffffll, "transpose: more than 2^32-1 stored entries per device block");
+    t.ptr.alloc((size_t)t.nrow + 1);
+    t.idx.alloc((size_t)a.nnz);
+    t.val.alloc((size_t)a.nnz);
+    // column pointer: histogram + exclusive scan (integer atomics: order-independent)
+    DevBuf<unsigned long long> count((size_t)t.nrow + 1);
+    count.zero();
+    if (a.nnz) {
+        hipLaunchKernelGGL(k_count_cols, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, a.idx.p, count.p);
+        SLP_HIP(hipGetLastError());
+    }
+    {
+        size_t bytes = 0;
+        SLP_HIP(rocprim::exclusive_scan(nullptr, bytes, count.p, (unsigned long long *)t.ptr.p, 0ull, (size_t)t.nrow + 1,
+                                        rocprim::plus<unsigned long long>(), st));
+        DevBuf<char> tmp(bytes);
+        SLP_HIP(rocprim::exclusive_scan(tmp.p, bytes, count.p, (unsigned long long *)t.ptr.p, 0ull, (size_t)t.nrow + 1,
+                                        rocprim::plus<unsigned long long>(), st));
+        SLP_HIP(hipStreamSynchronize(st));
+    }
+    count.release();
+    if (a.nnz) {
+        DevBuf<unsigned int> pos_in((size_t)a.nnz), pos_out((size_t)a.nnz), key_out((size_t)a.nnz);
+        hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, pos_in.p);
+        SLP_HIP(hipGetLastError());
+        unsigned int bits = 1;
+        while (bits < 32 && ((i64)1 << bits) < a.ncol) ++bits;
+        size_t bytes = 0;
+        const unsigned int *keys_in = reinterpret_cast<const unsigned int *>(a.idx.p);
+        SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, key_out.p, pos_in.p, pos_out.p, (size_t)a.nnz, 0u, bits, st));
+        DevBuf<char> tmp(bytes);
+        SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys_in, key_out.p, pos_in.p, pos_out.p, (size_t)a.nnz, 0u, bits, st));
+        hipLaunchKernelGGL(k_gather_transposed, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, a.nrow, a.ptr.p,
+                           a.val.p, pos_out.p, t.idx.p, t.val.p);
+        SLP_HIP(hipGetLastError());
+        SLP_HIP(hipStreamSynchronize(st));
+    }
+    finish_stats(t);
+    m->have_at = true;
+}
+
+static slp_matrix *matrix_from_host(i64 nrow, i64 ncol, const i64 *indptr, const i32 *indices, const double *data) {
+    SLP_REQUIRE(nrow >= 0 && ncol >= 0 && indptr != nullptr, "slp_matrix_create: bad arguments");
+    SLP_REQUIRE(ncol < (i64)1 << 31, "column count must fit int32");
+    const i64 nnz = indptr[nrow];
+    SLP_REQUIRE(indptr[0] == 0 && nnz >= 0, "slp_matrix_create: indptr must start at 0");
+    ctx();
+    auto *m = new slp_matrix();
+    try {
+        m->a.nrow = nrow;
+        m->a.ncol = ncol;
+        m->a.nnz = nnz;
+        m->a.ptr.upload(indptr, (size_t)nrow + 1);
+        m->a.idx.upload(indices, (size_t)nnz);
+        m->a.val.upload(data, (size_t)nnz);
+        finish_stats(m->a);
+    } catch (...) {
+        delete m;
+        throw;
+    }
+    return m;
+}
+
+}  // namespace slp
+
+using namespace slp;
+
+extern "C" {
+
+int slp_version(void) { return 100; }
+
+const char *slp_last_error(void) { return g_err.c_str(); }
+
+int slp_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+        return -1;
+    }
+    return n;
+}
+
+int slp_init(int device) {
+    SLP_API_INT({
+        Context &c = ctx_unchecked();
+        int n = 0;
+        SLP_HIP(hipGetDeviceCount(&n));
+        SLP_REQUIRE(n > 0, "no HIP device visible");
+        SLP_REQUIRE(device >= 0 && device < n, "slp_init: device index out of range");
+        if (c.ready && c.device == device) return 0;
+        SLP_REQUIRE(!c.ready, "slp_init: this process is already bound to another device");
+        SLP_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        SLP_HIP(hipGetDeviceProperties(&prop, device));
+        c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        SLP_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        SLP_HIP(hipEventCreate(&c.ev0));
+        SLP_HIP(hipEventCreate(&c.ev1));
+        c.device = device;
+        c.ready = true;
+    })
+}
+
+int slp_synchronize(void) { SLP_API_INT({ SLP_HIP(hipStreamSynchronize(ctx().stream)); }) }
+
+int slp_timer_start(void) { SLP_API_INT({ SLP_HIP(hipEventRecord(ctx().ev0, ctx().stream)); }) }
+
+int slp_timer_stop(double *ms) {
+    SLP_API_INT({
+        SLP_HIP(hipEventRecord(ctx().ev1, ctx().stream));
+        SLP_HIP(hipEventSynchronize(ctx().ev1));
+        float f = 0.f;
+        SLP_HIP(hipEventElapsedTime(&f, ctx().ev0, ctx().ev1));
+        if (ms) *ms = (double)f;
+    })
+}
+
+slp_matrix *slp_matrix_create(int64_t nrow, int64_t ncol, const int64_t *indptr, const int32_t *indices,
+                              const double *data) {
+    SLP_API_PTR({ return matrix_from_host(nrow, ncol, indptr, indices, data); })
+}
+
+void slp_matrix_destroy(slp_matrix *a) { delete a; }
+
+int64_t slp_matrix_nnz(const slp_matrix *a) { return a ? a->a.nnz : -1; }
+
+int slp_matrix_spmv(slp_matrix *m, const double *x, double *y, int order) {
+    SLP_API_INT({
+        SLP_REQUIRE(m && x && y, "slp_matrix_spmv: NULL argument");
+        m->vx.upload(x, (size_t)m->a.ncol);
+        if (m->vy.n < (size_t)m->a.nrow) m->vy.alloc((size_t)m->a.nrow);
+        launch_spmv(m->a, m->vx.p, m->vy.p, order);
+        m->vy.download(y, (size_t)m->a.nrow);
+    })
+}
+
+int slp_matrix_spmv_t(slp_matrix *m, const double *y, double *out, int order) {
+    SLP_API_INT({
+        SLP_REQUIRE(m && y && out, "slp_matrix_spmv_t: NULL argument");
+        build_transpose(m);
+        DevBuf<double> vy((size_t)m->a.nrow), vo((size_t)m->a.ncol);
+        vy.upload(y, (size_t)m->a.nrow);
+        launch_spmv(m->at, vy.p, vo.p, order);
+        vo.download(out, (size_t)m->a.ncol);
+    })
+}
+
+int slp_matrix_download(slp_matrix *m, int transposed, int64_t *indptr, int32_t *indices, double *data) {
+    SLP_API_INT({
+        SLP_REQUIRE(m, "slp_matrix_download: NULL matrix");
+        if (transposed) build_transpose(m);
+        const CsrDev &a = transposed ? m->at : m->a;
+        if (indptr) a.ptr.download(indptr, (size_t)a.nrow + 1);
+        if (indices) a.idx.download(indices, (size_t)a.nnz);
+        if (data) a.val.download(data, (size_t)a.nnz);
+    })
+}
+
+int slp_matrix_bench_spmv(slp_matrix *m, int transposed, int order, int reps, double *ms) {
+    SLP_API_INT({
+        SLP_REQUIRE(m && reps > 0 && ms, "slp_matrix_bench_spmv: bad arguments");
+        if (transposed) build_transpose(m);
+        const CsrDev &a = transposed ? m->at : m->a;
+        DevBuf<double> vx((size_t)a.ncol), vy((size_t)a.nrow);
+        std::vector<double> h((size_t)a.ncol);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = 1.0 + 1e-3 * (double)(i % 1000);
+        vx.upload(h.data(), h.size());
+        launch_spmv(a, vx.p, vy.p, order);  // warm-up
+        SLP_HIP(hipEventRecord(ctx().ev0, ctx().stream));
+        for (int r = 0; r < reps; ++r) launch_spmv(a, vx.p, vy.p, order);
+        SLP_HIP(hipEventRecord(ctx().ev1, ctx().stream));
+        SLP_HIP(hipEventSynchronize(ctx().ev1));
+        float f = 0.f;
+        SLP_HIP(hipEventElapsedTime(&f, ctx().ev0, ctx().ev1));
+        *ms = (double)f / reps;
+    })
+}
+
+}  // extern "C"

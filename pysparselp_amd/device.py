@@ -1,0 +1,82 @@
+"""Device-resident sparse matrix handle (``slp_matrix`` of include/slp_hip.h)."""
+import numpy as np
+
+import scipy.sparse
+
+from . import _lib
+from ._lib import ORDER_AUTO
+
+
+class DeviceMatrix:
+    """CSR matrix living in HBM, in both orientations (the transposed copy is
+    built on the device the first time ``A^T y`` is needed)."""
+
+    def __init__(self, handle, shape):
+        self._l = _lib.lib()
+        self._h = handle
+        self.shape = (int(shape[0]), int(shape[1]))
+
+    @classmethod
+    def from_csr(cls, a):
+        l = _lib.lib()
+        indptr, indices, data = _lib.csr_arrays(a)
+        h = _lib.check_handle(l.slp_matrix_create(a.shape[0], a.shape[1], _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(data)))
+        return cls(h, a.shape)
+
+    @classmethod
+    def random(cls, nrow, ncol, density, seed, row_offset=0):
+        """Rows ``row_offset .. row_offset+nrow`` of the synthetic benchmark matrix
+        (distribution of the reference's randomLP.rand_sparse, generated on the GPU)."""
+        l = _lib.lib()
+        h = _lib.check_handle(l.slp_matrix_random(int(nrow), int(ncol), float(density), int(seed), int(row_offset)))
+        return cls(h, (nrow, ncol))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.slp_matrix_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def nnz(self):
+        return int(self._l.slp_matrix_nnz(self._h))
+
+    def matvec(self, x, order=ORDER_AUTO):
+        x = _lib.f64(x)
+        assert x.size == self.shape[1]
+        y = np.empty(self.shape[0])
+        _lib.check(self._l.slp_matrix_spmv(self._h, _lib.ptr(x), _lib.ptr(y), int(order)))
+        return y
+
+    def rmatvec(self, y, order=ORDER_AUTO):
+        y = _lib.f64(y)
+        assert y.size == self.shape[0]
+        out = np.empty(self.shape[1])
+        _lib.check(self._l.slp_matrix_spmv_t(self._h, _lib.ptr(y), _lib.ptr(out), int(order)))
+        return out
+
+    def download(self, transposed=False):
+        """scipy CSR copy of the device arrays (``transposed=True``: the device-built A^T)."""
+        nrow, ncol = (self.shape[1], self.shape[0]) if transposed else self.shape
+        indptr = np.empty(nrow + 1, dtype=np.int64)
+        _lib.check(self._l.slp_matrix_download(self._h, int(transposed), _lib.ptr(indptr), None, None))
+        nnz = int(indptr[-1])
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz)
+        _lib.check(self._l.slp_matrix_download(self._h, int(transposed), None, _lib.ptr(indices), _lib.ptr(data)))
+        return scipy.sparse.csr_matrix((data, indices, indptr), shape=(nrow, ncol))
+
+    def bench_spmv(self, transposed=False, order=ORDER_AUTO, reps=20):
+        """Average GPU milliseconds of one SpMV launch on resident vectors (HIP events)."""
+        ms = np.zeros(1)
+        _lib.check(self._l.slp_matrix_bench_spmv(self._h, int(transposed), int(order), int(reps), _lib.ptr(ms)))
+        return float(ms[0])
+
+    def random_lp_vectors(self, density, seed, row_offset=0):
+        """``(feasible_x, c, lb, ub, b_upper)`` of the synthetic LP whose rows this matrix holds."""
+        n, m = self.shape[1], self.shape[0]
+        xf, c, lb, ub, b = (np.empty(n), np.empty(n), np.empty(n), np.empty(n), np.empty(m))
+        _lib.check(self._l.slp_random_lp_vectors(self._h, float(density), int(seed), int(row_offset), _lib.ptr(xf),
+                                                 _lib.ptr(c), _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(b)))
+        return xf, c, lb, ub, b
