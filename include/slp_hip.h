@@ -144,6 +144,43 @@ int slp_admm_get_lambda(slp_admm *s, double *lam);          /* m */
 int64_t slp_admm_num_levels(const slp_admm *s);
 int slp_admm_bench(slp_admm *s, int64_t k, double *ms);
 
+/* ---- ADMM, matrix-free conjugate-gradient x-step ------------------------- *
+ * The reference's own alternative x-step (ADMM.py:182-201 with
+ * conjugateGradientLinearSolver.py:30-52, selected by its hard-coded flags
+ * ADMM.py:66-71: use_cg), with M v evaluated as gamma_eq A^T (A v) +
+ * gamma_ineq v so that M is never formed: the only ADMM form that exists at
+ * 1e6 x 2e6 (M would be dense).  Per iteration (ten passes over A):
+ *   y = -c + g_eq A^T b + g_ineq xp - A^T lambda_eq - lambda_ineq      (:148)
+ *   exact line search along the previous displacement                  (:190-194)
+ *   one conjugate-gradient step on M x = y                             (:199)
+ *   speed = x - xprev ; x = 1.4 x + (1 - 1.4) xp                       (:200-201)
+ *   xp = clip(x + lambda_ineq / g_ineq, lb, ub) ; lambda_ineq += g_ineq (x - xp)   (:253-256)
+ *   lambda_eq += g_eq (A x - b)                                        (:261-263)
+ * slp_admm_cg_create: A, b, c, lb, ub, x0 = the standard-form, row-normalised
+ * problem of ADMM.py:76-91 (any mix of equalities and inequalities).
+ * slp_admm_cg_create_on: all-inequality LP  A_ineq x <= b_upper  whose matrix is
+ * already resident; row normalisation and the slack standard form
+ * [A' -I] (tools.py:272-290, :88-127) are applied ON THE DEVICE, scaling the
+ * matrix values in place (a_ineq is modified and must outlive the solver).
+ * With slp_comm_init active the rows (and their slack variables) are this
+ * rank's block; the n original variables are replicated. */
+typedef struct slp_admm_cg slp_admm_cg;
+slp_admm_cg *slp_admm_cg_create(int64_t N, int64_t m, const int64_t *indptr, const int32_t *indices,
+                                const double *data, const double *b, const double *c,
+                                const double *lb, const double *ub, const double *x0,
+                                double gamma_eq, double gamma_ineq, int order);
+slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, const double *c,
+                                   const double *lb, const double *ub, double gamma_eq,
+                                   double gamma_ineq, int order);
+void slp_admm_cg_destroy(slp_admm_cg *s);
+int slp_admm_cg_iterate(slp_admm_cg *s, int64_t k);
+/* Halves of one iteration around the reference's report (:213-248). */
+int slp_admm_cg_xstep(slp_admm_cg *s);
+int slp_admm_cg_multiplier_step(slp_admm_cg *s);
+/* out[0] augmented-Lagrangian energy (:124-132)  out[1] max |A x - b|  out[2] max(0, -min x) */
+int slp_admm_cg_report(slp_admm_cg *s, double out[3]);
+int slp_admm_cg_get_x(slp_admm_cg *s, double *x, int64_t count);
+
 /* ---- synthetic random LP on the device (randomLP.py:14-75) -------------- *
  * Row r of A_ineq (global row index row_offset + r): every entry is non-zero
  * with probability `density`, value round(N(0,1)*100)/100, exact zeros

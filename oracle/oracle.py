@@ -446,3 +446,90 @@ def lp_admm(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2,
         lambda_eq = lambda_eq + gamma_eq * (matvec(a, x) - b)  # :261-263
         i += 1
     return x[0:n]
+
+
+# --------------------------------------------------------------------------
+# ADMM, conjugate-gradient x-step (ADMM.py:182-201 + conjugateGradientLinearSolver.py:30-52):
+# the reference's own alternative to the Gauss-Seidel sweep, selected by its
+# hard-coded flags (use_cg=True, use_bounded_gauss_siedel=False at ADMM.py:66-71).
+# It is the ADMM form that still exists when M = gamma_eq A^T A + gamma_ineq I
+# cannot be formed (hard part 2), because M only enters
+# through products M v.
+#   explicit_m=True : M v by csr_matvec on the explicit M, exactly the reference.
+#   explicit_m=False: M v = gamma_eq A^T (A v) + gamma_ineq v, matrix-free (what
+#                     the device does); same maths, fp64 rounding differences only.
+# --------------------------------------------------------------------------
+def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2, gamma_ineq=3, nb_iter=100,
+               callback_func=None, max_time=None, use_preconditioning=True, nb_iter_plot=10, explicit_m=False,
+               iterate_hook=None):
+    n = np.asarray(c).size
+    c = _f64(c)
+    a_eq, a_ineq = as_csr(a_eq), as_csr(a_ineq)
+    if x0 is None:
+        x0 = np.zeros(c.size)
+    if a_eq is not None:
+        a_eq, beq = precondition_constraints(a_eq, beq)
+    if a_ineq is not None:
+        a_ineq, b_lower, b_upper = precondition_constraints(a_ineq, b_lower, b_upper)
+    c, a, b, lb, ub, x = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
+    if use_preconditioning:
+        a, b = precondition_constraints(a, b)
+    atb = rmatvec(a, b)
+    if explicit_m:
+        m = normal_matrix(a, gamma_eq, gamma_ineq)
+
+        def m_apply(v):
+            return matvec(m, v)
+    else:
+        def m_apply(v):
+            return gamma_eq * rmatvec(a, matvec(a, v)) + gamma_ineq * v
+
+    xp = np.maximum(x, 0)  # :98
+    lambda_eq = np.zeros(a.shape[0])
+    lambda_ineq = np.zeros(x.shape)
+    speed = np.zeros(x.shape)  # :136
+    alpha = 1.4  # :140
+
+    def energy(x, xp, lambda_eq, lambda_ineq):  # :124-132
+        r = matvec(a, x) - b
+        return (c.dot(x) + 0.5 * gamma_eq * np.sum(r ** 2) + 0.5 * gamma_ineq * np.sum((x - xp) ** 2)
+                + lambda_eq.dot(matvec(a, x) - b) + lambda_ineq.dot(x - xp))
+
+    start = time.perf_counter()
+    i = 0
+    while i <= nb_iter:  # :143
+        y = -c + gamma_eq * atb + gamma_ineq * xp - rmatvec(a, lambda_eq) - lambda_ineq  # :148
+        xprev = x.copy()  # :184
+        direction = speed  # :190-194: exact line search along the previous displacement
+        t = -direction.dot(m_apply(x) - y)
+        if abs(t) > 0:
+            step_length = t / (direction.dot(m_apply(direction)))
+            x = x + step_length * direction
+        # :199 conjgrad(m, y, maxiter=1, x0=x)  (conjugateGradientLinearSolver.py:36-46)
+        r = y - m_apply(x)
+        p = r
+        rsold = r.dot(r)
+        a_p = m_apply(p)
+        alpha_cg = rsold / (p.dot(a_p))
+        x = x + alpha_cg * p
+        speed = x - xprev  # :200
+        x = alpha * x + (1 - alpha) * xp  # :201 over-relaxation
+        if iterate_hook is not None:
+            iterate_hook(i, x[0:n], x, lambda_eq)
+        if i % nb_iter_plot == 0:  # :213-248
+            elapsed = time.perf_counter() - start
+            if max_time is not None and elapsed > max_time:
+                break
+            energy1 = energy(x, xp, lambda_eq, lambda_ineq)
+            r = matvec(a, x) - b
+            max_violated_equality = np.max(np.abs(r))
+            max_violated_inequality = max(0, -np.min(x))
+            if callback_func is not None:
+                callback_func(i, x[0:n], energy1, energy1, elapsed, max_violated_equality, max_violated_inequality)
+        xp = x.copy() + lambda_ineq / gamma_ineq  # :253-256
+        xp = np.maximum(xp, lb)
+        xp = np.minimum(xp, ub)
+        lambda_ineq = lambda_ineq + gamma_ineq * (x - xp)
+        lambda_eq = lambda_eq + gamma_eq * (matvec(a, x) - b)  # :261-263
+        i += 1
+    return x[0:n]

@@ -94,8 +94,22 @@ def lp_admm(
     use_preconditioning=True,
     nb_iter_plot=10,
     order=ORDER_AUTO,
+    xstep="gauss_seidel",
 ):
-    """minimise c.x  s.t.  a_eq x = beq,  b_lower <= a_ineq x <= b_upper,  lb <= x <= ub."""
+    """minimise c.x  s.t.  a_eq x = beq,  b_lower <= a_ineq x <= b_upper,  lb <= x <= ub.
+
+    ``xstep`` (extension): ``"gauss_seidel"`` is the reference as shipped;
+    ``"cg"`` is the reference's conjugate-gradient branch (flags at
+    ADMM.py:66-71), run matrix-free -- see ``admm_cg.py``.
+    """
+    if xstep == "cg":
+        from .admm_cg import lp_admm_cg
+
+        return lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=x0, gamma_eq=gamma_eq, gamma_ineq=gamma_ineq,
+                          nb_iter=nb_iter, callback_func=callback_func, max_time=max_time,
+                          use_preconditioning=use_preconditioning, nb_iter_plot=nb_iter_plot, order=order)
+    if xstep != "gauss_seidel":
+        raise ValueError(f"unknown xstep {xstep!r}")
     c = _lib.f64(c)
     n = c.size
     if x0 is None:

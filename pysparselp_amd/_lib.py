@@ -63,6 +63,14 @@ _SIGNATURES = {
     "slp_admm_get_lambda": (c_int, [c_vp, c_vp]),
     "slp_admm_num_levels": (c_i64, [c_vp]),
     "slp_admm_bench": (c_int, [c_vp, c_i64, c_vp]),
+    "slp_admm_cg_create": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
+    "slp_admm_cg_create_on": (c_vp, [c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
+    "slp_admm_cg_destroy": (None, [c_vp]),
+    "slp_admm_cg_iterate": (c_int, [c_vp, c_i64]),
+    "slp_admm_cg_xstep": (c_int, [c_vp]),
+    "slp_admm_cg_multiplier_step": (c_int, [c_vp]),
+    "slp_admm_cg_report": (c_int, [c_vp, c_vp]),
+    "slp_admm_cg_get_x": (c_int, [c_vp, c_vp, c_i64]),
     "slp_matrix_random": (c_vp, [c_i64, c_i64, c_dbl, ctypes.c_uint64, c_i64]),
     "slp_random_lp_vectors": (c_int, [c_vp, c_dbl, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "slp_comm_unique_id": (c_int, [c_vp]),

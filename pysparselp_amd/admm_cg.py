@@ -1,0 +1,122 @@
+"""ADMM with the reference's conjugate-gradient x-step, matrix-free on the GPU.
+
+The reference ships ``lp_admm`` with a projected Gauss-Seidel x-step on the
+explicit ``M = gamma_eq A^T A + gamma_ineq I``; its other x-steps are selected
+by editing hard-coded flags (ADMM.py:66-71).  The conjugate-gradient branch
+(ADMM.py:182-201, ``conjgrad`` with one step) only needs products ``M v``,
+which the device evaluates as ``gamma_eq A^T (A v) + gamma_ineq v``.  It is
+the ADMM that exists on the BASELINE-sized problems, where ``M`` would be
+dense (hard part 2).  Kernels: csrc/slp_admm_cg.hip.
+"""
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import ORDER_AUTO
+from .tools import convert_to_standard_form_with_bounds, precondition_constraints
+
+
+class _CGBase:
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.slp_admm_cg_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def iterate(self, k):
+        _lib.check(self._l.slp_admm_cg_iterate(self._h, int(k)))
+
+    def xstep(self):
+        _lib.check(self._l.slp_admm_cg_xstep(self._h))
+
+    def multiplier_step(self):
+        _lib.check(self._l.slp_admm_cg_multiplier_step(self._h))
+
+    def report(self):
+        out = np.zeros(4)
+        _lib.check(self._l.slp_admm_cg_report(self._h, _lib.ptr(out)))
+        return out
+
+    def x(self, count=None):
+        count = self.N if count is None else int(count)
+        out = np.empty(count)
+        _lib.check(self._l.slp_admm_cg_get_x(self._h, _lib.ptr(out), count))
+        return out
+
+
+class ADMMCGState(_CGBase):
+    """Standard-form problem handed over from the host (any mix of equalities / inequalities)."""
+
+    def __init__(self, a, b, c, lb, ub, x0, gamma_eq, gamma_ineq, order=ORDER_AUTO):
+        self._l = _lib.lib()
+        self.N, self.m = a.shape[1], a.shape[0]
+        b, c, lb, ub, x0 = (_lib.f64(v) for v in (b, c, lb, ub, x0))
+        self._h = _lib.check_handle(self._l.slp_admm_cg_create(
+            self.N, self.m, _lib.ptr(a.indptr), _lib.ptr(a.indices), _lib.ptr(a.data), _lib.ptr(b), _lib.ptr(c),
+            _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(x0), float(gamma_eq), float(gamma_ineq), int(order)))
+
+
+class DeviceADMM(_CGBase):
+    """All-inequality LP over a DeviceMatrix; setup transforms run on the device and scale the
+    matrix IN PLACE (the DeviceMatrix then holds the row-normalised values)."""
+
+    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO):
+        self._l = _lib.lib()
+        self.a = a
+        self.n = a.shape[1]
+        self.N = a.shape[1] + a.shape[0]
+        self.c = _lib.f64(c)
+        b_upper, lb, ub = _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
+        self._h = _lib.check_handle(self._l.slp_admm_cg_create_on(a._h, _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
+                                                                  _lib.ptr(ub), float(gamma_eq), float(gamma_ineq), int(order)))
+
+    def objective(self):
+        return float(self.c.dot(self.x(self.n)))
+
+    @staticmethod
+    def matrix_passes_per_iteration():
+        return 10  # A^T lambda, 4 x (A v, A^T w) for the M-products, A x for the multiplier
+
+    @staticmethod
+    def describe():
+        return "ADMM, matrix-free conjugate-gradient x-step of the reference (ADMM.py:182-201), gamma_eq=2, gamma_ineq=3"
+
+
+def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2, gamma_ineq=3, nb_iter=100,
+               callback_func=None, max_time=None, use_preconditioning=True, nb_iter_plot=10, order=ORDER_AUTO):
+    """``lp_admm`` of the reference with its ``use_cg`` flags; same signature, callback and return value."""
+    c = _lib.f64(c)
+    n = c.size
+    if x0 is None:
+        x0 = np.zeros(n)
+    if a_eq is not None:
+        a_eq, beq = precondition_constraints(a_eq, beq, alpha=2)
+    if a_ineq is not None:
+        a_ineq, b_lower, b_upper = precondition_constraints(a_ineq, b_lower, b_upper, alpha=2)
+    c2, a, b, lb2, ub2, x_init = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
+    if use_preconditioning:
+        a, b = precondition_constraints(a, b, alpha=2)
+    state = ADMMCGState(a, b, c2, lb2, ub2, x_init, gamma_eq, gamma_ineq, order)
+    try:
+        start = time.perf_counter()
+        i = 0
+        while i <= nb_iter:
+            if i % nb_iter_plot == 0:
+                state.xstep()
+                elapsed = time.perf_counter() - start
+                if max_time is not None and elapsed > max_time:
+                    break
+                energy1, max_violated_equality, max_violated_inequality = state.report()[:3]
+                if callback_func is not None:
+                    callback_func(i, state.x(n), energy1, energy1, elapsed, max_violated_equality, max_violated_inequality)
+                state.multiplier_step()
+                i += 1
+            else:
+                k = min(nb_iter_plot - i % nb_iter_plot, nb_iter + 1 - i)
+                state.iterate(k)
+                i += k
+        return state.x(n)
+    finally:
+        state.close()

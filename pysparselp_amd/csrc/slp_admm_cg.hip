@@ -1,0 +1,499 @@
+// slp_admm_cg.hip -- ADMM with the reference's conjugate-gradient x-step
+// (ADMM.py:182-201 + conjugateGradientLinearSolver.py:30-52, the branch its
+// hard-coded flags at ADMM.py:66-71 select with use_cg=True), matrix-free:
+//     M v = gamma_eq A^T (A v) + gamma_ineq v
+// so that it exists where M = gamma_eq A^T A + gamma_ineq I cannot be formed
+// (1e6 x 2e6 at 1000 entries per row: M would be dense).  Ten passes over the
+// constraint matrix per iteration (5 x A v, 5 x A^T w), everything else is
+// elementwise work and dot products on length-N vectors.
+//
+// The standard-form matrix is A = [ At | diag(sc) ]: `At` is a CSR block over
+// the n_o original variables (both orientations resident), the optional
+// diagonal block holds one slack variable per row (ADMM.py:84-86: [A_ineq -I],
+// row-scaled).  Without `sc` the caller passes the whole standard-form matrix
+// as `At` (host path, any mix of equalities and inequalities).
+//
+// Multi-GPU: rows (and their slack variables) are partitioned; the n_o original
+// variables are replicated.  Each A^T w needs one all-reduce of n_o partial
+// sums; each dot product one scalar all-reduce of its slack part.
+#include <cmath>
+
+#include "slp_common.h"
+#include "slp_kernels.h"
+
+namespace slp {
+bool comm_active();
+void comm_allreduce_dev(double *buf, i64 count, int op);
+
+constexpr int kCgPartials = 2048;
+enum { S_T = 0, S_DMD = 2, S_RS = 4, S_PAP = 6, S_TMP = 8, S_COUNT = 32 };
+
+// w_i = At_i . v_o + sc_i v_s,i          (A v)
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_cg_rows(i64 m, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+                                                    const double *__restrict__ val, const double *__restrict__ v,
+                                                    const double *__restrict__ sc, i64 n_o, double *__restrict__ w) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 i = group; i < m; i += ngroups) {
+        double s = row_dot<L>(ptr, idx, val, v, i, sub);
+        if (sub == 0) {
+            if (sc) s = s + sc[i] * v[n_o + i];
+            w[i] = s;
+        }
+    }
+}
+
+// u_j = sum_i At_ij w_i  for the n_o original variables (partial sum on this rank)
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_cg_cols(i64 n_o, const i64 *__restrict__ tptr, const i32 *__restrict__ tidx,
+                                                    const double *__restrict__ tval, const double *__restrict__ w,
+                                                    double *__restrict__ u) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 j = group; j < n_o; j += ngroups) {
+        const double s = row_dot<L>(tptr, tidx, tval, w, j, sub);
+        if (sub == 0) u[j] = s;
+    }
+}
+
+// (A^T w)_j for any j in [0, N): column sums for the original variables, sc_i w_i for slack i
+__device__ __forceinline__ double at_elem(i64 j, i64 n_o, const double *__restrict__ u, const double *__restrict__ sc,
+                                          const double *__restrict__ w) {
+    return j < n_o ? u[j] : sc[j - n_o] * w[j - n_o];
+}
+
+// Elementwise passes over the N unknowns.  Each also produces one dot product, split into the part over
+// the replicated original variables (slot) and the part over this rank's slack variables (slot + 1).
+enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7 };
+
+struct CgVecs {
+    const double *q, *c, *lb, *ub, *u, *sc, *w;
+    double *x, *xp, *y, *dir, *xprev, *r, *lin;
+    const double *scal;
+    i64 n_o, N;
+    double gamma_eq, gamma_ineq, alpha, one_minus_alpha;
+};
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double acc_o = 0.0, acc_s = 0.0;
+    double f = 0.0;
+    bool on = true;
+    if (OP == E_LINE_STEP) {
+        const double t = -(a.scal[S_T] + a.scal[S_T + 1]);
+        on = fabs(t) > 0.0;                                      // ADMM.py:192
+        f = t / (a.scal[S_DMD] + a.scal[S_DMD + 1]);             // :193
+    }
+    if (OP == E_UPDATE) f = (a.scal[S_RS] + a.scal[S_RS + 1]) / (a.scal[S_PAP] + a.scal[S_PAP + 1]);  // conjgrad :38
+    for (i64 j = (i64)blockIdx.x * kBlock + threadIdx.x; j < a.N; j += (i64)gridDim.x * kBlock) {
+        double term = 0.0;
+        if (OP == E_RHS) {  // y = -c + g_eq A^T b + g_ineq xp - A^T lambda_eq - lambda_ineq (:148) ; xprev = x (:184)
+            const double atl = at_elem(j, a.n_o, a.u, a.sc, a.w);
+            a.y[j] = ((a.q[j] + a.gamma_ineq * a.xp[j]) - atl) - a.lin[j];
+            a.xprev[j] = a.x[j];
+        } else if (OP == E_LINE_T) {  // t = -dir.(M x - y) (:191)
+            const double mx = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.x[j];
+            term = a.dir[j] * (mx - a.y[j]);
+        } else if (OP == E_LINE_DMD) {  // dir.(M dir) (:193)
+            const double md = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.dir[j];
+            term = a.dir[j] * md;
+        } else if (OP == E_LINE_STEP) {  // x = x + step * dir (:194)
+            if (on) a.x[j] = a.x[j] + f * a.dir[j];
+        } else if (OP == E_RESID) {  // r = y - M x ; p = r ; rsold = r.r (conjgrad :33-35)
+            const double mx = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.x[j];
+            const double r = a.y[j] - mx;
+            a.r[j] = r;
+            term = r * r;
+        } else if (OP == E_PAP) {  // p.(M p) (conjgrad :37-38)
+            const double ap = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.r[j];
+            term = a.r[j] * ap;
+        } else if (OP == E_UPDATE) {  // x += alpha_cg p (:39) ; speed = x - xprev (:200) ; x = 1.4 x + (1-1.4) xp (:201)
+            const double xn = a.x[j] + f * a.r[j];
+            a.dir[j] = xn - a.xprev[j];
+            a.x[j] = a.alpha * xn + a.one_minus_alpha * a.xp[j];
+        } else if (OP == E_PROJECT) {  // xp = clip(x + lambda_ineq / g_ineq) ; lambda_ineq += g_ineq (x - xp) (:253-256)
+            const double xj = a.x[j];
+            double p = xj + a.lin[j] / a.gamma_ineq;
+            const double l = a.lb[j], u = a.ub[j];
+            p = (p < l) ? l : p;
+            p = (p > u) ? u : p;
+            a.xp[j] = p;
+            a.lin[j] = a.lin[j] + a.gamma_ineq * (xj - p);
+        }
+        if (j < a.n_o) acc_o += term;
+        else acc_s += term;
+    }
+    if (OP == E_LINE_T || OP == E_LINE_DMD || OP == E_RESID || OP == E_PAP) {
+        const double ro = block_reduce<false>(acc_o, lds), rs = block_reduce<false>(acc_s, lds);
+        if (threadIdx.x == 0) {
+            part[blockIdx.x * 2] = ro;
+            part[blockIdx.x * 2 + 1] = rs;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cg_finish(int nparts, const double *__restrict__ part, double *__restrict__ scal, int slot) {
+    __shared__ double lds[kBlock / kWave];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) {
+        a += part[i * 2];
+        b += part[i * 2 + 1];
+    }
+    const double ra = block_reduce<false>(a, lds), rb = block_reduce<false>(b, lds);
+    if (threadIdx.x == 0) {
+        scal[slot] = ra;
+        scal[slot + 1] = rb;
+    }
+}
+
+// lambda_eq_i += gamma_eq (w_i - b_i)  (:261-263), w = A x
+__global__ void k_cg_multiplier(i64 m, const double *__restrict__ w, const double *__restrict__ b, double gamma_eq,
+                                double *__restrict__ lam) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x)
+        lam[i] = lam[i] + gamma_eq * (w[i] - b[i]);
+}
+
+__global__ void k_cg_q(i64 N, i64 n_o, const double *__restrict__ c, const double *__restrict__ u, const double *__restrict__ sc,
+                       const double *__restrict__ b, double gamma_eq, double *__restrict__ q) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (i64)gridDim.x * blockDim.x)
+        q[j] = (-c[j]) + gamma_eq * at_elem(j, n_o, u, sc, b);  // -c + gamma_eq A^T b
+}
+
+// report partials over rows: [0] sum r^2  [1] sum lambda r  [2] max |r|   (w = A x)
+__global__ __launch_bounds__(kBlock) void k_cg_report_rows(i64 m, const double *__restrict__ w, const double *__restrict__ b,
+                                                           const double *__restrict__ lam, double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double s0 = 0.0, s1 = 0.0, mx = -__builtin_inf();
+    for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < m; i += (i64)gridDim.x * kBlock) {
+        const double r = w[i] - b[i];
+        s0 += r * r;
+        s1 += lam[i] * r;
+        mx = fabs(r) > mx ? fabs(r) : mx;
+    }
+    const double r0 = block_reduce<false>(s0, lds), r1 = block_reduce<false>(s1, lds), r2 = block_reduce<true>(mx, lds);
+    if (threadIdx.x == 0) { part[blockIdx.x * 3] = r0; part[blockIdx.x * 3 + 1] = r1; part[blockIdx.x * 3 + 2] = r2; }
+}
+
+// over unknowns, original / slack parts apart: [0,1] sum c x  [2,3] sum (x-xp)^2  [4,5] sum lin (x-xp)  [6,7] max(-x)
+__global__ __launch_bounds__(kBlock) void k_cg_report_cols(i64 N, i64 n_o, const double *__restrict__ c, const double *__restrict__ x,
+                                                           const double *__restrict__ xp, const double *__restrict__ lin,
+                                                           double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double v[8] = {0, 0, 0, 0, 0, 0, -__builtin_inf(), -__builtin_inf()};
+    for (i64 j = (i64)blockIdx.x * kBlock + threadIdx.x; j < N; j += (i64)gridDim.x * kBlock) {
+        const int o = j < n_o ? 0 : 1;
+        const double dx = x[j] - xp[j];
+        v[0 + o] += c[j] * x[j];
+        v[2 + o] += dx * dx;
+        v[4 + o] += lin[j] * dx;
+        v[6 + o] = (-x[j]) > v[6 + o] ? (-x[j]) : v[6 + o];
+    }
+    for (int k = 0; k < 8; ++k) {
+        const double r = k < 6 ? block_reduce<false>(v[k], lds) : block_reduce<true>(v[k], lds);
+        if (threadIdx.x == 0) part[blockIdx.x * 8 + k] = r;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cg_report_final(int nr, const double *__restrict__ rp, int nc, const double *__restrict__ cp,
+                                                            double *__restrict__ out) {
+    __shared__ double lds[kBlock / kWave];
+    double r[3] = {0, 0, -__builtin_inf()};
+    double c[8] = {0, 0, 0, 0, 0, 0, -__builtin_inf(), -__builtin_inf()};
+    for (int i = threadIdx.x; i < nr; i += kBlock) {
+        r[0] += rp[i * 3];
+        r[1] += rp[i * 3 + 1];
+        r[2] = rp[i * 3 + 2] > r[2] ? rp[i * 3 + 2] : r[2];
+    }
+    for (int i = threadIdx.x; i < nc; i += kBlock)
+        for (int k = 0; k < 8; ++k) {
+            if (k < 6) c[k] += cp[i * 8 + k];
+            else c[k] = cp[i * 8 + k] > c[k] ? cp[i * 8 + k] : c[k];
+        }
+    for (int k = 0; k < 3; ++k) {
+        const double v = k < 2 ? block_reduce<false>(r[k], lds) : block_reduce<true>(r[k], lds);
+        if (threadIdx.x == 0) out[k] = v;
+    }
+    for (int k = 0; k < 8; ++k) {
+        const double v = k < 6 ? block_reduce<false>(c[k], lds) : block_reduce<true>(c[k], lds);
+        if (threadIdx.x == 0) out[3 + k] = v;
+    }
+}
+
+// ---- device-side setup of the all-inequality standard form (ADMM.py:76-91, tools.py:272-290,88-127)
+// pass 1: inv1_i = 1/||a_i||_2 (0 -> 1);  a_ij *= inv1_i ; bu_i *= inv1_i
+// pass 2: inv2_i = 1/sqrt(sum_j a'_ij^2 + 1) ; a'_ij *= inv2_i ; sc_i = -1 * inv2_i   (the slack entry of [A' -I])
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, const i64 *__restrict__ ptr, double *__restrict__ val, int pass,
+                                                          double *__restrict__ bu, double *__restrict__ sc) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 i = group; i < m; i += ngroups) {
+        const i64 s = ptr[i], e = ptr[i + 1];
+        double acc = 0.0;
+        for (i64 k = s + sub; k < e; k += L) acc += (val[k] * val[k]) * 1.0;
+        acc = group_sum<L>(acc);
+        if (pass == 2) acc = acc + 1.0;
+        double nrm = sqrt(acc);
+        if (nrm == 0.0) nrm = 1.0;
+        const double inv = 1.0 / nrm;
+        for (i64 k = s + sub; k < e; k += L) val[k] = inv * val[k];
+        if (sub == 0) {
+            if (pass == 1) bu[i] = inv * bu[i];
+            else sc[i] = inv * -1.0;
+        }
+    }
+}
+
+__global__ void k_fill(i64 n, double *__restrict__ p, double v) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) p[j] = v;
+}
+
+}  // namespace slp
+
+using namespace slp;
+
+struct slp_admm_cg {
+    slp_matrix *a = nullptr;
+    bool owns_a = false;
+    i64 n_o = 0, m = 0, ns = 0, N = 0;
+    double gamma_eq = 2, gamma_ineq = 3, alpha = 1.4;
+    int order = SLP_ORDER_AUTO, lanes_rows = 1, lanes_cols = 1;
+    bool distributed = false;
+    DevBuf<double> sc, b, lam, w;                                         // rows
+    DevBuf<double> c, lb, ub, x, xp, y, q, dir, xprev, r, lin, u;        // unknowns (u: n_o)
+    DevBuf<double> part, rowpart, colpart, scal, out;
+};
+
+namespace slp {
+
+static void cg_rows(slp_admm_cg *s, const double *v) {
+    if (s->m == 0) return;
+    const CsrDev &a = s->a->a;
+    const int lanes = s->lanes_rows;
+    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_rows<L>), dim3(grid_for(s->m * lanes, kBlock)), dim3(kBlock), 0, ctx().stream,
+                                                 s->m, a.ptr.p, a.idx.p, a.val.p, v, s->ns ? s->sc.p : nullptr, s->n_o, s->w.p));
+    SLP_HIP(hipGetLastError());
+}
+
+// u = (A^T w) restricted to the original variables, summed over the ranks
+static void cg_cols(slp_admm_cg *s, const double *w) {
+    if (s->n_o == 0) return;
+    const CsrDev &at = s->a->at;
+    const int lanes = s->lanes_cols;
+    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_cols<L>), dim3(grid_for(s->n_o * lanes, kBlock)), dim3(kBlock), 0, ctx().stream,
+                                                 s->n_o, at.ptr.p, at.idx.p, at.val.p, w, s->u.p));
+    SLP_HIP(hipGetLastError());
+    if (s->distributed) comm_allreduce_dev(s->u.p, s->n_o, 0);
+}
+
+static CgVecs cg_vecs(slp_admm_cg *s) {
+    CgVecs v;
+    v.q = s->q.p; v.c = s->c.p; v.lb = s->lb.p; v.ub = s->ub.p; v.u = s->u.p; v.sc = s->sc.p; v.w = s->w.p;
+    v.x = s->x.p; v.xp = s->xp.p; v.y = s->y.p; v.dir = s->dir.p; v.xprev = s->xprev.p; v.r = s->r.p; v.lin = s->lin.p;
+    v.scal = s->scal.p; v.n_o = s->n_o; v.N = s->N;
+    v.gamma_eq = s->gamma_eq; v.gamma_ineq = s->gamma_ineq; v.alpha = s->alpha; v.one_minus_alpha = 1.0 - s->alpha;
+    return v;
+}
+
+template <int OP>
+static void cg_elem(slp_admm_cg *s, int slot) {
+    int grid = grid_for(s->N, kBlock);
+    if (grid > kCgPartials) grid = kCgPartials;
+    hipLaunchKernelGGL((k_cg_elem<OP>), dim3(grid), dim3(kBlock), 0, ctx().stream, cg_vecs(s), s->part.p);
+    SLP_HIP(hipGetLastError());
+    if (slot >= 0) {
+        hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(kBlock), 0, ctx().stream, grid, s->part.p, s->scal.p, slot);
+        SLP_HIP(hipGetLastError());
+        if (s->distributed) comm_allreduce_dev(s->scal.p + slot + 1, 1, 0);  // slack part lives on its rank
+    }
+}
+
+// first half of an iteration: everything up to (and including) the over-relaxed x (:148-201)
+static void cg_xstep(slp_admm_cg *s) {
+    cg_cols(s, s->lam.p);                      // A^T lambda_eq  (w is not used by the slack part here: see below)
+    // slack part of A^T lambda: sc_i * lambda_i -> at_elem reads w, so stage lambda in w
+    s->w.copy_from(s->lam);
+    cg_elem<E_RHS>(s, -1);
+    cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_LINE_T>(s, S_T);
+    cg_rows(s, s->dir.p); cg_cols(s, s->w.p); cg_elem<E_LINE_DMD>(s, S_DMD);
+    cg_elem<E_LINE_STEP>(s, -1);
+    cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_RESID>(s, S_RS);
+    cg_rows(s, s->r.p); cg_cols(s, s->w.p); cg_elem<E_PAP>(s, S_PAP);
+    cg_elem<E_UPDATE>(s, -1);
+}
+
+// second half: projection step and both multiplier updates (:253-263)
+static void cg_multipliers(slp_admm_cg *s) {
+    cg_elem<E_PROJECT>(s, -1);
+    cg_rows(s, s->x.p);
+    if (s->m) {
+        hipLaunchKernelGGL(k_cg_multiplier, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->w.p, s->b.p,
+                           s->gamma_eq, s->lam.p);
+        SLP_HIP(hipGetLastError());
+    }
+}
+
+static void cg_alloc_state(slp_admm_cg *s) {
+    const size_t N = (size_t)s->N, m = (size_t)s->m;
+    s->lam.alloc(m); s->lam.zero();
+    s->w.alloc(m);
+    s->xp.alloc(N); s->y.alloc(N); s->q.alloc(N); s->dir.alloc(N); s->dir.zero(); s->xprev.alloc(N); s->r.alloc(N);
+    s->lin.alloc(N); s->lin.zero();
+    s->u.alloc((size_t)s->n_o);
+    s->part.alloc((size_t)kCgPartials * 2); s->rowpart.alloc((size_t)kCgPartials * 3); s->colpart.alloc((size_t)kCgPartials * 8);
+    s->scal.alloc(S_COUNT); s->scal.zero(); s->out.alloc(16);
+    s->distributed = comm_active();
+    s->lanes_rows = lanes_for(s->a->a, s->order);
+    s->lanes_cols = lanes_for(s->a->at, s->order);
+    hipStream_t st = ctx().stream;
+    // q = -c + gamma_eq A^T b (:95,:148)
+    cg_cols(s, s->b.p);
+    s->w.copy_from(s->b);
+    if (s->N) {
+        hipLaunchKernelGGL(k_cg_q, dim3(grid_for(s->N, kBlock)), dim3(kBlock), 0, st, s->N, s->n_o, s->c.p, s->u.p, s->sc.p, s->w.p,
+                           s->gamma_eq, s->q.p);
+        SLP_HIP(hipGetLastError());
+    }
+}
+
+__global__ void k_cg_max0(i64 n, const double *__restrict__ x, double *__restrict__ xp) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x)
+        xp[j] = (x[j] < 0.0) ? 0.0 : x[j];
+}
+
+}  // namespace slp
+
+extern "C" {
+
+slp_admm_cg *slp_admm_cg_create(int64_t N, int64_t m, const int64_t *indptr, const int32_t *indices, const double *data,
+                                const double *b, const double *c, const double *lb, const double *ub, const double *x0,
+                                double gamma_eq, double gamma_ineq, int order) {
+    SLP_API_PTR({
+        SLP_REQUIRE(indptr && b && c && lb && ub && x0, "slp_admm_cg_create: NULL argument");
+        auto *s = new slp_admm_cg();
+        try {
+            s->a = slp_matrix_create(m, N, indptr, indices, data);
+            if (!s->a) throw Error(slp_last_error());
+            s->owns_a = true;
+            build_transpose(s->a);
+            s->n_o = N; s->m = m; s->ns = 0; s->N = N;
+            s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
+            s->b.upload(b, (size_t)m); s->c.upload(c, (size_t)N); s->lb.upload(lb, (size_t)N); s->ub.upload(ub, (size_t)N);
+            s->x.upload(x0, (size_t)N);
+            cg_alloc_state(s);
+            if (N) hipLaunchKernelGGL(k_cg_max0, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, ctx().stream, N, s->x.p, s->xp.p);
+            SLP_HIP(hipGetLastError());
+            SLP_HIP(hipStreamSynchronize(ctx().stream));
+        } catch (...) {
+            if (s->owns_a) delete s->a;
+            delete s;
+            throw;
+        }
+        return s;
+    })
+}
+
+slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, const double *c, const double *lb,
+                                   const double *ub, double gamma_eq, double gamma_ineq, int order) {
+    SLP_API_PTR({
+        SLP_REQUIRE(a_ineq && b_upper && c && lb && ub, "slp_admm_cg_create_on: NULL argument");
+        auto *s = new slp_admm_cg();
+        try {
+            hipStream_t st = ctx().stream;
+            s->a = a_ineq;
+            s->owns_a = false;
+            CsrDev &a = a_ineq->a;
+            const i64 m = a.nrow, n = a.ncol;
+            s->n_o = n; s->m = m; s->ns = m; s->N = n + m;
+            s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
+            // rows scaled in place, twice; the transposed copy is (re)built from the scaled values
+            a_ineq->have_at = false;
+            a_ineq->at = CsrDev();
+            DevBuf<double> bu((size_t)m);
+            bu.upload(b_upper, (size_t)m);
+            s->sc.alloc((size_t)m);
+            if (m) {
+                const int lanes = lanes_for(a, SLP_ORDER_TREE);
+                for (int pass = 1; pass <= 2; ++pass) {
+                    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_scale_rows<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0,
+                                                                 st, m, a.ptr.p, a.val.p, pass, bu.p, s->sc.p));
+                    SLP_HIP(hipGetLastError());
+                }
+            }
+            build_transpose(a_ineq);
+            // c2 = [c; 0]  lb2 = [lb; -inf]  ub2 = [ub; bu']  b = 0  x0 = 0
+            const size_t N = (size_t)s->N;
+            s->c.alloc(N); s->lb.alloc(N); s->ub.alloc(N); s->x.alloc(N); s->b.alloc((size_t)m);
+            s->c.zero(); s->x.zero(); s->b.zero();
+            SLP_HIP(hipMemcpyAsync(s->c.p, c, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+            SLP_HIP(hipMemcpyAsync(s->lb.p, lb, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+            SLP_HIP(hipMemcpyAsync(s->ub.p, ub, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+            if (m) {
+                hipLaunchKernelGGL(k_fill, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, st, m, s->lb.p + n, -__builtin_inf());
+                SLP_HIP(hipMemcpyAsync(s->ub.p + n, bu.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
+            SLP_HIP(hipStreamSynchronize(st));
+            cg_alloc_state(s);
+            s->xp.zero();  // max(0, 0)
+            SLP_HIP(hipStreamSynchronize(st));
+        } catch (...) {
+            delete s;
+            throw;
+        }
+        return s;
+    })
+}
+
+void slp_admm_cg_destroy(slp_admm_cg *s) {
+    if (!s) return;
+    if (s->owns_a) delete s->a;
+    delete s;
+}
+
+int slp_admm_cg_iterate(slp_admm_cg *s, int64_t k) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && k >= 0, "slp_admm_cg_iterate: bad arguments");
+        for (i64 it = 0; it < k; ++it) { cg_xstep(s); cg_multipliers(s); }
+    })
+}
+
+int slp_admm_cg_xstep(slp_admm_cg *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cg_xstep(s); }) }
+
+int slp_admm_cg_multiplier_step(slp_admm_cg *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cg_multipliers(s); }) }
+
+int slp_admm_cg_report(slp_admm_cg *s, double out[3]) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && out, "slp_admm_cg_report: NULL argument");
+        hipStream_t st = ctx().stream;
+        cg_rows(s, s->x.p);
+        int gr = std::min(grid_for(s->m, kBlock), kCgPartials), gc = std::min(grid_for(s->N, kBlock), kCgPartials);
+        hipLaunchKernelGGL(k_cg_report_rows, dim3(gr), dim3(kBlock), 0, st, s->m, s->w.p, s->b.p, s->lam.p, s->rowpart.p);
+        hipLaunchKernelGGL(k_cg_report_cols, dim3(gc), dim3(kBlock), 0, st, s->N, s->n_o, s->c.p, s->x.p, s->xp.p, s->lin.p, s->colpart.p);
+        hipLaunchKernelGGL(k_cg_report_final, dim3(1), dim3(kBlock), 0, st, gr, s->rowpart.p, gc, s->colpart.p, s->out.p);
+        SLP_HIP(hipGetLastError());
+        double h[11];
+        s->out.download(h, 11);
+        if (s->distributed) {
+            double sums[5] = {h[0], h[1], h[4], h[6], h[8]}, maxs[2] = {h[2], h[10]};
+            SLP_REQUIRE(slp_comm_allreduce_host(sums, 5, 0) == 0, slp_last_error());
+            SLP_REQUIRE(slp_comm_allreduce_host(maxs, 2, 1) == 0, slp_last_error());
+            h[0] = sums[0]; h[1] = sums[1]; h[4] = sums[2]; h[6] = sums[3]; h[8] = sums[4]; h[2] = maxs[0]; h[10] = maxs[1];
+        }
+        const double cx = h[3] + h[4], dx2 = h[5] + h[6], ldx = h[7] + h[8];
+        const double mneg = h[9] > h[10] ? h[9] : h[10];
+        out[0] = cx + 0.5 * s->gamma_eq * h[0] + 0.5 * s->gamma_ineq * dx2 + h[1] + ldx;  // ADMM.py:124-132
+        out[1] = h[2];                                                                       // :221
+        out[2] = mneg > 0.0 ? mneg : 0.0;                                                    // :222
+    })
+}
+
+int slp_admm_cg_get_x(slp_admm_cg *s, double *x, int64_t count) {
+    SLP_API_INT({ SLP_REQUIRE(s && x && count >= 0 && count <= s->N, "slp_admm_cg_get_x: bad arguments"); s->x.download(x, (size_t)count); })
+}
+
+}  // extern "C"

@@ -316,3 +316,42 @@ def test_spmv_linearity_at_scale():
     rhs = 2.0 * a.matvec(x1) - 3.0 * a.matvec(x2)
     assert np.max(np.abs(lhs - rhs)) < 1e-10 * np.max(np.abs(rhs))
     assert abs(a.matvec(x1).dot(y) - x1.dot(a.rmatvec(y))) < 1e-9 * abs(a.matvec(x1).dot(y))
+
+
+# ------------------------------------------------ ADMM with the matrix-free CG x-step
+@pytest.mark.parametrize("case", ["sc50a", "sc105", "potts8", "potts50", "random0", "random1", "random2"])
+@pytest.mark.parametrize("order", [1, 2])
+def test_admm_cg_iterates(case, order):
+    """Reference iterates of the conjugate-gradient branch (flag-flipped ADMM.py).  Tolerance, not bits:
+    dot products are reduced in another order than BLAS does, and this variant amplifies rounding
+    differences on some LPs (make_golden.py) -- 1e-9 relative over the first 200 iterations."""
+    lp_admm = _mods()[0]
+    d = load_golden("lp_" + case)
+    keep = [it for it in d["admmcg_it"] if it <= 200]
+    rec = Recorder(keep)
+    lp_admm(*solver_args(d), nb_iter=200, callback_func=rec, nb_iter_plot=1, xstep="cg", order=order)
+    assert rec.it == keep
+    for got, ref in zip(rec.x, d["admmcg_x"]):
+        assert np.max(np.abs(got - ref) / (1 + np.abs(ref))) < TREE_RTOL
+    for got, ref in zip(rec.e1, d["admmcg_e1"]):
+        assert abs(got - ref) <= 1e-9 * (1 + abs(ref))
+    np.testing.assert_allclose(rec.veq, d["admmcg_veq"][: len(keep)], rtol=1e-7, atol=1e-12)
+
+
+def test_admm_cg_on_device_generated_lp_matches_oracle():
+    """The at-scale path: device-side row normalisation + slack standard form + matrix-free ADMM,
+    against the oracle run on the downloaded (unscaled) matrix; objective within 1e-6 relative."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.problems import random_lp_on_device
+
+    n, m, p = 3000, 5000, 0.02
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=4)
+    s = a.download()
+    iters = 40
+    solver = DeviceADMM(a, b, c, lb, ub)
+    solver.iterate(iters)
+    x = solver.x(n)
+    solver.close()
+    xo = oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
+    assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < TREE_RTOL
+    assert abs(c.dot(x) - c.dot(xo)) <= 1e-6 * abs(c.dot(xo))
