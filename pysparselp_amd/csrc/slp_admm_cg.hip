@@ -271,9 +271,22 @@ struct slp_admm_cg {
 
 namespace slp {
 
+__global__ void k_cg_add_slack(i64 m, const double *__restrict__ sc, const double *__restrict__ vs, double *__restrict__ w) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) w[i] = w[i] + sc[i] * vs[i];
+}
+
 static void cg_rows(slp_admm_cg *s, const double *v) {
     if (s->m == 0) return;
     const CsrDev &a = s->a->a;
+    if (const StripJds *f = fast_format(s->a, false)) {  // long rows: LDS-tiled product, then the slack column
+        strip_spmv(*f, v, s->w.p);
+        if (s->ns) {
+            hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->sc.p, v + s->n_o,
+                               s->w.p);
+            SLP_HIP(hipGetLastError());
+        }
+        return;
+    }
     const int lanes = s->lanes_rows;
     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_rows<L>), dim3(grid_for(s->m * lanes, kBlock)), dim3(kBlock), 0, ctx().stream,
                                                  s->m, a.ptr.p, a.idx.p, a.val.p, v, s->ns ? s->sc.p : nullptr, s->n_o, s->w.p));
@@ -284,10 +297,14 @@ static void cg_rows(slp_admm_cg *s, const double *v) {
 static void cg_cols(slp_admm_cg *s, const double *w) {
     if (s->n_o == 0) return;
     const CsrDev &at = s->a->at;
-    const int lanes = s->lanes_cols;
-    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_cols<L>), dim3(grid_for(s->n_o * lanes, kBlock)), dim3(kBlock), 0, ctx().stream,
-                                                 s->n_o, at.ptr.p, at.idx.p, at.val.p, w, s->u.p));
-    SLP_HIP(hipGetLastError());
+    if (const StripJds *f = fast_format(s->a, true)) {
+        strip_spmv(*f, w, s->u.p);
+    } else {
+        const int lanes = s->lanes_cols;
+        SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_cols<L>), dim3(grid_for(s->n_o * lanes, kBlock)), dim3(kBlock), 0,
+                                                     ctx().stream, s->n_o, at.ptr.p, at.idx.p, at.val.p, w, s->u.p));
+        SLP_HIP(hipGetLastError());
+    }
     if (s->distributed) comm_allreduce_dev(s->u.p, s->n_o, 0);
 }
 
@@ -412,8 +429,7 @@ slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, co
             s->n_o = n; s->m = m; s->ns = m; s->N = n + m;
             s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
             // rows scaled in place, twice; the transposed copy is (re)built from the scaled values
-            a_ineq->have_at = false;
-            a_ineq->at = CsrDev();
+            invalidate_derived(a_ineq);
             DevBuf<double> bu((size_t)m);
             bu.upload(b_upper, (size_t)m);
             s->sc.alloc((size_t)m);

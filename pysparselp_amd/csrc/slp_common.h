@@ -127,12 +127,29 @@ struct CsrDev {
     double mean_row_len() const { return nrow ? (double)nnz / (double)nrow : 0.0; }
 };
 
+// strip-JDS copy of a CSR matrix for the LDS-tiled SpMV (slp_strip.hip)
+struct StripJds {
+    bool ok = false;
+    i64 nrow = 0, ncol = 0, nnz = 0, T = 0, B = 0;
+    DevBuf<i64> base;             // [B*T + 1] first entry of every (row block, strip) cell
+    DevBuf<unsigned short> perm;  // [B*T*R] sorted position -> local row
+    DevBuf<unsigned char> slen;   // [B*T*R] entry count of the row at a sorted position
+    DevBuf<unsigned int> soff;    // [B*T*256] offset of jagged diagonal s inside the cell
+    DevBuf<double> val;           // [nnz]
+    DevBuf<unsigned short> col;   // [nnz] column inside the strip
+};
+bool strip_wanted(const CsrDev &a);
+bool strip_build(const CsrDev &a, StripJds &f);
+void strip_spmv(const StripJds &f, const double *x, double *out);
+
 }  // namespace slp
 
 struct slp_matrix {
     slp::CsrDev a;        // rows of A
     slp::CsrDev at;       // rows of A^T (CSC of A), built on the device on first use
     bool have_at = false;
+    slp::StripJds fa, fat;            // LDS-tiled copies of a / at, built on first use when they pay
+    bool tried_fa = false, tried_fat = false;
     slp::DevBuf<double> vx, vy;  // scratch vectors for the host-vector entry points
 };
 
@@ -140,5 +157,10 @@ namespace slp {
 void build_transpose(slp_matrix *m);   // stable: rows increasing inside every column
 int lanes_for(const CsrDev &a, int order);
 void launch_spmv(const CsrDev &a, const double *x, double *y, int order);
+// The strip copy of one orientation (built lazily), or NULL when the matrix does not qualify.
+const StripJds *fast_format(slp_matrix *m, bool transposed);
+// y = A x (transposed: y = A^T x) with the best kernel for the matrix.
+void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int order);
+void invalidate_derived(slp_matrix *m);  // after the CSR values were modified in place
 // two-stage deterministic reductions; result lands in out[0..k) (device), see slp_reduce.hip
 }  // namespace slp

@@ -137,6 +137,17 @@ __global__ __launch_bounds__(kBlock) void k_cp_dual(i64 m, const i64 *__restrict
     }
 }
 
+// dual half-iteration from a precomputed K z (LDS-tiled SpMV path)
+__global__ void k_cp_dual_from(i64 m, const double *__restrict__ kz, const double *__restrict__ b,
+                               const double *__restrict__ sigma, double *__restrict__ y, i64 m_eq) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        const double r = kz[i] - b[i];
+        double yn = y[i] + sigma[i] * r;
+        if (i >= m_eq) yn = (yn < 0.0) ? 0.0 : yn;
+        y[i] = yn;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // report (:242-329).  x4_j = ub_j if d_j < 0 else lb_j (:260-261).
 // Row pass: per row three dot products (K x, K x4, K z); partial sums / maxima per workgroup:
@@ -258,7 +269,7 @@ struct slp_cp {
     double alpha = 1, theta = 1;
     int order = SLP_ORDER_AUTO;
     int lanes_rows = 1, lanes_cols = 1;
-    DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, rowparts, colparts, out;
+    DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, kz, rowparts, colparts, out;
     bool distributed = false;
 };
 
@@ -297,12 +308,22 @@ static void cp_primal(slp_cp *s, bool store_d) {
     double *dout = store_d ? s->d.p : nullptr;
     const double opt = 1.0 + s->theta;
     if (s->distributed) {
-        const int lanes = s->lanes_cols;
-        const int grid = grid_for(s->n * lanes, kBlock);
-        SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_colsum_y<L>), dim3(grid), dim3(kBlock), 0, st, s->n, at.ptr.p,
-                                                     at.idx.p, at.val.p, s->y.p, s->pre.p));
+        if (const StripJds *f = fast_format(s->k, true)) {
+            strip_spmv(*f, s->y.p, s->pre.p);
+        } else {
+            const int lanes = s->lanes_cols;
+            const int grid = grid_for(s->n * lanes, kBlock);
+            SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_colsum_y<L>), dim3(grid), dim3(kBlock), 0, st, s->n, at.ptr.p,
+                                                         at.idx.p, at.val.p, s->y.p, s->pre.p));
+        }
         SLP_HIP(hipGetLastError());
         comm_allreduce_dev(s->pre.p, s->n, 0);
+        hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
+                           at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
+                           s->m_ineq, opt, s->theta);
+    } else if (const StripJds *f = (s->m_eq == 0 || s->m_ineq == 0) ? fast_format(s->k, true) : nullptr) {
+        // long columns: LDS-tiled K^T y, then the elementwise update (the eq/ineq split is void with one kind of row)
+        strip_spmv(*f, s->y.p, s->pre.p);
         hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
                            at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
                            s->m_ineq, opt, s->theta);
@@ -319,6 +340,14 @@ static void cp_primal(slp_cp *s, bool store_d) {
 static void cp_dual(slp_cp *s) {
     if (s->m == 0) return;
     const CsrDev &a = s->k->a;
+    if (const StripJds *f = fast_format(s->k, false)) {
+        if (s->kz.n < (size_t)s->m) s->kz.alloc((size_t)s->m);
+        strip_spmv(*f, s->z.p, s->kz.p);
+        hipLaunchKernelGGL(k_cp_dual_from, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->kz.p, s->b.p,
+                           s->sigma.p, s->y.p, s->m_eq);
+        SLP_HIP(hipGetLastError());
+        return;
+    }
     const int lanes = s->lanes_rows;
     const int grid = grid_for(s->m * lanes, kBlock);
     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_dual<L>), dim3(grid), dim3(kBlock), 0, ctx().stream, s->m, a.ptr.p,

@@ -98,6 +98,35 @@ void launch_spmv(const CsrDev &a, const double *x, double *y, int order) {
     SLP_HIP(hipGetLastError());
 }
 
+const StripJds *fast_format(slp_matrix *m, bool transposed) {
+    if (transposed) build_transpose(m);
+    const CsrDev &a = transposed ? m->at : m->a;
+    StripJds &f = transposed ? m->fat : m->fa;
+    bool &tried = transposed ? m->tried_fat : m->tried_fa;
+    if (!tried) {
+        tried = true;
+        if (strip_wanted(a)) strip_build(a, f);
+    }
+    return f.ok ? &f : nullptr;
+}
+
+void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int order) {
+    // the strip kernel sums every row with one accumulator in storage order: valid for every `order`
+    if (const StripJds *f = fast_format(m, transposed)) {
+        strip_spmv(*f, x, y);
+        return;
+    }
+    launch_spmv(transposed ? m->at : m->a, x, y, order);
+}
+
+void invalidate_derived(slp_matrix *m) {
+    m->have_at = false;
+    m->at = CsrDev();
+    m->fa = StripJds();
+    m->fat = StripJds();
+    m->tried_fa = m->tried_fat = false;
+}
+
 static void finish_stats(CsrDev &a) {
     DevBuf<unsigned long long> mx(1);
     mx.zero();
@@ -254,7 +283,7 @@ int slp_matrix_spmv(slp_matrix *m, const double *x, double *y, int order) {
         SLP_REQUIRE(m && x && y, "slp_matrix_spmv: NULL argument");
         m->vx.upload(x, (size_t)m->a.ncol);
         if (m->vy.n < (size_t)m->a.nrow) m->vy.alloc((size_t)m->a.nrow);
-        launch_spmv(m->a, m->vx.p, m->vy.p, order);
+        matrix_spmv(m, false, m->vx.p, m->vy.p, order);
         m->vy.download(y, (size_t)m->a.nrow);
     })
 }
@@ -265,7 +294,7 @@ int slp_matrix_spmv_t(slp_matrix *m, const double *y, double *out, int order) {
         build_transpose(m);
         DevBuf<double> vy((size_t)m->a.nrow), vo((size_t)m->a.ncol);
         vy.upload(y, (size_t)m->a.nrow);
-        launch_spmv(m->at, vy.p, vo.p, order);
+        matrix_spmv(m, true, vy.p, vo.p, order);
         vo.download(out, (size_t)m->a.ncol);
     })
 }
@@ -290,9 +319,9 @@ int slp_matrix_bench_spmv(slp_matrix *m, int transposed, int order, int reps, do
         std::vector<double> h((size_t)a.ncol);
         for (size_t i = 0; i < h.size(); ++i) h[i] = 1.0 + 1e-3 * (double)(i % 1000);
         vx.upload(h.data(), h.size());
-        launch_spmv(a, vx.p, vy.p, order);  // warm-up
+        matrix_spmv(m, transposed != 0, vx.p, vy.p, order);  // warm-up
         SLP_HIP(hipEventRecord(ctx().ev0, ctx().stream));
-        for (int r = 0; r < reps; ++r) launch_spmv(a, vx.p, vy.p, order);
+        for (int r = 0; r < reps; ++r) matrix_spmv(m, transposed != 0, vx.p, vy.p, order);
         SLP_HIP(hipEventRecord(ctx().ev1, ctx().stream));
         SLP_HIP(hipEventSynchronize(ctx().ev1));
         float f = 0.f;

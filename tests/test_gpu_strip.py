@@ -1,0 +1,72 @@
+"""The LDS-tiled strip SpMV (csrc/slp_strip.hip) against the oracle.  It sums every
+row with one accumulator in storage order, so it must reproduce the oracle's
+csr_matvec BIT FOR BIT -- also for the device-built transpose.  -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def strips_everywhere(monkeypatch):
+    """Force the strip format on small matrices (it normally starts at 2e7 stored entries)."""
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
+    yield
+    monkeypatch.delenv("SLP_STRIP_MIN_NNZ", raising=False)
+
+
+@pytest.mark.parametrize("n,m,p", [(30000, 2500, 0.001), (20000, 3000, 0.002), (70000, 1100, 0.0008), (8192, 1024, 0.004)])
+def test_strip_spmv_bit_exact(strips_everywhere, n, m, p):
+    """Several strips, partial last strip / last row block, rows with no entry in a strip."""
+    from pysparselp_amd.problems import random_lp_on_device
+
+    a = random_lp_on_device(n, m, p, seed=n % 7)[0]
+    s = a.download()
+    oa = oracle.as_csr(s)
+    rng = np.random.RandomState(1)
+    x, y = rng.randn(n), rng.randn(m)
+    assert np.array_equal(a.matvec(x), oracle.matvec(oa, x))
+    assert np.array_equal(a.rmatvec(y), oracle.rmatvec(oa, y))
+
+
+def test_strip_falls_back_when_a_row_is_too_dense(strips_everywhere):
+    """>= 256 entries of one row inside one 8192-column strip: the generic kernel takes over."""
+    import scipy.sparse
+    from pysparselp_amd.device import DeviceMatrix
+
+    rng = np.random.RandomState(0)
+    a = scipy.sparse.random(300, 20000, density=0.003, random_state=rng, format="lil")
+    a[7, :400] = 1.5
+    a = a.tocsr()
+    a.sort_indices()
+    dm = DeviceMatrix.from_csr(a)
+    x = rng.randn(20000)
+    assert np.array_equal(dm.matvec(x, 1), oracle.matvec(oracle.as_csr(a), x))
+
+
+def test_solvers_on_strip_path_match_oracle(strips_everywhere):
+    """CP and matrix-free ADMM through the strip kernels (long rows in both orientations)."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    n, m, p = 30000, 40000, 0.001
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=3)
+    s = a.download()
+    cp = DeviceCP(a, b, c, lb, ub)
+    cp.iterate(40)
+    x = cp.x()
+    cp.close()
+    xo, _ = oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=40, nb_iter_plot=10 ** 9)
+    assert np.array_equal(x, xo)  # sequential-order sums on both sides
+    admm = DeviceADMM(a, b, c, lb, ub)
+    admm.iterate(25)
+    x = admm.x(n)
+    admm.close()
+    xo = oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=24, nb_iter_plot=10 ** 9)
+    assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-9
+    assert abs(c.dot(x) - c.dot(xo)) <= 1e-6 * abs(c.dot(xo))
