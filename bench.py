@@ -104,21 +104,16 @@ def main():
     if world > 1:
         import torch.distributed as dist  # gloo, CPU: control plane only (RCCL id exchange)
 
+        from pysparselp_amd.parallel import init_comm
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        import ctypes
-
-        uid = ctypes.create_string_buffer(128)
-        if rank == 0:
-            _lib.check(lib.slp_comm_unique_id(uid))
-        box = [uid.raw]
-        dist.broadcast_object_list(box, src=0)
-        _lib.check(lib.slp_comm_init(world, rank, ctypes.create_string_buffer(box[0], 128)))
+        init_comm(dist, rank, world)
 
     # ---- the workload: this rank's row block, generated in HBM
-    rows_per = (args.m + world - 1) // world
-    r0 = min(rank * rows_per, args.m)
-    rows = min(rows_per, args.m - r0)
+    from pysparselp_amd.parallel import row_block
+
+    r0, rows = row_block(args.m, world, rank)
     t_gen = time.perf_counter()
     a = DeviceMatrix.random(rows, args.n, args.density, args.seed, r0)
     xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed, r0)
@@ -156,6 +151,17 @@ def main():
         gbs_ax = b_ax / (ms_ax * 1e-3) / 1e9
         gbs_aty = b_aty / (ms_aty * 1e-3) / 1e9
         passes = solver.matrix_passes_per_iteration()
+        strip = lib.slp_matrix_spmv_kernel(a._h, 0) == 1
+        kernel = ("k_strip_spmv (LDS-tiled strip-JDS SpMV y = A x, rank 0's row block)" if strip
+                  else "k_spmv (CSR SpMV y = A x, rank 0's row block)")
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(REPO, "profiles", "r01_cp_c3_pmc_hbm.json")
+        if strip and world == 1 and (args.n, args.m, args.density) == (1_000_000, 2_000_000, 1e-3) and os.path.exists(pmc_file):
+            # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 correction),
+            # collected on this exact workload and kernel; see tools/summarize_rocprof.py and DESIGN.md
+            k = json.load(open(pmc_file))["kernels"].get("slp::k_strip_spmv")
+            if k:
+                traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/r01_cp_c3_pmc_hbm.json"
         out = {
             "metric": f"{'admm' if args.method == 'admm' else 'chambolle_pock'}_iterations_per_sec",
             "value": args.steps / dt,
@@ -178,12 +184,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_spmv (CSR SpMV y = A x, rank 0's row block)",
+                "kernel": kernel,
                 "achieved": gbs_ax,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": gbs_ax / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": b_ax,
                 "ms_per_launch": ms_ax,
                 "spmv_transposed": {"achieved": gbs_aty, "frac": gbs_aty / HBM_PEAK_GBS, "ms_per_launch": ms_aty,

@@ -310,6 +310,16 @@ int slp_matrix_download(slp_matrix *m, int transposed, int64_t *indptr, int32_t 
     })
 }
 
+int slp_matrix_spmv_kernel(slp_matrix *m, int transposed) {
+    try {
+        SLP_REQUIRE(m, "slp_matrix_spmv_kernel: NULL matrix");
+        return fast_format(m, transposed != 0) ? 1 : 0;
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return -1;
+    }
+}
+
 int slp_matrix_bench_spmv(slp_matrix *m, int transposed, int order, int reps, double *ms) {
     SLP_API_INT({
         SLP_REQUIRE(m && reps > 0 && ms, "slp_matrix_bench_spmv: bad arguments");

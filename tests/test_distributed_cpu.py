@@ -1,0 +1,184 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes run the row-partitioned
+algorithms exactly as the device code decomposes them (pysparselp_amd/parallel.py,
+csrc/slp_cp.hip "distributed", csrc/slp_admm_cg.hip), with the ORACLE's kernels
+standing in for the HIP kernels of each rank (test only), and must reproduce the
+single-process oracle.  Also covers the partition helpers and the id exchange."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+from oracle import oracle
+from pysparselp_amd.parallel import exchange_unique_id, row_block, row_block_by_nnz
+
+
+def test_row_block_covers_all_rows():
+    for m, world in ((10, 1), (10, 3), (7, 8), (2_000_000, 8), (0, 2)):
+        blocks = [row_block(m, world, r) for r in range(world)]
+        assert blocks[0][0] == 0 and sum(c for _, c in blocks) == m
+        for (f0, c0), (f1, _) in zip(blocks, blocks[1:]):
+            assert f1 == f0 + c0 or c0 == 0 or f1 == m
+
+
+def test_row_block_by_nnz_balances_ragged_rows():
+    rng = np.random.RandomState(0)
+    lens = np.concatenate((rng.randint(1, 4, 900), rng.randint(200, 400, 100)))
+    indptr = np.concatenate(([0], np.cumsum(lens)))
+    world = 4
+    blocks = [row_block_by_nnz(indptr, world, r) for r in range(world)]
+    assert blocks[0][0] == 0 and sum(c for _, c in blocks) == 1000
+    nnz = [indptr[f + c] - indptr[f] for f, c in blocks]
+    assert max(nnz) - min(nnz) <= 2 * 400  # every cut is within one long row of the ideal split
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _small_lp(seed=0, n=40, m=70):
+    rng = np.random.RandomState(seed)
+    a = scipy.sparse.random(m, n, density=0.2, random_state=rng, format="csr")
+    a.data = np.round(rng.randn(a.nnz) * 100) / 100
+    a.sort_indices()
+    xf = np.round(rng.randn(n) * 100) / 100
+    b = np.ceil((a @ xf + 0.01) * 1000) / 1000
+    c = np.round(rng.randn(n) * 100) / 100
+    t = np.round(rng.randn(n) * 100) / 100
+    return a, b, c, xf + np.minimum(0, t), xf + np.maximum(0, t)
+
+
+def _rank_main(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def allreduce(v, op=dist.ReduceOp.SUM):
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64).copy())
+        dist.all_reduce(t, op=op)
+        return t.numpy()
+
+    # --- id exchange helper
+    uid = exchange_unique_id(dist, rank, lambda: bytes(range(128)))
+    assert uid == bytes(range(128))
+
+    a, b, c, lb, ub = _small_lp()
+    m, n = a.shape
+    r0, rows = row_block(m, world, rank)
+    ag = oracle.as_csr(a[r0:r0 + rows])
+    bg = b[r0:r0 + rows]
+
+    # --- Chambolle-Pock, rows partitioned (slp_cp.hip: k_cp_colsum -> all-reduce -> invert; k_cp_colsum_y ->
+    #     all-reduce -> k_cp_primal<FROM_PRE>; k_cp_dual local)
+    colsum = oracle.rmatvec(oracle.Csr(ag.indptr, ag.indices, np.abs(ag.data), ag.shape), np.ones(rows))
+    tsum = allreduce(colsum)
+    tsum[tsum == 0] = 1
+    diag_t = 1 / tsum
+    rs = oracle.matvec(oracle.Csr(ag.indptr, ag.indices, np.abs(ag.data), ag.shape), np.ones(n))
+    rs[rs == 0] = 1
+    sigma = 1 / rs
+    x, y = np.zeros(n), np.zeros(rows)
+    for _ in range(60):
+        d = c + allreduce(oracle.rmatvec(ag, y))
+        x2 = np.minimum(np.maximum(x - diag_t * d, lb), ub)
+        z = 2 * x2 - x
+        x = x2
+        y = np.maximum(y + sigma * (oracle.matvec(ag, z) - bg), 0)
+    out["cp_x"] = x
+
+    # --- matrix-free ADMM, rows + their slack variables partitioned (slp_admm_cg.hip)
+    inv1 = np.empty(rows)
+    oracle._lib().orc_row_scale_l2(rows, oracle._p(ag.indptr), oracle._p(ag.data), oracle._p(inv1))
+    rowid = np.repeat(np.arange(rows), np.diff(ag.indptr))
+    a1 = oracle.Csr(ag.indptr, ag.indices, inv1[rowid] * ag.data, ag.shape)
+    bu = inv1 * bg
+    s2 = np.sqrt(np.add.reduceat(np.append(a1.data ** 2, 0.0), a1.indptr[:-1])[:rows] * (np.diff(a1.indptr) > 0) + 1.0)
+    inv2 = 1 / s2
+    a2 = oracle.Csr(a1.indptr, a1.indices, inv2[rowid] * a1.data, a1.shape)
+    sc = -inv2
+    ge, gi, alpha = 2.0, 3.0, 1.4
+    xo, xs = np.zeros(n), np.zeros(rows)            # original (replicated) | slack (local)
+    lbo, ubo, lbs, ubs = lb, ub, np.full(rows, -np.inf), bu
+    xpo, xps = np.maximum(xo, 0), np.maximum(xs, 0)
+    lam, lio, lis = np.zeros(rows), np.zeros(n), np.zeros(rows)
+    diro, dirs = np.zeros(n), np.zeros(rows)
+    co = c
+
+    def a_apply(vo, vs):
+        return oracle.matvec(a2, vo) + sc * vs
+
+    def at_apply(w):
+        return allreduce(oracle.rmatvec(a2, w)), sc * w
+
+    def dot(ao, as_, bo, bs):
+        return ao.dot(bo) + float(allreduce(np.array([as_.dot(bs)]))[0])
+
+    def m_apply(vo, vs):
+        uo, us = at_apply(a_apply(vo, vs))
+        return ge * uo + gi * vo, ge * us + gi * vs
+
+    for _ in range(30):
+        uo, us = at_apply(lam)
+        yo, ys = (-co + gi * xpo) - uo - lio, (gi * xps) - us - lis  # A^T b = 0 (b = 0 for slack form)
+        xprev_o, xprev_s = xo.copy(), xs.copy()
+        mo, ms = m_apply(xo, xs)
+        t = -dot(diro, dirs, mo - yo, ms - ys)
+        if abs(t) > 0:
+            mdo, mds = m_apply(diro, dirs)
+            step = t / dot(diro, dirs, mdo, mds)
+            xo, xs = xo + step * diro, xs + step * dirs
+        mo, ms = m_apply(xo, xs)
+        ro, rs_ = yo - mo, ys - ms
+        rsold = dot(ro, rs_, ro, rs_)
+        apo, aps = m_apply(ro, rs_)
+        a_cg = rsold / dot(ro, rs_, apo, aps)
+        xo, xs = xo + a_cg * ro, xs + a_cg * rs_
+        diro, dirs = xo - xprev_o, xs - xprev_s
+        xo, xs = alpha * xo + (1 - alpha) * xpo, alpha * xs + (1 - alpha) * xps
+        xpo = np.minimum(np.maximum(xo + lio / gi, lbo), ubo)
+        xps = np.minimum(np.maximum(xs + lis / gi, lbs), ubs)
+        lio, lis = lio + gi * (xo - xpo), lis + gi * (xs - xps)
+        lam = lam + ge * (a_apply(xo, xs) - 0.0)
+    out["admm_x"] = xo
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _worker(rank, world, port, q):
+    out = {}
+    _rank_main(rank, world, port, out)
+    q.put((rank, out))
+
+
+@pytest.mark.timeout(300)
+def test_row_partitioned_solvers_match_single_process_oracle():
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b, c, lb, ub = _small_lp()
+    x_ref, _ = oracle.chambolle_pock_ppd(c, None, None, a, None, b, lb, ub, nb_max_iter=60, nb_iter_plot=10 ** 9)
+    for r in range(world):
+        assert np.max(np.abs(results[r]["cp_x"] - x_ref)) < 1e-12          # partial sums add in another order
+    assert np.array_equal(results[0]["cp_x"], results[1]["cp_x"])          # replicas stay bit-identical
+    x_ref = oracle.lp_admm_cg(c, None, None, a, None, b, lb, ub, nb_iter=29, nb_iter_plot=10 ** 9)
+    for r in range(world):
+        assert np.max(np.abs(results[r]["admm_x"] - x_ref) / (1 + np.abs(x_ref))) < 1e-9
+    assert np.array_equal(results[0]["admm_x"], results[1]["admm_x"])

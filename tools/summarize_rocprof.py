@@ -1,0 +1,49 @@
+"""Condense rocprofv3 CSV output (gpurun_out/...) into the small summaries kept under profiles/.
+
+  python tools/summarize_rocprof.py stats  <kernel_stats.csv>            > profiles/rNN_<what>_kernel_stats.csv
+  python tools/summarize_rocprof.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/rNN_pmc.json
+
+PMC units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are in KiB; FETCH_SIZE reports one half of the bytes of a coalesced streaming read on gfx950, so it is
+doubled; WRITE_SIZE is taken as is.  Collected in separate --pmc passes (TCC slots).
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def stats(path):
+    rows = list(csv.DictReader(open(path)))
+    w = csv.writer(sys.stdout)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+    for r in rows[:25]:
+        w.writerow([short(r["Name"])[:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+
+
+def pmc(fetch_path, write_path):
+    out = collections.defaultdict(dict)
+    for path, counter in ((fetch_path, "FETCH_SIZE"), (write_path, "WRITE_SIZE")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            out[k][counter + "_KiB_mean_per_launch"] = sum(v) / len(v)
+            out[k][counter + "_launches"] = len(v)
+    res = {}
+    for k, d in out.items():
+        f = d.get("FETCH_SIZE_KiB_mean_per_launch", 0.0)
+        w = d.get("WRITE_SIZE_KiB_mean_per_launch", 0.0)
+        d["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
+        res[k] = d
+    keep = {k: v for k, v in res.items() if v["hbm_bytes_per_launch_corrected"] > 1e8}
+    print(json.dumps({"correction": "FETCH_SIZE x2 (gfx950, coalesced streaming reads), KiB -> bytes x1024", "kernels": keep}, indent=1))
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](*sys.argv[2:])
