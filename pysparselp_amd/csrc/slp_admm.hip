@@ -25,7 +25,24 @@ __global__ __launch_bounds__(kBlock) void k_gs_level(i64 count, const i32 *__res
     if (t >= count) return;
     const i32 i = rows[t];
     double v = 0.0;
-    for (i64 k = ptr[i]; k < ptr[i + 1]; ++k) v += x[idx[k]] * val[k];  // gaussSiedel.pyx:139-141
+    // gaussSiedel.pyx:139-141, same order of additions; the loads of a batch of 8 entries are issued
+    // together (a level is a latency chain: index -> x gather -> add), the adds stay sequential
+    const i64 e = ptr[i + 1];
+    for (i64 k = ptr[i]; k < e; k += 8) {
+        i32 j[8];
+        double a[8], xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const i64 kk = (k + q < e) ? k + q : e - 1;
+            j[q] = idx[kk];
+            a[q] = val[kk];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = x[j[q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (k + q < e) v += xv[q] * a[q];
+    }
     v = w * (b[i] - v) * invd[i] + x[i];                                 // :145
     const double l = lo[i], u = hi[i];
     if (v < l) v = l;                                                    // :148-151
@@ -285,6 +302,7 @@ struct slp_admm {
     double gamma_eq = 2, gamma_ineq = 3;
     int order = SLP_ORDER_AUTO, lanes_rows = 1, lanes_cols = 1;
     bool xp_is_x = false;     // false only before the first multiplier step (:98 vs :259)
+    IterGraph graph;
     DevBuf<double> b, c, lb, ub, x, xp0, lam, q, y, rowparts, colparts, out;
 };
 
@@ -386,7 +404,14 @@ void slp_admm_destroy(slp_admm *s) {
 int slp_admm_iterate(slp_admm *s, int64_t k) {
     SLP_API_INT({
         SLP_REQUIRE(s && k >= 0, "slp_admm_iterate: bad arguments");
-        for (i64 it = 0; it < k; ++it) { admm_sweep(s); admm_multiplier(s); }
+        auto one = [&]() { admm_sweep(s); admm_multiplier(s); };
+        if (k > 0 && !s->xp_is_x) {  // the first iteration reads xp0 instead of x: not part of the replayed graph
+            one();
+            --k;
+        }
+        // one launch per dependency level is launch-latency bound: replay the iteration as a captured graph
+        if (s->a->a.nnz <= 20000000) s->graph.run(k, s->plan.nlevels > 64 || s->plan.one_block ? 1 : 8, one);
+        else for (i64 it = 0; it < k; ++it) one();
     })
 }
 

@@ -10,6 +10,8 @@
 // is issued on the library's own stream, in order with the kernels around it.
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include "slp_common.h"
 
 namespace slp {
@@ -54,7 +56,14 @@ static void check(int rc, const char *what) {
     if (rc != 0) throw Error(std::string(what) + ": " + (g.error_string ? g.error_string(rc) : "RCCL error"));
 }
 
-bool comm_active() { return g.comm != nullptr && g.nranks > 1; }
+// SLP_FORCE_DISTRIBUTED=1 runs the partitioned code path (partial sums -> all-reduce -> update) on a single
+// rank too, so that it can be exercised on a one-GPU box; the all-reduce is then the identity.
+bool comm_active() {
+    if (g.comm == nullptr) return false;
+    if (g.nranks > 1) return true;
+    const char *e = getenv("SLP_FORCE_DISTRIBUTED");
+    return e && e[0] == '1';
+}
 
 void comm_allreduce_dev(double *buf, i64 count, int op) {
     SLP_REQUIRE(g.comm, "slp_comm_init has not been called");

@@ -271,6 +271,7 @@ struct slp_cp {
     int lanes_rows = 1, lanes_cols = 1;
     DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, kz, rowparts, colparts, out;
     bool distributed = false;
+    IterGraph graph;
 };
 
 namespace slp {
@@ -278,6 +279,9 @@ namespace slp {
 static void cp_setup(slp_cp *s) {
     hipStream_t st = ctx().stream;
     build_transpose(s->k);
+    // derived formats are settled here, never lazily inside a (possibly captured) iteration
+    fast_format(s->k, true);
+    if (fast_format(s->k, false)) s->kz.alloc((size_t)s->m);
     const CsrDev &a = s->k->a, &at = s->k->at;
     s->lanes_rows = lanes_for(a, s->order);
     s->lanes_cols = lanes_for(at, s->order);
@@ -427,10 +431,10 @@ void slp_cp_destroy(slp_cp *s) {
 int slp_cp_iterate(slp_cp *s, int64_t k) {
     SLP_API_INT({
         SLP_REQUIRE(s && k >= 0, "slp_cp_iterate: bad arguments");
-        for (i64 it = 0; it < k; ++it) {
-            cp_primal(s, false);
-            cp_dual(s);
-        }
+        auto one = [&]() { cp_primal(s, false); cp_dual(s); };
+        // cache-resident problems are launch-latency bound: replay a captured graph of 16 iterations
+        if (!s->distributed && s->k->a.nnz <= 20000000) s->graph.run(k, 16, one);
+        else for (i64 it = 0; it < k; ++it) one();
     })
 }
 

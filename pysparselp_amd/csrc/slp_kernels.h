@@ -71,8 +71,24 @@ __device__ __forceinline__ double row_dot(const i64 *__restrict__ ptr, const i32
                                           i64 row, int sub) {
     const i64 s = ptr[row], e = ptr[row + 1];
     if (L == 1) {
+        // single accumulator, storage order; loads are issued four entries at a time so that the
+        // index -> gather latency chain is paid once per batch, the adds stay in order
         double acc = 0.0;
-        for (i64 k = s; k < e; ++k) acc += val[k] * x[idx[k]];
+        for (i64 k = s; k < e; k += 4) {
+            i32 j[4];
+            double a[4], xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i64 kk = (k + q < e) ? k + q : e - 1;
+                j[q] = idx[kk];
+                a[q] = val[kk];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[q] = x[j[q]];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k + q < e) acc += a[q] * xv[q];
+        }
         return acc;
     } else {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;

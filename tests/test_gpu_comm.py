@@ -1,0 +1,59 @@
+"""RCCL path on one GPU: the communicator is created with a single rank and
+SLP_FORCE_DISTRIBUTED=1 routes the solvers through the partitioned code path
+(partial column sums -> all-reduce -> update; scalar all-reduces for dot
+products and report terms).  With one rank the all-reduce is the identity, so the
+results must equal the non-partitioned run.  Runs in a subprocess because the
+communicator is process-wide.  -m gpu."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r)
+os.environ["SLP_FORCE_DISTRIBUTED"] = "1"
+os.environ["SLP_STRIP_MIN_NNZ"] = %(min_nnz)r
+from pysparselp_amd import _lib
+from pysparselp_amd.problems import random_lp_on_device
+from pysparselp_amd.scale import DeviceCP
+from pysparselp_amd.admm_cg import DeviceADMM
+lib = _lib.lib(0)
+n, m, p = 30000, 40000, 0.001
+
+def run():
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=3)
+    cp = DeviceCP(a, b, c, lb, ub); cp.iterate(30); x_cp = cp.x(); cp.close()
+    admm = DeviceADMM(a, b, c, lb, ub); admm.iterate(15); x_admm = admm.x(n); rep = admm.report(); admm.close()
+    a.close()
+    return x_cp, x_admm, rep
+
+plain = run()                                   # no communicator yet: single-GPU code path
+uid = ctypes.create_string_buffer(128)
+_lib.check(lib.slp_comm_unique_id(uid))
+_lib.check(lib.slp_comm_init(1, 0, uid))
+v = np.array([1.5, -2.0]); _lib.check(lib.slp_comm_allreduce_host(_lib.ptr(v), 2, 0)); assert np.array_equal(v, [1.5, -2.0])
+_lib.check(lib.slp_comm_barrier())
+part = run()                                    # partitioned code path, one rank
+_lib.check(lib.slp_comm_finalize())
+if os.environ["SLP_STRIP_MIN_NNZ"] == "1":      # strip kernels: sequential-order sums on both paths
+    assert np.array_equal(plain[0], part[0]), np.max(np.abs(plain[0] - part[0]))
+else:                                           # lane-parallel sums: the two paths unroll differently
+    assert np.max(np.abs(plain[0] - part[0]) / (1 + np.abs(plain[0]))) < 1e-12
+assert np.max(np.abs(plain[1] - part[1]) / (1 + np.abs(plain[1]))) < 1e-12
+assert np.allclose(plain[2], part[2], rtol=1e-10)
+print("COMM-OK")
+"""
+
+
+@pytest.mark.parametrize("min_nnz", ["1", "1000000000"])  # strip kernels / generic kernels
+def test_partitioned_path_single_rank(min_nnz):
+    code = SCRIPT % {"repo": REPO, "min_nnz": min_nnz}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "COMM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
