@@ -101,7 +101,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     lib = _lib.lib(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SLP_BENCH_FORCE_DIST") == "1":  # the latter: one-GPU test of the whole N > 1 plumbing
+        os.environ.setdefault("MASTER_PORT", "29511")
         import torch.distributed as dist  # gloo, CPU: control plane only (RCCL id exchange)
 
         from pysparselp_amd.parallel import init_comm
@@ -207,7 +208,7 @@ def main():
         print(json.dumps(out), flush=True)
     solver.close()
     a.close()
-    if world > 1:
+    if dist is not None:
         _lib.check(lib.slp_comm_barrier())
         _lib.check(lib.slp_comm_finalize())
         dist.destroy_process_group()

@@ -25,6 +25,11 @@ class _CGBase:
 
     __del__ = close
 
+    def set_reuse(self, reuse):
+        """``True``: 8 matrix passes per iteration (the CG residual reuses the line search's products)."""
+        _lib.check(self._l.slp_admm_cg_set_reuse(self._h, int(bool(reuse))))
+        self.reuse = bool(reuse)
+
     def iterate(self, k):
         _lib.check(self._l.slp_admm_cg_iterate(self._h, int(k)))
 
@@ -62,7 +67,7 @@ class DeviceADMM(_CGBase):
     """All-inequality LP over a DeviceMatrix; setup transforms run on the device and scale the
     matrix IN PLACE (the DeviceMatrix then holds the row-normalised values)."""
 
-    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO):
+    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO, reuse=True):
         self._l = _lib.lib()
         self.a = a
         self.n = a.shape[1]
@@ -71,21 +76,23 @@ class DeviceADMM(_CGBase):
         b_upper, lb, ub = _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
         self._h = _lib.check_handle(self._l.slp_admm_cg_create_on(a._h, _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
                                                                   _lib.ptr(ub), float(gamma_eq), float(gamma_ineq), int(order)))
+        self.set_reuse(reuse)
 
     def objective(self):
         return float(self.c.dot(self.x(self.n)))
 
-    @staticmethod
-    def matrix_passes_per_iteration():
-        return 10  # A^T lambda, 4 x (A v, A^T w) for the M-products, A x for the multiplier
+    def matrix_passes_per_iteration(self):
+        # A^T lambda, (A v, A^T w) for each product M v (4, or 3 with reuse), A x for the multiplier
+        return 8 if self.reuse else 10
 
-    @staticmethod
-    def describe():
-        return "ADMM, matrix-free conjugate-gradient x-step of the reference (ADMM.py:182-201), gamma_eq=2, gamma_ineq=3"
+    def describe(self):
+        return ("ADMM, matrix-free conjugate-gradient x-step of the reference (ADMM.py:182-201), gamma_eq=2, gamma_ineq=3, "
+                + ("8 matrix passes (CG residual reuses the line-search products)" if self.reuse else "10 matrix passes"))
 
 
 def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2, gamma_ineq=3, nb_iter=100,
-               callback_func=None, max_time=None, use_preconditioning=True, nb_iter_plot=10, order=ORDER_AUTO):
+               callback_func=None, max_time=None, use_preconditioning=True, nb_iter_plot=10, order=ORDER_AUTO,
+               reuse=False):
     """``lp_admm`` of the reference with its ``use_cg`` flags; same signature, callback and return value."""
     c = _lib.f64(c)
     n = c.size
@@ -99,6 +106,7 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
     if use_preconditioning:
         a, b = precondition_constraints(a, b, alpha=2)
     state = ADMMCGState(a, b, c2, lb2, ub2, x_init, gamma_eq, gamma_ineq, order)
+    state.set_reuse(reuse)
     try:
         start = time.perf_counter()
         i = 0

@@ -67,11 +67,12 @@ __device__ __forceinline__ double at_elem(i64 j, i64 n_o, const double *__restri
 
 // Elementwise passes over the N unknowns.  Each also produces one dot product, split into the part over
 // the replicated original variables (slot) and the part over this rank's slack variables (slot + 1).
-enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7 };
+enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7, E_RESID_REUSE = 8 };
 
 struct CgVecs {
     const double *q, *c, *lb, *ub, *u, *sc, *w;
-    double *x, *xp, *y, *dir, *xprev, *r, *lin;
+    double *x, *xp, *y, *dir, *xprev, *r, *lin, *mx, *md;
+    int keep;  // store M x and M dir for E_RESID_REUSE
     const double *scal;
     i64 n_o, N;
     double gamma_eq, gamma_ineq, alpha, one_minus_alpha;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
     double acc_o = 0.0, acc_s = 0.0;
     double f = 0.0;
     bool on = true;
-    if (OP == E_LINE_STEP) {
+    if (OP == E_LINE_STEP || OP == E_RESID_REUSE) {
         const double t = -(a.scal[S_T] + a.scal[S_T + 1]);
         on = fabs(t) > 0.0;                                      // ADMM.py:192
         f = t / (a.scal[S_DMD] + a.scal[S_DMD + 1]);             // :193
@@ -97,15 +98,22 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
             a.xprev[j] = a.x[j];
         } else if (OP == E_LINE_T) {  // t = -dir.(M x - y) (:191)
             const double mx = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.x[j];
+            if (a.keep) a.mx[j] = mx;
             term = a.dir[j] * (mx - a.y[j]);
         } else if (OP == E_LINE_DMD) {  // dir.(M dir) (:193)
             const double md = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.dir[j];
+            if (a.keep) a.md[j] = md;
             term = a.dir[j] * md;
         } else if (OP == E_LINE_STEP) {  // x = x + step * dir (:194)
             if (on) a.x[j] = a.x[j] + f * a.dir[j];
         } else if (OP == E_RESID) {  // r = y - M x ; p = r ; rsold = r.r (conjgrad :33-35)
             const double mx = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.x[j];
             const double r = a.y[j] - mx;
+            a.r[j] = r;
+            term = r * r;
+        } else if (OP == E_RESID_REUSE) {  // same residual from the stored products: M(x + step dir) = M x + step M dir
+            const double mxn = on ? a.mx[j] + f * a.md[j] : a.mx[j];
+            const double r = a.y[j] - mxn;
             a.r[j] = r;
             term = r * r;
         } else if (OP == E_PAP) {  // p.(M p) (conjgrad :37-38)
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
         if (j < a.n_o) acc_o += term;
         else acc_s += term;
     }
-    if (OP == E_LINE_T || OP == E_LINE_DMD || OP == E_RESID || OP == E_PAP) {
+    if (OP == E_LINE_T || OP == E_LINE_DMD || OP == E_RESID || OP == E_RESID_REUSE || OP == E_PAP) {
         const double ro = block_reduce<false>(acc_o, lds), rs = block_reduce<false>(acc_s, lds);
         if (threadIdx.x == 0) {
             part[blockIdx.x * 2] = ro;
@@ -264,8 +272,9 @@ struct slp_admm_cg {
     double gamma_eq = 2, gamma_ineq = 3, alpha = 1.4;
     int order = SLP_ORDER_AUTO, lanes_rows = 1, lanes_cols = 1;
     bool distributed = false;
+    bool reuse = false;   // 8 matrix passes instead of 10: the CG residual reuses M x and M dir of the line search
     DevBuf<double> sc, b, lam, w;                                         // rows
-    DevBuf<double> c, lb, ub, x, xp, y, q, dir, xprev, r, lin, u;        // unknowns (u: n_o)
+    DevBuf<double> c, lb, ub, x, xp, y, q, dir, xprev, r, lin, u, mx, md;        // unknowns (u: n_o)
     DevBuf<double> part, rowpart, colpart, scal, out;
 };
 
@@ -312,6 +321,7 @@ static CgVecs cg_vecs(slp_admm_cg *s) {
     CgVecs v;
     v.q = s->q.p; v.c = s->c.p; v.lb = s->lb.p; v.ub = s->ub.p; v.u = s->u.p; v.sc = s->sc.p; v.w = s->w.p;
     v.x = s->x.p; v.xp = s->xp.p; v.y = s->y.p; v.dir = s->dir.p; v.xprev = s->xprev.p; v.r = s->r.p; v.lin = s->lin.p;
+    v.mx = s->mx.p; v.md = s->md.p; v.keep = s->reuse ? 1 : 0;
     v.scal = s->scal.p; v.n_o = s->n_o; v.N = s->N;
     v.gamma_eq = s->gamma_eq; v.gamma_ineq = s->gamma_ineq; v.alpha = s->alpha; v.one_minus_alpha = 1.0 - s->alpha;
     return v;
@@ -339,7 +349,11 @@ static void cg_xstep(slp_admm_cg *s) {
     cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_LINE_T>(s, S_T);
     cg_rows(s, s->dir.p); cg_cols(s, s->w.p); cg_elem<E_LINE_DMD>(s, S_DMD);
     cg_elem<E_LINE_STEP>(s, -1);
-    cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_RESID>(s, S_RS);
+    if (s->reuse) {
+        cg_elem<E_RESID_REUSE>(s, S_RS);
+    } else {
+        cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_RESID>(s, S_RS);
+    }
     cg_rows(s, s->r.p); cg_cols(s, s->w.p); cg_elem<E_PAP>(s, S_PAP);
     cg_elem<E_UPDATE>(s, -1);
 }
@@ -475,6 +489,14 @@ int slp_admm_cg_iterate(slp_admm_cg *s, int64_t k) {
     SLP_API_INT({
         SLP_REQUIRE(s && k >= 0, "slp_admm_cg_iterate: bad arguments");
         for (i64 it = 0; it < k; ++it) { cg_xstep(s); cg_multipliers(s); }
+    })
+}
+
+int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse) {
+    SLP_API_INT({
+        SLP_REQUIRE(s, "NULL handle");
+        if (reuse && s->mx.n < (size_t)s->N) { s->mx.alloc((size_t)s->N); s->md.alloc((size_t)s->N); s->mx.zero(); s->md.zero(); }
+        s->reuse = reuse != 0;
     })
 }
 

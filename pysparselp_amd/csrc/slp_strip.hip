@@ -125,6 +125,8 @@ __global__ __launch_bounds__(kStripR) void k_strip_fill(i64 nrow, i64 T, const i
 // ---- the product ---------------------------------------------------------------
 // One workgroup per row block; 64 KB x-tile + 8 KB running sums + 1 KB slot offsets of LDS
 // (two workgroups per CU).  out[row] = sum over the row (single accumulator, storage order).
+// ABLATE (timing experiments only, wrong results): 1 = no x-tile staging, 2 = no entry streaming
+template <int ABLATE>
 __global__ __launch_bounds__(kStripR, 8) void k_strip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                         const unsigned short *__restrict__ perm,
                                                         const unsigned char *__restrict__ slen,
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kStripR, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
         // stage the strip of x: 8 doubles per thread, 16-byte loads
         const i64 c0 = t * (i64)kStripC;
 #pragma unroll
-        for (int q = 0; q < kStripC / kStripR / 2; ++q) {
+        for (int q = 0; q < (ABLATE == 1 ? 0 : kStripC / kStripR / 2); ++q) {
             const int j = (q * kStripR + p) * 2;
             double2 v = make_double2(0.0, 0.0);
             if (c0 + j + 1 < ncol) v = *reinterpret_cast<const double2 *>(x + c0 + j);
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(kStripR, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
         }
         if (p < kStripSL) offs[p] = soff[cell * kStripSL + p];
         const unsigned int r = perm[cell * kStripR + p];
-        const unsigned int n = slen[cell * kStripR + p];
+        const unsigned int n = (ABLATE == 2) ? 0u : slen[cell * kStripR + p];
         const double *__restrict__ v = val + base[cell];
         const unsigned short *__restrict__ c = col + base[cell];
         __syncthreads();
@@ -223,8 +225,15 @@ bool strip_build(const CsrDev &a, StripJds &f) {
 }
 
 void strip_spmv(const StripJds &f, const double *x, double *out) {
-    hipLaunchKernelGGL(k_strip_spmv, dim3((unsigned)f.B), dim3(kStripR), 0, ctx().stream, f.nrow, f.ncol, f.T, f.base.p, f.perm.p,
-                       f.slen.p, f.soff.p, f.val.p, f.col.p, x, out);
+    const char *e = getenv("SLP_STRIP_ABLATE");
+    const int ab = e ? atoi(e) : 0;
+#define SLP_STRIP_LAUNCH(A)                                                                                                        \
+    hipLaunchKernelGGL((k_strip_spmv<A>), dim3((unsigned)f.B), dim3(kStripR), 0, ctx().stream, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, \
+                       f.slen.p, f.soff.p, f.val.p, f.col.p, x, out)
+    if (ab == 1) SLP_STRIP_LAUNCH(1);
+    else if (ab == 2) SLP_STRIP_LAUNCH(2);
+    else SLP_STRIP_LAUNCH(0);
+#undef SLP_STRIP_LAUNCH
     SLP_HIP(hipGetLastError());
 }
 

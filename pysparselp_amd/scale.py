@@ -45,12 +45,10 @@ class DeviceCP:
         _lib.check(self._l.slp_cp_bench(self._h, int(k), _lib.ptr(ms)))
         return ms
 
-    @staticmethod
-    def matrix_passes_per_iteration():
+    def matrix_passes_per_iteration(self):
         return 2  # one A^T y, one A z
 
-    @staticmethod
-    def describe():
+    def describe(self):
         return "diagonally preconditioned Chambolle-Pock, alpha=1, theta=1"
 
 
