@@ -9,15 +9,16 @@
 // peak) instead of streaming the matrix.  Here the matrix is cut into vertical
 // strips of C columns; a workgroup owns R rows, keeps their R running sums in
 // LDS, and walks the strips: it stages x[strip] (C doubles) in LDS once and then
-// streams the cell's entries with perfectly coalesced loads -- lane p reads
-// entry `slot_offset[s] + p` for s = 0, 1, ... -- and gathers x from LDS.
+// streams the cell's entries with perfectly coalesced loads and gathers x from LDS.
 //
 // Layout of one cell (row block b, strip t), all cells back to back, b-major:
 //   rows of the cell are sorted by their entry count in the strip (descending),
 //   `perm[p]` = local row at sorted position p, `len[p]` = its count;
 //   jagged diagonal s holds the s-th entry of every row with len > s, in sorted
-//   order, so diagonal s has cnt[s] entries at offset soff[s] = sum_{s'<s} cnt[s'].
+//   order, padded to an even number of entries, at offset soff[s] inside the cell.
 //   Entry = (fp64 value, uint16 column inside the strip): 10 B instead of 12 B.
+// Thread p of the 1024 owns sorted positions 2p and 2p+1: one 16-byte load brings
+// the s-th value of both rows, one 4-byte load both columns.
 // A row's entries keep their column order across and inside strips, and each
 // row is accumulated by one thread at a time starting from its running sum, so
 // the result equals the SEQUENTIAL single-accumulator sum of the CSR row -- bit
@@ -33,155 +34,186 @@
 
 namespace slp {
 
-constexpr int kStripC = 8192;    // columns per strip: 64 KB of x in LDS
-constexpr int kStripR = 1024;    // rows per block = threads per workgroup
+constexpr int kStripC = 7680;    // columns per strip: 60 KB of x in LDS
+constexpr int kStripT = 1024;    // threads per workgroup
+constexpr int kStripR = 2048;    // rows per block (two per thread)
 constexpr int kStripSL = 256;    // slots (max entries of one row inside one strip)
+static_assert(kStripC % 2 == 0 && kStripR == 2 * kStripT, "strip geometry");
 
 // ---- conversion -------------------------------------------------------------
-// pass 1: per (block, strip): every row's entry count (uint8) and the cell total
-__global__ __launch_bounds__(kStripR) void k_strip_count(i64 nrow, i64 T, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+// pass 1: per (block, strip): every row's entry count (uint8) and the padded cell size
+//         sum_s even(cnt[s]),  cnt[s] = rows of the cell with more than s entries
+__global__ __launch_bounds__(kStripT) void k_strip_count(i64 nrow, i64 T, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
                                                          unsigned char *__restrict__ len, unsigned long long *__restrict__ total,
                                                          int *__restrict__ bad) {
-    __shared__ unsigned long long lds[kStripR / kWave];
+    __shared__ unsigned int hist[kStripSL];
     const i64 b = blockIdx.x;
-    const i64 row = b * kStripR + threadIdx.x;
-    i64 k = 0, e = 0;
-    if (row < nrow) { k = ptr[row]; e = ptr[row + 1]; }
-    i32 prev = -1;
+    i64 k[2], e[2];
+    i32 prev[2] = {-1, -1};
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + threadIdx.x;
+        k[h] = e[h] = 0;
+        if (row < nrow) { k[h] = ptr[row]; e[h] = ptr[row + 1]; }
+    }
     for (i64 t = 0; t < T; ++t) {
+        if (threadIdx.x < kStripSL) hist[threadIdx.x] = 0;
+        __syncthreads();
         const i64 hi = (t + 1) * (i64)kStripC;
-        i64 c = 0;
-        while (k < e) {
-            const i32 j = idx[k];
-            if (j >= hi) break;
-            if (j <= prev) atomicOr(bad, 1);  // rows must be strictly increasing in column
-            prev = j;
-            ++k; ++c;
+        for (int h = 0; h < 2; ++h) {
+            i64 c = 0;
+            while (k[h] < e[h]) {
+                const i32 j = idx[k[h]];
+                if (j >= hi) break;
+                if (j <= prev[h]) atomicOr(bad, 1);  // rows must be strictly increasing in column
+                prev[h] = j;
+                ++k[h]; ++c;
+            }
+            if (c >= kStripSL) { atomicOr(bad, 2); c = kStripSL - 1; }
+            len[(b * T + t) * kStripR + h * kStripT + threadIdx.x] = (unsigned char)c;
+            atomicAdd(&hist[c], 1u);
         }
-        if (c >= kStripSL) { atomicOr(bad, 2); c = kStripSL - 1; }
-        len[(b * T + t) * kStripR + threadIdx.x] = (unsigned char)c;
-        // workgroup sum of c
-        unsigned long long v = (unsigned long long)c;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-        if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = v;
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned long long s = 0;
-            for (int i = 0; i < kStripR / kWave; ++i) s += lds[i];
-            total[b * T + t] = s;
+            unsigned int above = 0;  // rows with a count > l
+            unsigned long long sum = 0;
+            for (int l = kStripSL - 1; l >= 0; --l) {
+                sum += (above + 1u) & ~1u;  // slot l holds `above` entries, padded to even (0 stays 0)
+                above += hist[l];
+            }
+            total[b * T + t] = sum;
         }
         __syncthreads();
     }
 }
 
 // pass 2: sort the rows of every cell by count, write perm / sorted len / slot offsets and the entries
-__global__ __launch_bounds__(kStripR) void k_strip_fill(i64 nrow, i64 T, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+// (the output arrays are zero-filled beforehand: the pad entries stay (0.0, column 0))
+__global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
                                                         const double *__restrict__ val, const unsigned char *__restrict__ len,
                                                         const i64 *__restrict__ base, unsigned short *__restrict__ perm,
                                                         unsigned char *__restrict__ slen, unsigned int *__restrict__ soff,
                                                         double *__restrict__ oval, unsigned short *__restrict__ ocol) {
-    __shared__ unsigned int hist[kStripSL];   // rows with exactly this count
+    __shared__ unsigned int hist[kStripSL];   // rows with exactly this count, then the per-count cursor
     __shared__ unsigned int start[kStripSL];  // rows with a larger count  (= first sorted position of this count)
     __shared__ unsigned int offs[kStripSL];   // slot offsets
     const i64 b = blockIdx.x;
-    const i64 row = b * kStripR + threadIdx.x;
-    i64 k = (row < nrow) ? ptr[row] : 0;
+    i64 k[2];
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + threadIdx.x;
+        k[h] = (row < nrow) ? ptr[row] : 0;
+    }
     for (i64 t = 0; t < T; ++t) {
         const i64 cell = b * T + t;
         if (threadIdx.x < kStripSL) hist[threadIdx.x] = 0;
         __syncthreads();
-        const unsigned int c = len[cell * kStripR + threadIdx.x];
-        atomicAdd(&hist[c], 1u);
+        unsigned int c[2];
+        for (int h = 0; h < 2; ++h) {
+            c[h] = len[cell * kStripR + h * kStripT + threadIdx.x];
+            atomicAdd(&hist[c[h]], 1u);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned int above = 0;
             for (int l = kStripSL - 1; l >= 0; --l) { start[l] = above; above += hist[l]; }
-            // cnt[s] = rows with count > s = start[s];  soff[s] = sum_{s' < s} cnt[s']
-            unsigned int o = 0;
-            for (int s = 0; s < kStripSL; ++s) { offs[s] = o; o += start[s]; }
+            unsigned int o = 0;  // cnt[s] = start[s]; slot s occupies even(cnt[s]) entries
+            for (int s = 0; s < kStripSL; ++s) { offs[s] = o; o += (start[s] + 1u) & ~1u; }
         }
         __syncthreads();
         if (threadIdx.x < kStripSL) {
             soff[cell * kStripSL + threadIdx.x] = offs[threadIdx.x];
-            hist[threadIdx.x] = 0;  // reused as the per-count cursor
+            hist[threadIdx.x] = 0;
         }
         __syncthreads();
-        const unsigned int pos = start[c] + atomicAdd(&hist[c], 1u);
-        perm[cell * kStripR + pos] = (unsigned short)threadIdx.x;
-        slen[cell * kStripR + pos] = (unsigned char)c;
         const i64 bs = base[cell];
         const i32 col0 = (i32)(t * (i64)kStripC);
-        for (unsigned int s = 0; s < c; ++s) {
-            const i64 o = bs + offs[s] + pos;
-            oval[o] = val[k + s];
-            ocol[o] = (unsigned short)(idx[k + s] - col0);
+        for (int h = 0; h < 2; ++h) {
+            const unsigned int pos = start[c[h]] + atomicAdd(&hist[c[h]], 1u);
+            perm[cell * kStripR + pos] = (unsigned short)(h * kStripT + threadIdx.x);
+            slen[cell * kStripR + pos] = (unsigned char)c[h];
+            for (unsigned int s = 0; s < c[h]; ++s) {
+                const i64 o = bs + offs[s] + pos;
+                oval[o] = val[k[h] + s];
+                ocol[o] = (unsigned short)(idx[k[h] + s] - col0);
+            }
+            k[h] += c[h];
         }
-        k += c;
         __syncthreads();
     }
 }
 
 // ---- the product ---------------------------------------------------------------
-// One workgroup per row block; 64 KB x-tile + 8 KB running sums + 1 KB slot offsets of LDS
+// One workgroup per row block; 60 KB x-tile + 16 KB running sums + 1 KB slot offsets of LDS
 // (two workgroups per CU).  out[row] = sum over the row (single accumulator, storage order).
 // ABLATE (timing experiments only, wrong results): 1 = no x-tile staging, 2 = no entry streaming
 template <int ABLATE>
-__global__ __launch_bounds__(kStripR, 8) void k_strip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
-                                                        const unsigned short *__restrict__ perm,
-                                                        const unsigned char *__restrict__ slen,
-                                                        const unsigned int *__restrict__ soff, const double *__restrict__ val,
-                                                        const unsigned short *__restrict__ col, const double *__restrict__ x,
-                                                        double *__restrict__ out) {
+__global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
+                                                           const unsigned short *__restrict__ perm,
+                                                           const unsigned char *__restrict__ slen,
+                                                           const unsigned int *__restrict__ soff, const double *__restrict__ val,
+                                                           const unsigned short *__restrict__ col, const double *__restrict__ x,
+                                                           double *__restrict__ out) {
     __shared__ double xt[kStripC];
     __shared__ double acc[kStripR];
     __shared__ unsigned int offs[kStripSL];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
     acc[p] = 0.0;
+    acc[p + kStripT] = 0.0;
     for (i64 t = 0; t < T; ++t) {
         const i64 cell = b * T + t;
-        // stage the strip of x: 8 doubles per thread, 16-byte loads
+        // stage the strip of x with 16-byte loads
         const i64 c0 = t * (i64)kStripC;
 #pragma unroll
-        for (int q = 0; q < (ABLATE == 1 ? 0 : kStripC / kStripR / 2); ++q) {
-            const int j = (q * kStripR + p) * 2;
-            double2 v = make_double2(0.0, 0.0);
-            if (c0 + j + 1 < ncol) v = *reinterpret_cast<const double2 *>(x + c0 + j);
-            else if (c0 + j < ncol) v.x = x[c0 + j];
-            *reinterpret_cast<double2 *>(&xt[j]) = v;
+        for (int q = 0; q < (ABLATE == 1 ? 0 : (kStripC / 2 + kStripT - 1) / kStripT); ++q) {
+            const int j = (q * kStripT + p) * 2;
+            if (j < kStripC) {
+                double2 v = make_double2(0.0, 0.0);
+                if (c0 + j + 1 < ncol) v = *reinterpret_cast<const double2 *>(x + c0 + j);
+                else if (c0 + j < ncol) v.x = x[c0 + j];
+                *reinterpret_cast<double2 *>(&xt[j]) = v;
+            }
         }
         if (p < kStripSL) offs[p] = soff[cell * kStripSL + p];
-        const unsigned int r = perm[cell * kStripR + p];
-        const unsigned int n = (ABLATE == 2) ? 0u : slen[cell * kStripR + p];
-        const double *__restrict__ v = val + base[cell];
-        const unsigned short *__restrict__ c = col + base[cell];
+        const ushort2 r = reinterpret_cast<const ushort2 *>(perm + cell * kStripR)[p];
+        const uchar2 nn = reinterpret_cast<const uchar2 *>(slen + cell * kStripR)[p];
+        const unsigned int n0 = (ABLATE == 2) ? 0u : nn.x, n1 = (ABLATE == 2) ? 0u : nn.y;  // n0 >= n1 (sorted)
+        const double2 *__restrict__ v2 = reinterpret_cast<const double2 *>(val + base[cell]);
+        const ushort2 *__restrict__ c2 = reinterpret_cast<const ushort2 *>(col + base[cell]);
         __syncthreads();
-        double a = acc[r];
+        double a0 = acc[r.x], a1 = acc[r.y];
         unsigned int s = 0;
-        for (; s + 4 <= n; s += 4) {  // four independent loads in flight per lane
-            const unsigned int o0 = offs[s] + p, o1 = offs[s + 1] + p, o2 = offs[s + 2] + p, o3 = offs[s + 3] + p;
-            const double v0 = v[o0], v1 = v[o1], v2 = v[o2], v3 = v[o3];
-            const unsigned int j0 = c[o0], j1 = c[o1], j2 = c[o2], j3 = c[o3];
-            a += v0 * xt[j0];
-            a += v1 * xt[j1];
-            a += v2 * xt[j2];
-            a += v3 * xt[j3];
+        for (; s + 4 <= n0; s += 4) {  // four independent 16-byte + 4-byte loads in flight per lane
+            const unsigned int o0 = (offs[s] >> 1) + p, o1 = (offs[s + 1] >> 1) + p, o2 = (offs[s + 2] >> 1) + p,
+                               o3 = (offs[s + 3] >> 1) + p;
+            const double2 w0 = v2[o0], w1 = v2[o1], w2 = v2[o2], w3 = v2[o3];
+            const ushort2 j0 = c2[o0], j1 = c2[o1], j2 = c2[o2], j3 = c2[o3];
+            a0 += w0.x * xt[j0.x];
+            a0 += w1.x * xt[j1.x];
+            a0 += w2.x * xt[j2.x];
+            a0 += w3.x * xt[j3.x];
+            if (s < n1) a1 += w0.y * xt[j0.y];
+            if (s + 1 < n1) a1 += w1.y * xt[j1.y];
+            if (s + 2 < n1) a1 += w2.y * xt[j2.y];
+            if (s + 3 < n1) a1 += w3.y * xt[j3.y];
         }
-        for (; s < n; ++s) {
-            const unsigned int o = offs[s] + p;
-            a += v[o] * xt[c[o]];
+        for (; s < n0; ++s) {
+            const unsigned int o = (offs[s] >> 1) + p;
+            const double2 w = v2[o];
+            const ushort2 j = c2[o];
+            a0 += w.x * xt[j.x];
+            if (s < n1) a1 += w.y * xt[j.y];
         }
-        acc[r] = a;
+        acc[r.x] = a0;
+        acc[r.y] = a1;
         __syncthreads();
     }
-    const i64 row = b * kStripR + p;
-    if (row < nrow) out[row] = acc[p];
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + p;
+        if (row < nrow) out[row] = acc[h * kStripT + p];
+    }
 }
 
 // ---- host side ------------------------------------------------------------------
-void strip_release(StripJds &f) { f = StripJds(); }
-
 // Builds the strip format of `a` (rows sorted by column).  Returns false (and leaves f.ok == false)
 // when the matrix does not qualify: unsorted rows, or a row with >= 256 entries inside one strip.
 bool strip_build(const CsrDev &a, StripJds &f) {
@@ -195,7 +227,7 @@ bool strip_build(const CsrDev &a, StripJds &f) {
     DevBuf<int> bad(1);
     total.zero();
     bad.zero();
-    hipLaunchKernelGGL(k_strip_count, dim3((unsigned)B), dim3(kStripR), 0, st, a.nrow, T, a.ptr.p, a.idx.p, len.p, total.p, bad.p);
+    hipLaunchKernelGGL(k_strip_count, dim3((unsigned)B), dim3(kStripT), 0, st, a.nrow, T, a.ptr.p, a.idx.p, len.p, total.p, bad.p);
     SLP_HIP(hipGetLastError());
     int hbad = 0;
     bad.download(&hbad, 1);
@@ -210,12 +242,17 @@ bool strip_build(const CsrDev &a, StripJds &f) {
                                         rocprim::plus<unsigned long long>(), st));
         SLP_HIP(hipStreamSynchronize(st));
     }
+    i64 padded = 0;
+    SLP_HIP(hipMemcpyAsync(&padded, f.base.p + cells, sizeof(i64), hipMemcpyDeviceToHost, st));
+    SLP_HIP(hipStreamSynchronize(st));
     f.perm.alloc(cells * kStripR);
     f.slen.alloc(cells * kStripR);
     f.soff.alloc(cells * kStripSL);
-    f.val.alloc((size_t)a.nnz);
-    f.col.alloc((size_t)a.nnz);
-    hipLaunchKernelGGL(k_strip_fill, dim3((unsigned)B), dim3(kStripR), 0, st, a.nrow, T, a.ptr.p, a.idx.p, a.val.p, len.p, f.base.p,
+    f.val.alloc((size_t)padded);
+    f.col.alloc((size_t)padded);
+    f.val.zero();
+    f.col.zero();
+    hipLaunchKernelGGL(k_strip_fill, dim3((unsigned)B), dim3(kStripT), 0, st, a.nrow, T, a.ptr.p, a.idx.p, a.val.p, len.p, f.base.p,
                        f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p);
     SLP_HIP(hipGetLastError());
     SLP_HIP(hipStreamSynchronize(st));
@@ -228,7 +265,7 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
     const char *e = getenv("SLP_STRIP_ABLATE");
     const int ab = e ? atoi(e) : 0;
 #define SLP_STRIP_LAUNCH(A)                                                                                                        \
-    hipLaunchKernelGGL((k_strip_spmv<A>), dim3((unsigned)f.B), dim3(kStripR), 0, ctx().stream, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, \
+    hipLaunchKernelGGL((k_strip_spmv<A>), dim3((unsigned)f.B), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, \
                        f.slen.p, f.soff.p, f.val.p, f.col.p, x, out)
     if (ab == 1) SLP_STRIP_LAUNCH(1);
     else if (ab == 2) SLP_STRIP_LAUNCH(2);
