@@ -173,6 +173,8 @@ struct CsrDev {
 struct StripJds {
     bool ok = false;
     i64 nrow = 0, ncol = 0, nnz = 0, T = 0, B = 0;
+    int S = 1;                    // strip ranges per row block (S > 1: few row blocks, e.g. a 1/8 row partition)
+    DevBuf<double> part;          // [S * nrow] partial row sums when S > 1
     DevBuf<i64> base;             // [B*T + 1] first entry of every (row block, strip) cell
     DevBuf<unsigned short> perm;  // [B*T*R] sorted position -> local row
     DevBuf<unsigned char> slen;   // [B*T*R] entry count of the row at a sorted position

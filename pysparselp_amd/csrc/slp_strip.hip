@@ -159,7 +159,9 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
     const int p = threadIdx.x;
     acc[p] = 0.0;
     acc[p + kStripT] = 0.0;
-    for (i64 t = 0; t < T; ++t) {
+    // gridDim.y > 1: this workgroup covers only its share of the strips and writes partial sums
+    const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
+    for (i64 t = t_begin; t < t_end; ++t) {
         const i64 cell = b * T + t;
         // stage the strip of x with 16-byte loads
         const i64 c0 = t * (i64)kStripC;
@@ -209,7 +211,16 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
     }
     for (int h = 0; h < 2; ++h) {
         const i64 row = b * kStripR + h * kStripT + p;
-        if (row < nrow) out[row] = acc[h * kStripT + p];
+        if (row < nrow) out[(i64)blockIdx.y * nrow + row] = acc[h * kStripT + p];
+    }
+}
+
+// out[row] = ((part[0][row] + part[1][row]) + ...) in strip order (deterministic)
+__global__ void k_strip_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
+        double a = part[r];
+        for (int s = 1; s < S; ++s) a += part[(i64)s * nrow + r];
+        out[r] = a;
     }
 }
 
@@ -257,6 +268,15 @@ bool strip_build(const CsrDev &a, StripJds &f) {
     SLP_HIP(hipGetLastError());
     SLP_HIP(hipStreamSynchronize(st));
     f.nrow = a.nrow; f.ncol = a.ncol; f.nnz = a.nnz; f.T = T; f.B = B;
+    // Few row blocks (a 1/4 or 1/8 row partition of the constraints): split every block's strips over S
+    // workgroups so that the launch still fills the 256 CUs x 2 resident workgroups.
+    const char *es = getenv("SLP_STRIP_SPLIT");
+    int S = es ? atoi(es) : 1;
+    if (!es && a.nnz >= 50000000) while (S < 8 && B * S < 384 && 2 * S <= T) S *= 2;
+    if (S < 1) S = 1;
+    if (S > T) S = (int)T;
+    f.S = S;
+    if (S > 1) f.part.alloc((size_t)S * (size_t)a.nrow);
     f.ok = true;
     return true;
 }
@@ -265,12 +285,14 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
     const char *e = getenv("SLP_STRIP_ABLATE");
     const int ab = e ? atoi(e) : 0;
 #define SLP_STRIP_LAUNCH(A)                                                                                                        \
-    hipLaunchKernelGGL((k_strip_spmv<A>), dim3((unsigned)f.B), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, \
-                       f.slen.p, f.soff.p, f.val.p, f.col.p, x, out)
+    hipLaunchKernelGGL((k_strip_spmv<A>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, \
+                       f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out)
     if (ab == 1) SLP_STRIP_LAUNCH(1);
     else if (ab == 2) SLP_STRIP_LAUNCH(2);
     else SLP_STRIP_LAUNCH(0);
 #undef SLP_STRIP_LAUNCH
+    if (f.S > 1)
+        hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
     SLP_HIP(hipGetLastError());
 }
 

@@ -70,3 +70,22 @@ def test_solvers_on_strip_path_match_oracle(strips_everywhere):
     xo = oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=24, nb_iter_plot=10 ** 9)
     assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-9
     assert abs(c.dot(x) - c.dot(xo)) <= 1e-6 * abs(c.dot(xo))
+
+
+@pytest.mark.parametrize("split", ["2", "4"])
+def test_strip_split_over_workgroups(strips_everywhere, monkeypatch, split):
+    """Few row blocks (a 1/8 row partition): every block's strips are shared by several workgroups and the
+    partial row sums are added in strip order -- same terms, another association than the single chain."""
+    from pysparselp_amd.problems import random_lp_on_device
+
+    monkeypatch.setenv("SLP_STRIP_SPLIT", split)
+    n, m, p = 60000, 3000, 0.001
+    a = random_lp_on_device(n, m, p, seed=1)[0]
+    s = a.download()
+    rng = np.random.RandomState(2)
+    x, y = rng.randn(n), rng.randn(m)
+    ax, ref = a.matvec(x), oracle.matvec(oracle.as_csr(s), x)
+    assert np.max(np.abs(ax - ref)) <= 1e-13 * np.max(np.abs(s).dot(np.abs(x)))
+    assert not np.array_equal(ax, ref) or split == "1"
+    aty, ref = a.rmatvec(y), oracle.rmatvec(oracle.as_csr(s), y)
+    assert np.max(np.abs(aty - ref)) <= 1e-13 * max(1e-300, np.max(np.abs(s).T.dot(np.abs(y))))
