@@ -160,7 +160,8 @@ def main():
         if strip and world == 1 and (args.n, args.m, args.density) == (1_000_000, 2_000_000, 1e-3) and os.path.exists(pmc_file):
             # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 correction),
             # collected on this exact workload and kernel; see tools/summarize_rocprof.py and DESIGN.md
-            k = json.load(open(pmc_file))["kernels"].get("slp::k_strip_spmv")
+            kernels = json.load(open(pmc_file))["kernels"]
+            k = kernels.get("slp::k_strip_spmv<0>") or kernels.get("slp::k_strip_spmv")
             if k:
                 traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/r01_cp_c3_pmc_hbm.json"
         out = {
