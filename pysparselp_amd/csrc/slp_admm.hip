@@ -15,36 +15,45 @@
 
 namespace slp {
 
-// one level of one sweep; rows[] lists the rows of this level
-__global__ __launch_bounds__(kBlock) void k_gs_level(i64 count, const i32 *__restrict__ rows, const i64 *__restrict__ ptr,
+// Row-dot of one Gauss-Seidel row, gaussSiedel.pyx:139-141: v = sum_k x[idx[k]] * val[k] in storage order with
+// one accumulator.  The loads of 16 entries are issued together (a level is a latency chain: pointer -> index ->
+// x gather -> add), the adds stay sequential.
+__device__ __forceinline__ double gs_row_dot(i64 s, i64 e, const i32 *__restrict__ idx, const double *__restrict__ val,
+                                             const double *x) {
+    double v = 0.0;
+    for (i64 k = s; k < e; k += 16) {
+        i32 j[16];
+        double a[16], xv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const i64 kk = (k + q < e) ? k + q : e - 1;
+            j[q] = idx[kk];
+            a[q] = val[kk];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xv[q] = x[j[q]];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (k + q < e) v += xv[q] * a[q];
+    }
+    return v;
+}
+
+// One level of one sweep.  The matrix is stored in LEVEL ORDER: position t (first..first+count) holds row rows[t];
+// its entries are ptr[t]..ptr[t+1], so pointer and entry loads do not wait for the row id.
+__global__ __launch_bounds__(kBlock) void k_gs_level(i64 first, i64 count, const i32 *__restrict__ rows, const i64 *__restrict__ ptr,
                                                      const i32 *__restrict__ idx, const double *__restrict__ val,
                                                      const double *__restrict__ invd, const double *__restrict__ b,
                                                      const double *__restrict__ lo, const double *__restrict__ hi,
                                                      double *__restrict__ x, double w) {
     const i64 t = (i64)blockIdx.x * kBlock + threadIdx.x;
     if (t >= count) return;
-    const i32 i = rows[t];
-    double v = 0.0;
-    // gaussSiedel.pyx:139-141, same order of additions; the loads of a batch of 8 entries are issued
-    // together (a level is a latency chain: index -> x gather -> add), the adds stay sequential
-    const i64 e = ptr[i + 1];
-    for (i64 k = ptr[i]; k < e; k += 8) {
-        i32 j[8];
-        double a[8], xv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const i64 kk = (k + q < e) ? k + q : e - 1;
-            j[q] = idx[kk];
-            a[q] = val[kk];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) xv[q] = x[j[q]];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (k + q < e) v += xv[q] * a[q];
-    }
-    v = w * (b[i] - v) * invd[i] + x[i];                                 // :145
-    const double l = lo[i], u = hi[i];
+    const i64 pos = first + t;
+    const i32 i = rows[pos];
+    const i64 s = ptr[pos], e = ptr[pos + 1];
+    const double bi = b[i], inv = invd[pos], l = lo[i], u = hi[i], xi = x[i];  // independent of the row walk
+    double v = gs_row_dot(s, e, idx, val, x);
+    v = w * (bi - v) * inv + xi;                                         // :145
     if (v < l) v = l;                                                    // :148-151
     else if (v > u) v = u;
     x[i] = v;
@@ -65,8 +74,8 @@ __global__ __launch_bounds__(1024) void k_gs_sweep_one_block(i64 nlevels, const 
             for (i64 t = beg + threadIdx.x; t < end; t += blockDim.x) {
                 const i32 i = rows[t];
                 double v = 0.0;
-                for (i64 k = ptr[i]; k < ptr[i + 1]; ++k) v += __hip_atomic_load(&x[idx[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * val[k];
-                v = w * (b[i] - v) * invd[i] + x[i];
+                for (i64 k = ptr[t]; k < ptr[t + 1]; ++k) v += __hip_atomic_load(&x[idx[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * val[k];
+                v = w * (b[i] - v) * invd[t] + x[i];
                 const double lw = lo[i], u = hi[i];
                 if (v < lw) v = lw;
                 else if (v > u) v = u;
@@ -77,21 +86,22 @@ __global__ __launch_bounds__(1024) void k_gs_sweep_one_block(i64 nlevels, const 
     }
 }
 
-__global__ void k_invert_diag(i64 n, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, const double *__restrict__ val,
-                              double *__restrict__ invd) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+__global__ void k_invert_diag(i64 n, const i32 *__restrict__ rows, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+                              const double *__restrict__ val, double *__restrict__ invd) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i32 i = rows[t];
         double d = 0.0;  // A.diagonal(): 0 where no entry is stored
-        for (i64 k = ptr[i]; k < ptr[i + 1]; ++k)
+        for (i64 k = ptr[t]; k < ptr[t + 1]; ++k)
             if (idx[k] == i) d += val[k];
-        invd[i] = 1.0 / d;  // gaussSiedel.pyx:91-92
+        invd[t] = 1.0 / d;  // gaussSiedel.pyx:91-92
     }
 }
 
 struct GsPlan {
     i64 n = 0, nnz = 0, nlevels = 0, max_width = 0;
-    DevBuf<i64> ptr;
+    DevBuf<i64> ptr;         // level-ordered storage: position t holds row rows[t], entries ptr[t]..ptr[t+1]
     DevBuf<i32> idx;
-    DevBuf<double> val, invd;
+    DevBuf<double> val, invd; // invd[t] = 1 / M[rows[t], rows[t]]
     DevBuf<i32> rows;        // rows sorted by level (stable: increasing row inside a level)
     DevBuf<i64> lptr_dev;    // level pointer on the device (single-workgroup path)
     std::vector<i64> lptr;   // level pointer on the host (launch sizes)
@@ -134,15 +144,30 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         std::vector<i64> next(g.lptr.begin(), g.lptr.end() - (g.nlevels ? 1 : 0));
         for (i64 i = 0; i < n; ++i) rows[(size_t)next[(size_t)level[(size_t)i]]++] = (i32)i;
     }
-    g.ptr.upload(indptr, (size_t)n + 1);
-    g.idx.upload(indices, (size_t)g.nnz);
-    g.val.upload(data, (size_t)g.nnz);
+    {   // permute the matrix into level order on the host (one O(nnz) pass)
+        std::vector<i64> p2((size_t)n + 1, 0);
+        std::vector<i32> j2((size_t)g.nnz);
+        std::vector<double> v2((size_t)g.nnz);
+        i64 o = 0;
+        for (i64 t = 0; t < n; ++t) {
+            const i64 i = rows[(size_t)t];
+            p2[(size_t)t] = o;
+            for (i64 k = indptr[i]; k < indptr[i + 1]; ++k, ++o) {
+                j2[(size_t)o] = indices[k];
+                v2[(size_t)o] = data[k];
+            }
+        }
+        p2[(size_t)n] = o;
+        g.ptr.upload(p2.data(), (size_t)n + 1);
+        g.idx.upload(j2.data(), (size_t)g.nnz);
+        g.val.upload(v2.data(), (size_t)g.nnz);
+    }
     g.rows.upload(rows.data(), (size_t)n);
     g.lptr_dev.upload(g.lptr.data(), g.lptr.size());
     g.invd.alloc((size_t)n);
     if (n) {
-        hipLaunchKernelGGL(k_invert_diag, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, g.ptr.p, g.idx.p, g.val.p,
-                           g.invd.p);
+        hipLaunchKernelGGL(k_invert_diag, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, g.rows.p, g.ptr.p, g.idx.p,
+                           g.val.p, g.invd.p);
         SLP_HIP(hipGetLastError());
     }
     // a single workgroup wins while the per-level launch cost (>= ~1.5 us) exceeds the work of a level
@@ -162,7 +187,7 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
     for (int s = 0; s < sweeps; ++s)
         for (i64 l = 0; l < g.nlevels; ++l) {
             const i64 beg = g.lptr[(size_t)l], cnt = g.lptr[(size_t)l + 1] - beg;
-            hipLaunchKernelGGL(k_gs_level, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cnt, g.rows.p + beg,
+            hipLaunchKernelGGL(k_gs_level, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, beg, cnt, g.rows.p,
                                g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
         }
     SLP_HIP(hipGetLastError());
