@@ -172,6 +172,31 @@ class SparseLP:
     def add_equality_constraints(self, cols, vals, b):
         self.add_inequality_constraints(cols, vals, lower_bounds=b, upper_bounds=b)
 
+    def add_soft_inequality_constraints(self, cols, vals, coef_penalization, lower_bounds=None, upper_bounds=None):
+        """Penalised version: adds ``sum_i coef[i] * max(0, lower[i] - y_i, y_i - upper[i])`` to the objective,
+        ``y_i = sum_j vals[i, j] x[cols[i, j]]``, through one auxiliary variable per row (reference :575-613).
+        With an infinite penalty this is the hard constraint.  Returns the auxiliary variable indices (or None)."""
+        coef = np.asarray(coef_penalization, dtype=np.float64)
+        if np.all(coef == np.inf):
+            self.add_inequality_constraints(cols, vals, lower_bounds=lower_bounds, upper_bounds=upper_bounds)
+            return None
+        if np.any(coef == np.inf):
+            raise ValueError("mixing finite and infinite penalisation is not supported")
+        cols, vals = np.broadcast_arrays(np.asarray(cols), np.asarray(vals, dtype=np.float64))
+        assert upper_bounds is not None or lower_bounds is not None
+        costs = coef if coef.ndim else float(coef)
+        aux = self.add_variables_array((cols.shape[0],), lower_bounds=0, upper_bounds=None, costs=costs)
+        cols2 = np.column_stack((cols, aux))
+        if upper_bounds is not None:   # y - aux <= upper
+            self.add_inequality_constraints(cols2, np.column_stack((vals, -np.ones(vals.shape[0]))), None, upper_bounds)
+        if lower_bounds is not None:   # y + aux >= lower
+            self.add_inequality_constraints(cols2, np.column_stack((vals, np.ones(vals.shape[0]))), lower_bounds, None)
+        return aux
+
+    def add_soft_equality_constraints(self, cols, vals, b, coef_penalization):
+        """Adds ``sum_i coef[i] * |y_i - b_i|`` to the objective (reference :546-558)."""
+        return self.add_soft_inequality_constraints(cols, vals, coef_penalization, lower_bounds=b, upper_bounds=b)
+
     # ------------------------------------------------------------------ transforms
     def convert_to_one_sided_inequality_system(self):
         """``b_lower <= A x <= b_upper`` -> ``A' x <= b_upper'`` (finite upper rows, then negated finite lower rows)."""

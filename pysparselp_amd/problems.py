@@ -88,3 +88,56 @@ def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None):
     a = DeviceMatrix.random(rows, n, density, seed, row_offset)
     xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset)
     return a, xf, c, lb, ub, b
+
+
+def kmedians_lp(points, k, n_center_candidates, seed=0):
+    """LP relaxation of k-medians (reference examples/example_kmedians.py:15-44).
+
+    Variables: ``labeling[i, j]`` in [0, 1] (point i served by candidate j, cost = distance) and
+    ``used[j]`` in [0, 1].  Constraints: ``0 <= sum_j used[j] <= k``; ``sum_j labeling[i, j] = 1`` for every
+    point; ``labeling[i, j] - used[j] <= 0``.  Returns ``(lp, labeling_indices, pairdistances)``.
+    """
+    n = points.shape[0]
+    rng = np.random.RandomState(seed)
+    centers = points[rng.choice(n, n_center_candidates), :]
+    pairdistances = np.sqrt(np.sum((points[:, None, :] - centers[None, :, :]) ** 2, axis=2))
+    lp = SparseLP()
+    labeling = lp.add_variables_array(pairdistances.shape, 0, 1, pairdistances)
+    used = lp.add_variables_array(n_center_candidates, 0, 1, 0)
+    lp.add_inequality_constraints(used[None, :], np.ones((1, n_center_candidates)), lower_bounds=0, upper_bounds=k)
+    lp.add_inequality_constraints(labeling, np.ones((n, n_center_candidates)), lower_bounds=1, upper_bounds=1)
+    cols = np.column_stack((labeling.reshape(-1, 1), np.tile(used, n).reshape(-1, 1)))
+    vals = np.column_stack((np.ones(n * n_center_candidates), -np.ones(n * n_center_candidates)))
+    lp.add_inequality_constraints(cols, vals, lower_bounds=None, upper_bounds=0)
+    return lp, labeling, pairdistances
+
+
+def l1svm_lp(x, classes, nb_classes=None):
+    """L1-regularised multi-class SVM as an LP (reference examples/example_l1_svm.py:10-68).
+
+    Variables: weights (classes x (features + 1), free), one |w| auxiliary per weight (>= 0, cost 1), one slack
+    per example (>= 0, cost 1).  Constraints: ``+-w - aux <= 0`` and, for every class k and every example not
+    of class k, ``(w_class(e) - w_k) . [x_e, 1] + eps_e >= 1``.  Returns ``(lp, weight_indices, eps_indices)``.
+    """
+    nb_examples, nb_features = x.shape
+    xh = np.hstack((x, np.ones((nb_examples, 1))))
+    if nb_classes is None:
+        nb_classes = int(np.max(classes)) + 1
+    lp = SparseLP()
+    w = lp.add_variables_array((nb_classes, nb_features + 1), None, None)
+    aux = lp.add_variables_array(w.size, upper_bounds=None, lower_bounds=0)
+    lp.set_costs_variables(aux, np.ones(aux.shape))
+    cols = np.column_stack((w.ravel(), aux.ravel()))
+    lp.add_inequality_constraints(cols, np.tile([1.0, -1.0], (w.size, 1)), lower_bounds=None, upper_bounds=0)
+    lp.add_inequality_constraints(cols, np.tile([-1.0, -1.0], (w.size, 1)), lower_bounds=None, upper_bounds=0)
+    eps = lp.add_variables_array((nb_examples, 1), upper_bounds=None, lower_bounds=0, costs=1)
+    margin = np.ones((nb_examples, nb_classes))
+    margin[np.arange(nb_examples), classes] = 0
+    own = w[classes, :]
+    for k in range(nb_classes):
+        keep = classes != k
+        other = np.tile(w[[k], :], (nb_examples, 1))
+        vals = np.column_stack((xh, -xh, np.ones(eps.shape)))
+        cols = np.column_stack((own, other, eps))
+        lp.add_inequality_constraints(cols[keep, :], vals[keep, :], lower_bounds=margin[keep, k], upper_bounds=None)
+    return lp, w, eps
