@@ -68,7 +68,7 @@ int slp_matrix_download(slp_matrix *a, int transposed, int64_t *indptr,
  * vectors, no host traffic; *ms = average GPU time per launch (HIP events). */
 int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, double *ms);
 /* Which kernel serves that orientation: 1 = LDS-tiled strip kernel (k_strip_spmv; long sorted rows,
- * >= 2e7 stored entries), 0 = row-per-lane-group CSR kernel (k_spmv), -1 = error. */
+ * >= 3e7 stored entries), 0 = row-per-lane-group CSR kernel (k_spmv), -1 = error. */
 int slp_matrix_spmv_kernel(slp_matrix *a, int transposed);
 
 /* ---- Chambolle-Pock: replaces chambolle_pock_ppd's loop ----------------- *

@@ -272,7 +272,7 @@ bool strip_build(const CsrDev &a, StripJds &f) {
     // workgroups so that the launch still fills the 256 CUs x 2 resident workgroups.
     const char *es = getenv("SLP_STRIP_SPLIT");
     int S = es ? atoi(es) : 1;
-    if (!es && a.nnz >= 50000000) while (S < 8 && B * S < 384 && 2 * S <= T) S *= 2;
+    if (!es && a.nnz >= 30000000) while (S < 8 && B * S < 384 && 2 * S <= T) S *= 2;
     if (S < 1) S = 1;
     if (S > T) S = (int)T;
     f.S = S;
@@ -300,7 +300,7 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
 // the 3 bytes of per-(row, strip) metadata and the x-tile staging.
 bool strip_wanted(const CsrDev &a) {
     const char *e = getenv("SLP_STRIP_MIN_NNZ");  // below this size launch latency, not the gathers, dominates
-    const i64 min_nnz = e ? atoll(e) : 20000000ll;
+    const i64 min_nnz = e ? atoll(e) : 30000000ll;  // measured cross-over vs the CSR kernel (tools/strip_threshold.py)
     if (a.nnz < min_nnz) return false;
     const double per_cell = a.mean_row_len() / (double)((a.ncol + kStripC - 1) / kStripC);
     return per_cell >= 3.0 && per_cell <= 64.0;
