@@ -81,13 +81,23 @@ class DeviceADMM(_CGBase):
     def objective(self):
         return float(self.c.dot(self.x(self.n)))
 
+    def batched(self):
+        """Two-vector passes are used when both orientations run on the strip kernel (and reuse is on)."""
+        l = self._l
+        return bool(self.reuse and l.slp_matrix_spmv_kernel(self.a._h, 0) == 1 and l.slp_matrix_spmv_kernel(self.a._h, 1) == 1)
+
     def matrix_passes_per_iteration(self):
-        # A^T lambda, (A v, A^T w) for each product M v (4, or 3 with reuse), A x for the multiplier
-        return 8 if self.reuse else 10
+        # products per iteration: A^T lambda, (A v, A^T w) for each M v (4 of them, 3 with reuse), A x for the multiplier;
+        # batched: A [x, dir] and A^T [A x, A dir] each take ONE pass over the matrix
+        if not self.reuse:
+            return 10
+        return 5 if self.batched() else 8
 
     def describe(self):
-        return ("ADMM, matrix-free conjugate-gradient x-step of the reference (ADMM.py:182-201), gamma_eq=2, gamma_ineq=3, "
-                + ("8 matrix passes (CG residual reuses the line-search products)" if self.reuse else "10 matrix passes"))
+        mode = ("8 matrix products in 5 passes (two-vector passes for A[x,dir] and A^T[Ax,Adir]; CG residual reuses the "
+                "line-search products)" if self.batched() else
+                "8 matrix passes (CG residual reuses the line-search products)" if self.reuse else "10 matrix passes")
+        return ("ADMM, matrix-free conjugate-gradient x-step of the reference (ADMM.py:182-201), gamma_eq=2, gamma_ineq=3, " + mode)
 
 
 def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2, gamma_ineq=3, nb_iter=100,

@@ -276,6 +276,8 @@ struct slp_admm_cg {
     DevBuf<double> sc, b, lam, w;                                         // rows
     DevBuf<double> c, lb, ub, x, xp, y, q, dir, xprev, r, lin, u, mx, md;        // unknowns (u: n_o)
     DevBuf<double> part, rowpart, colpart, scal, out;
+    DevBuf<double> wx, wd, u2;   // batched form: A x, A dir (rows) and [A^T A x | A^T A dir] (2 n_o)
+    bool have_w = false;
 };
 
 namespace slp {
@@ -284,42 +286,75 @@ __global__ void k_cg_add_slack(i64 m, const double *__restrict__ sc, const doubl
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) w[i] = w[i] + sc[i] * vs[i];
 }
 
-static void cg_rows(slp_admm_cg *s, const double *v) {
+// w_out = A v   (v over the N unknowns: original part, then this rank's slack part)
+static void cg_rows(slp_admm_cg *s, const double *v, double *w_out = nullptr) {
     if (s->m == 0) return;
+    double *w = w_out ? w_out : s->w.p;
     const CsrDev &a = s->a->a;
     if (const StripJds *f = fast_format(s->a, false)) {  // long rows: LDS-tiled product, then the slack column
-        strip_spmv(*f, v, s->w.p);
+        strip_spmv(*f, v, w);
         if (s->ns) {
-            hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->sc.p, v + s->n_o,
-                               s->w.p);
+            hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->sc.p, v + s->n_o, w);
             SLP_HIP(hipGetLastError());
         }
         return;
     }
     const int lanes = s->lanes_rows;
     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_rows<L>), dim3(grid_for(s->m * lanes, kBlock)), dim3(kBlock), 0, ctx().stream,
-                                                 s->m, a.ptr.p, a.idx.p, a.val.p, v, s->ns ? s->sc.p : nullptr, s->n_o, s->w.p));
+                                                 s->m, a.ptr.p, a.idx.p, a.val.p, v, s->ns ? s->sc.p : nullptr, s->n_o, w));
     SLP_HIP(hipGetLastError());
 }
 
-// u = (A^T w) restricted to the original variables, summed over the ranks
-static void cg_cols(slp_admm_cg *s, const double *w) {
+// [w0, w1] = A [v0, v1]: ONE pass over the matrix when the strip format is available
+static void cg_rows2(slp_admm_cg *s, const double *v0, const double *v1, double *w0, double *w1) {
+    if (s->m == 0) return;
+    if (const StripJds *f = fast_format(s->a, false)) {
+        strip_spmv2(*f, v0, v1, w0, w1);
+        if (s->ns) {
+            hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->sc.p, v0 + s->n_o, w0);
+            hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->sc.p, v1 + s->n_o, w1);
+            SLP_HIP(hipGetLastError());
+        }
+        return;
+    }
+    cg_rows(s, v0, w0);
+    cg_rows(s, v1, w1);
+}
+
+// u_out = (A^T w) restricted to the original variables, summed over the ranks
+static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr) {
     if (s->n_o == 0) return;
+    double *u = u_out ? u_out : s->u.p;
     const CsrDev &at = s->a->at;
     if (const StripJds *f = fast_format(s->a, true)) {
-        strip_spmv(*f, w, s->u.p);
+        strip_spmv(*f, w, u);
     } else {
         const int lanes = s->lanes_cols;
         SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_cols<L>), dim3(grid_for(s->n_o * lanes, kBlock)), dim3(kBlock), 0,
-                                                     ctx().stream, s->n_o, at.ptr.p, at.idx.p, at.val.p, w, s->u.p));
+                                                     ctx().stream, s->n_o, at.ptr.p, at.idx.p, at.val.p, w, u));
         SLP_HIP(hipGetLastError());
     }
-    if (s->distributed) comm_allreduce_dev(s->u.p, s->n_o, 0);
+    if (s->distributed) comm_allreduce_dev(u, s->n_o, 0);
 }
 
-static CgVecs cg_vecs(slp_admm_cg *s) {
+// [u2[0..n_o), u2[n_o..2 n_o)] = A^T [w0, w1]: one pass, one all-reduce of 2 n_o values
+static void cg_cols2(slp_admm_cg *s, const double *w0, const double *w1, double *u2) {
+    if (s->n_o == 0) return;
+    const StripJds *f = fast_format(s->a, true);
+    if (!f) {
+        cg_cols(s, w0, u2);
+        cg_cols(s, w1, u2 + s->n_o);
+        return;
+    }
+    strip_spmv2(*f, w0, w1, u2, u2 + s->n_o);
+    if (s->distributed) comm_allreduce_dev(u2, 2 * s->n_o, 0);
+}
+
+static CgVecs cg_vecs(slp_admm_cg *s, const double *u, const double *w) {
     CgVecs v;
-    v.q = s->q.p; v.c = s->c.p; v.lb = s->lb.p; v.ub = s->ub.p; v.u = s->u.p; v.sc = s->sc.p; v.w = s->w.p;
+    v.q = s->q.p; v.c = s->c.p; v.lb = s->lb.p; v.ub = s->ub.p; v.sc = s->sc.p;
+    v.u = u ? u : s->u.p;   // (A^T .) over the original variables ...
+    v.w = w ? w : s->w.p;   // ... and the row vector whose slack column gives the rest: sc_i * w_i
     v.x = s->x.p; v.xp = s->xp.p; v.y = s->y.p; v.dir = s->dir.p; v.xprev = s->xprev.p; v.r = s->r.p; v.lin = s->lin.p;
     v.mx = s->mx.p; v.md = s->md.p; v.keep = s->reuse ? 1 : 0;
     v.scal = s->scal.p; v.n_o = s->n_o; v.N = s->N;
@@ -328,10 +363,10 @@ static CgVecs cg_vecs(slp_admm_cg *s) {
 }
 
 template <int OP>
-static void cg_elem(slp_admm_cg *s, int slot) {
+static void cg_elem(slp_admm_cg *s, int slot, const double *u = nullptr, const double *w = nullptr) {
     int grid = grid_for(s->N, kBlock);
     if (grid > kCgPartials) grid = kCgPartials;
-    hipLaunchKernelGGL((k_cg_elem<OP>), dim3(grid), dim3(kBlock), 0, ctx().stream, cg_vecs(s), s->part.p);
+    hipLaunchKernelGGL((k_cg_elem<OP>), dim3(grid), dim3(kBlock), 0, ctx().stream, cg_vecs(s, u, w), s->part.p);
     SLP_HIP(hipGetLastError());
     if (slot >= 0) {
         hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(kBlock), 0, ctx().stream, grid, s->part.p, s->scal.p, slot);
@@ -340,30 +375,58 @@ static void cg_elem(slp_admm_cg *s, int slot) {
     }
 }
 
+// Batched form (reuse mode + strip kernels): the products A x and A dir that the NEXT line search needs are
+// taken in one two-vector pass at the end of an iteration (the multiplier update needs A x anyway), and
+// A^T (A x), A^T (A dir) in one two-vector pass: 5 passes over the matrix per iteration instead of 8.
+// Every product is the same arithmetic as in the unbatched form; only the passes are shared.
+static bool cg_batched(slp_admm_cg *s) {
+    return s->reuse && s->m > 0 && s->n_o > 0 && fast_format(s->a, false) && fast_format(s->a, true);
+}
+
+static void cg_refresh_products(slp_admm_cg *s) {  // wx = A x, wd = A dir
+    if (s->wx.n < (size_t)s->m) { s->wx.alloc((size_t)s->m); s->wd.alloc((size_t)s->m); s->u2.alloc(2 * (size_t)s->n_o); }
+    cg_rows2(s, s->x.p, s->dir.p, s->wx.p, s->wd.p);
+    s->have_w = true;
+}
+
 // first half of an iteration: everything up to (and including) the over-relaxed x (:148-201)
 static void cg_xstep(slp_admm_cg *s) {
-    cg_cols(s, s->lam.p);                      // A^T lambda_eq  (w is not used by the slack part here: see below)
-    // slack part of A^T lambda: sc_i * lambda_i -> at_elem reads w, so stage lambda in w
-    s->w.copy_from(s->lam);
-    cg_elem<E_RHS>(s, -1);
-    cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_LINE_T>(s, S_T);
-    cg_rows(s, s->dir.p); cg_cols(s, s->w.p); cg_elem<E_LINE_DMD>(s, S_DMD);
-    cg_elem<E_LINE_STEP>(s, -1);
-    if (s->reuse) {
+    cg_cols(s, s->lam.p);                                   // A^T lambda_eq over the original variables
+    cg_elem<E_RHS>(s, -1, s->u.p, s->lam.p);                // slack part of A^T lambda: sc_i * lambda_i
+    if (cg_batched(s)) {
+        if (!s->have_w) cg_refresh_products(s);
+        cg_cols2(s, s->wx.p, s->wd.p, s->u2.p);
+        cg_elem<E_LINE_T>(s, S_T, s->u2.p, s->wx.p);
+        cg_elem<E_LINE_DMD>(s, S_DMD, s->u2.p + s->n_o, s->wd.p);
+        cg_elem<E_LINE_STEP>(s, -1);
         cg_elem<E_RESID_REUSE>(s, S_RS);
     } else {
-        cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_RESID>(s, S_RS);
+        cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_LINE_T>(s, S_T);
+        cg_rows(s, s->dir.p); cg_cols(s, s->w.p); cg_elem<E_LINE_DMD>(s, S_DMD);
+        cg_elem<E_LINE_STEP>(s, -1);
+        if (s->reuse) {
+            cg_elem<E_RESID_REUSE>(s, S_RS);
+        } else {
+            cg_rows(s, s->x.p); cg_cols(s, s->w.p); cg_elem<E_RESID>(s, S_RS);
+        }
     }
     cg_rows(s, s->r.p); cg_cols(s, s->w.p); cg_elem<E_PAP>(s, S_PAP);
     cg_elem<E_UPDATE>(s, -1);
+    s->have_w = false;  // x and dir changed
 }
 
 // second half: projection step and both multiplier updates (:253-263)
 static void cg_multipliers(slp_admm_cg *s) {
     cg_elem<E_PROJECT>(s, -1);
-    cg_rows(s, s->x.p);
+    const double *ax = s->w.p;
+    if (cg_batched(s)) {
+        cg_refresh_products(s);   // A x for the multiplier AND, with A dir, for the next line search
+        ax = s->wx.p;
+    } else {
+        cg_rows(s, s->x.p);
+    }
     if (s->m) {
-        hipLaunchKernelGGL(k_cg_multiplier, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->w.p, s->b.p,
+        hipLaunchKernelGGL(k_cg_multiplier, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, ax, s->b.p,
                            s->gamma_eq, s->lam.p);
         SLP_HIP(hipGetLastError());
     }
@@ -384,9 +447,8 @@ static void cg_alloc_state(slp_admm_cg *s) {
     hipStream_t st = ctx().stream;
     // q = -c + gamma_eq A^T b (:95,:148)
     cg_cols(s, s->b.p);
-    s->w.copy_from(s->b);
     if (s->N) {
-        hipLaunchKernelGGL(k_cg_q, dim3(grid_for(s->N, kBlock)), dim3(kBlock), 0, st, s->N, s->n_o, s->c.p, s->u.p, s->sc.p, s->w.p,
+        hipLaunchKernelGGL(k_cg_q, dim3(grid_for(s->N, kBlock)), dim3(kBlock), 0, st, s->N, s->n_o, s->c.p, s->u.p, s->sc.p, s->b.p,
                            s->gamma_eq, s->q.p);
         SLP_HIP(hipGetLastError());
     }
@@ -497,6 +559,7 @@ int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse) {
         SLP_REQUIRE(s, "NULL handle");
         if (reuse && s->mx.n < (size_t)s->N) { s->mx.alloc((size_t)s->N); s->md.alloc((size_t)s->N); s->mx.zero(); s->md.zero(); }
         s->reuse = reuse != 0;
+        s->have_w = false;
     })
 }
 

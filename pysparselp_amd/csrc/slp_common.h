@@ -175,6 +175,7 @@ struct StripJds {
     i64 nrow = 0, ncol = 0, nnz = 0, T = 0, B = 0;
     int S = 1;                    // strip ranges per row block (S > 1: few row blocks, e.g. a 1/8 row partition)
     DevBuf<double> part;          // [S * nrow] partial row sums when S > 1
+    mutable DevBuf<double> part2; // [2 * S * nrow] the same for the two-vector product
     DevBuf<i64> base;             // [B*T + 1] first entry of every (row block, strip) cell
     DevBuf<unsigned short> perm;  // [B*T*R] sorted position -> local row
     DevBuf<unsigned char> slen;   // [B*T*R] entry count of the row at a sorted position
@@ -185,6 +186,7 @@ struct StripJds {
 bool strip_wanted(const CsrDev &a);
 bool strip_build(const CsrDev &a, StripJds &f);
 void strip_spmv(const StripJds &f, const double *x, double *out);
+void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1);  // one pass, two vectors
 
 }  // namespace slp
 

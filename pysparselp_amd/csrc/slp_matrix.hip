@@ -330,8 +330,20 @@ int slp_matrix_bench_spmv(slp_matrix *m, int transposed, int order, int reps, do
         for (size_t i = 0; i < h.size(); ++i) h[i] = 1.0 + 1e-3 * (double)(i % 1000);
         vx.upload(h.data(), h.size());
         matrix_spmv(m, transposed != 0, vx.p, vy.p, order);  // warm-up
+        const char *two = getenv("SLP_BENCH_TWO_VECTORS");  // time the two-vector pass (strip format only)
+        const StripJds *f2 = (two && two[0] == '1') ? fast_format(m, transposed != 0) : nullptr;
+        DevBuf<double> vx2, vy2;
+        if (f2) {
+            vx2.alloc((size_t)a.ncol);
+            vy2.alloc((size_t)a.nrow);
+            vx2.copy_from(vx);
+            strip_spmv2(*f2, vx.p, vx2.p, vy.p, vy2.p);
+        }
         SLP_HIP(hipEventRecord(ctx().ev0, ctx().stream));
-        for (int r = 0; r < reps; ++r) matrix_spmv(m, transposed != 0, vx.p, vy.p, order);
+        for (int r = 0; r < reps; ++r) {
+            if (f2) strip_spmv2(*f2, vx.p, vx2.p, vy.p, vy2.p);
+            else matrix_spmv(m, transposed != 0, vx.p, vy.p, order);
+        }
         SLP_HIP(hipEventRecord(ctx().ev1, ctx().stream));
         SLP_HIP(hipEventSynchronize(ctx().ev1));
         float f = 0.f;

@@ -215,6 +215,90 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
     }
 }
 
+
+// Two right-hand sides in one pass over the matrix: out0 = A x0, out1 = A x1.  The matrix (the only
+// HBM-sized operand) is streamed once; both x-tiles and both sets of running sums live in LDS (153 KB,
+// one workgroup per CU).  Per row and per vector the additions are the same chain as in k_strip_spmv,
+// so each output is bit-identical to the single-vector product.
+__global__ __launch_bounds__(kStripT, 4) void k_strip_spmv2(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
+                                                            const unsigned short *__restrict__ perm,
+                                                            const unsigned char *__restrict__ slen,
+                                                            const unsigned int *__restrict__ soff, const double *__restrict__ val,
+                                                            const unsigned short *__restrict__ col, const double *__restrict__ x0,
+                                                            const double *__restrict__ x1, double *__restrict__ out0,
+                                                            double *__restrict__ out1) {
+    __shared__ double xt0[kStripC];
+    __shared__ double xt1[kStripC];
+    __shared__ double acc0[kStripR];
+    __shared__ double acc1[kStripR];
+    __shared__ unsigned int offs[kStripSL];
+    const i64 b = blockIdx.x;
+    const int p = threadIdx.x;
+    acc0[p] = 0.0; acc0[p + kStripT] = 0.0;
+    acc1[p] = 0.0; acc1[p + kStripT] = 0.0;
+    const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
+    for (i64 t = t_begin; t < t_end; ++t) {
+        const i64 cell = b * T + t;
+        const i64 c0 = t * (i64)kStripC;
+#pragma unroll
+        for (int q = 0; q < (kStripC / 2 + kStripT - 1) / kStripT; ++q) {
+            const int j = (q * kStripT + p) * 2;
+            if (j < kStripC) {
+                double2 v = make_double2(0.0, 0.0), u = make_double2(0.0, 0.0);
+                if (c0 + j + 1 < ncol) {
+                    v = *reinterpret_cast<const double2 *>(x0 + c0 + j);
+                    u = *reinterpret_cast<const double2 *>(x1 + c0 + j);
+                } else if (c0 + j < ncol) {
+                    v.x = x0[c0 + j];
+                    u.x = x1[c0 + j];
+                }
+                *reinterpret_cast<double2 *>(&xt0[j]) = v;
+                *reinterpret_cast<double2 *>(&xt1[j]) = u;
+            }
+        }
+        if (p < kStripSL) offs[p] = soff[cell * kStripSL + p];
+        const ushort2 r = reinterpret_cast<const ushort2 *>(perm + cell * kStripR)[p];
+        const uchar2 nn = reinterpret_cast<const uchar2 *>(slen + cell * kStripR)[p];
+        const unsigned int n0 = nn.x, n1 = nn.y;
+        const double2 *__restrict__ v2 = reinterpret_cast<const double2 *>(val + base[cell]);
+        const ushort2 *__restrict__ c2 = reinterpret_cast<const ushort2 *>(col + base[cell]);
+        __syncthreads();
+        double a0 = acc0[r.x], a1 = acc0[r.y], b0 = acc1[r.x], b1 = acc1[r.y];
+        unsigned int s = 0;
+        for (; s + 4 <= n0; s += 4) {
+            const unsigned int o0 = (offs[s] >> 1) + p, o1 = (offs[s + 1] >> 1) + p, o2 = (offs[s + 2] >> 1) + p,
+                               o3 = (offs[s + 3] >> 1) + p;
+            const double2 w0 = v2[o0], w1 = v2[o1], w2 = v2[o2], w3 = v2[o3];
+            const ushort2 j0 = c2[o0], j1 = c2[o1], j2 = c2[o2], j3 = c2[o3];
+            a0 += w0.x * xt0[j0.x]; b0 += w0.x * xt1[j0.x];
+            a0 += w1.x * xt0[j1.x]; b0 += w1.x * xt1[j1.x];
+            a0 += w2.x * xt0[j2.x]; b0 += w2.x * xt1[j2.x];
+            a0 += w3.x * xt0[j3.x]; b0 += w3.x * xt1[j3.x];
+            if (s < n1) { a1 += w0.y * xt0[j0.y]; b1 += w0.y * xt1[j0.y]; }
+            if (s + 1 < n1) { a1 += w1.y * xt0[j1.y]; b1 += w1.y * xt1[j1.y]; }
+            if (s + 2 < n1) { a1 += w2.y * xt0[j2.y]; b1 += w2.y * xt1[j2.y]; }
+            if (s + 3 < n1) { a1 += w3.y * xt0[j3.y]; b1 += w3.y * xt1[j3.y]; }
+        }
+        for (; s < n0; ++s) {
+            const unsigned int o = (offs[s] >> 1) + p;
+            const double2 w = v2[o];
+            const ushort2 j = c2[o];
+            a0 += w.x * xt0[j.x]; b0 += w.x * xt1[j.x];
+            if (s < n1) { a1 += w.y * xt0[j.y]; b1 += w.y * xt1[j.y]; }
+        }
+        acc0[r.x] = a0; acc0[r.y] = a1;
+        acc1[r.x] = b0; acc1[r.y] = b1;
+        __syncthreads();
+    }
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + p;
+        if (row < nrow) {
+            out0[(i64)blockIdx.y * nrow + row] = acc0[h * kStripT + p];
+            out1[(i64)blockIdx.y * nrow + row] = acc1[h * kStripT + p];
+        }
+    }
+}
+
 // out[row] = ((part[0][row] + part[1][row]) + ...) in strip order (deterministic)
 __global__ void k_strip_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
@@ -293,6 +377,23 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
 #undef SLP_STRIP_LAUNCH
     if (f.S > 1)
         hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
+    SLP_HIP(hipGetLastError());
+}
+
+void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1) {
+    hipStream_t st = ctx().stream;
+    double *o0 = out0, *o1 = out1;
+    if (f.S > 1) {
+        if (f.part2.n < 2 * (size_t)f.S * (size_t)f.nrow) f.part2.alloc(2 * (size_t)f.S * (size_t)f.nrow);
+        o0 = f.part2.p;
+        o1 = f.part2.p + (size_t)f.S * (size_t)f.nrow;
+    }
+    hipLaunchKernelGGL(k_strip_spmv2, dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p,
+                       f.slen.p, f.soff.p, f.val.p, f.col.p, x0, x1, o0, o1);
+    if (f.S > 1) {
+        hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, st, f.nrow, f.S, o0, out0);
+        hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, st, f.nrow, f.S, o1, out1);
+    }
     SLP_HIP(hipGetLastError());
 }
 
