@@ -176,9 +176,12 @@ slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, co
                                    const double *lb, const double *ub, double gamma_eq,
                                    double gamma_ineq, int order);
 void slp_admm_cg_destroy(slp_admm_cg *s);
-/* reuse = 1: the CG residual y - M(x + step dir) is formed from the products M x and M dir already
- * computed by the line search (M is linear) instead of a third product: 8 passes over A per
- * iteration instead of 10; same mathematics, fp64 rounding differences only.  Default 0. */
+/* Products of A per iteration (same mathematics, fp64 rounding differences only); default 0:
+ * 0  ten, as the reference writes the iteration;
+ * 1  eight: the CG residual y - M(x + step dir) is formed from M x and M dir of the line search (M is linear);
+ * 2  six: additionally A^T (g_eq A x + lambda_eq) is one product (y = ... - A^T lambda_eq is never formed).
+ * With the strip kernels, A [x, dir] and the two A^T products of the line search each share ONE sweep over the
+ * matrix (two-vector pass): 5 sweeps at level 1, 4 at level 2. */
 int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse);
 int slp_admm_cg_iterate(slp_admm_cg *s, int64_t k);
 /* Halves of one iteration around the reference's report (:213-248). */

@@ -26,9 +26,13 @@ class _CGBase:
     __del__ = close
 
     def set_reuse(self, reuse):
-        """``True``: 8 matrix passes per iteration (the CG residual reuses the line search's products)."""
-        _lib.check(self._l.slp_admm_cg_set_reuse(self._h, int(bool(reuse))))
-        self.reuse = bool(reuse)
+        """How many matrix products an iteration spends (same mathematics, fp64 rounding differences only):
+        0 -- ten, as the reference writes the iteration;
+        1 -- eight: the CG residual ``y - M(x + t d)`` is formed from ``M x`` and ``M d`` of the line search;
+        2 -- six: additionally ``A^T (g_eq A x + lambda_eq)`` is one product instead of two."""
+        reuse = int(reuse)
+        _lib.check(self._l.slp_admm_cg_set_reuse(self._h, reuse))
+        self.reuse = reuse
 
     def iterate(self, k):
         _lib.check(self._l.slp_admm_cg_iterate(self._h, int(k)))
@@ -67,7 +71,7 @@ class DeviceADMM(_CGBase):
     """All-inequality LP over a DeviceMatrix; setup transforms run on the device and scale the
     matrix IN PLACE (the DeviceMatrix then holds the row-normalised values)."""
 
-    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO, reuse=True):
+    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO, reuse=2):
         self._l = _lib.lib()
         self.a = a
         self.n = a.shape[1]
@@ -81,23 +85,24 @@ class DeviceADMM(_CGBase):
     def objective(self):
         return float(self.c.dot(self.x(self.n)))
 
-    def batched(self):
-        """Two-vector passes are used when both orientations run on the strip kernel (and reuse is on)."""
+    def two_vector_passes(self):
+        """A [x, dir] and the two A^T products of the line search share one sweep over the matrix each
+        when both orientations run on the strip kernel."""
         l = self._l
         return bool(self.reuse and l.slp_matrix_spmv_kernel(self.a._h, 0) == 1 and l.slp_matrix_spmv_kernel(self.a._h, 1) == 1)
 
+    def matrix_products_per_iteration(self):
+        return {0: 10, 1: 8, 2: 6}[self.reuse]
+
     def matrix_passes_per_iteration(self):
-        # products per iteration: A^T lambda, (A v, A^T w) for each M v (4 of them, 3 with reuse), A x for the multiplier;
-        # batched: A [x, dir] and A^T [A x, A dir] each take ONE pass over the matrix
-        if not self.reuse:
-            return 10
-        return 5 if self.batched() else 8
+        if not self.two_vector_passes():
+            return self.matrix_products_per_iteration()
+        return {1: 5, 2: 4}[self.reuse]
 
     def describe(self):
-        mode = ("8 matrix products in 5 passes (two-vector passes for A[x,dir] and A^T[Ax,Adir]; CG residual reuses the "
-                "line-search products)" if self.batched() else
-                "8 matrix passes (CG residual reuses the line-search products)" if self.reuse else "10 matrix passes")
-        return ("ADMM, matrix-free conjugate-gradient x-step of the reference (ADMM.py:182-201), gamma_eq=2, gamma_ineq=3, " + mode)
+        return ("ADMM, matrix-free conjugate-gradient x-step of the reference (ADMM.py:182-201), gamma_eq=2, gamma_ineq=3, "
+                f"{self.matrix_products_per_iteration()} matrix products in {self.matrix_passes_per_iteration()} passes per iteration "
+                f"(reuse level {self.reuse})")
 
 
 def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2, gamma_ineq=3, nb_iter=100,

@@ -67,7 +67,7 @@ __device__ __forceinline__ double at_elem(i64 j, i64 n_o, const double *__restri
 
 // Elementwise passes over the N unknowns.  Each also produces one dot product, split into the part over
 // the replicated original variables (slot) and the part over this rank's slack variables (slot + 1).
-enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7, E_RESID_REUSE = 8 };
+enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7, E_RESID_REUSE = 8, E_GRAD = 9, E_RESID_FUSED = 10 };
 
 struct CgVecs {
     const double *q, *c, *lb, *ub, *u, *sc, *w;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
     double acc_o = 0.0, acc_s = 0.0;
     double f = 0.0;
     bool on = true;
-    if (OP == E_LINE_STEP || OP == E_RESID_REUSE) {
+    if (OP == E_LINE_STEP || OP == E_RESID_REUSE || OP == E_RESID_FUSED) {
         const double t = -(a.scal[S_T] + a.scal[S_T + 1]);
         on = fabs(t) > 0.0;                                      // ADMM.py:192
         f = t / (a.scal[S_DMD] + a.scal[S_DMD + 1]);             // :193
@@ -116,6 +116,15 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
             const double r = a.y[j] - mxn;
             a.r[j] = r;
             term = r * r;
+        } else if (OP == E_GRAD) {  // fused: g = M x - y with A^T (g_eq A x + lambda_eq) taken as ONE product (u, w = v1)
+            const double g = (at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.x[j]) - ((a.q[j] + a.gamma_ineq * a.xp[j]) - a.lin[j]);
+            a.mx[j] = g;
+            a.xprev[j] = a.x[j];
+            term = a.dir[j] * g;  // t = -dir.g
+        } else if (OP == E_RESID_FUSED) {  // r = y - M(x + step dir) = -(g + step M dir)
+            const double r = on ? -(a.mx[j] + f * a.md[j]) : -a.mx[j];
+            a.r[j] = r;
+            term = r * r;
         } else if (OP == E_PAP) {  // p.(M p) (conjgrad :37-38)
             const double ap = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.r[j];
             term = a.r[j] * ap;
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
         if (j < a.n_o) acc_o += term;
         else acc_s += term;
     }
-    if (OP == E_LINE_T || OP == E_LINE_DMD || OP == E_RESID || OP == E_RESID_REUSE || OP == E_PAP) {
+    if (OP == E_LINE_T || OP == E_LINE_DMD || OP == E_RESID || OP == E_RESID_REUSE || OP == E_PAP || OP == E_GRAD ||
+        OP == E_RESID_FUSED) {
         const double ro = block_reduce<false>(acc_o, lds), rs = block_reduce<false>(acc_s, lds);
         if (threadIdx.x == 0) {
             part[blockIdx.x * 2] = ro;
@@ -160,9 +170,16 @@ __global__ __launch_bounds__(kBlock) void k_cg_finish(int nparts, const double *
 
 // lambda_eq_i += gamma_eq (w_i - b_i)  (:261-263), w = A x
 __global__ void k_cg_multiplier(i64 m, const double *__restrict__ w, const double *__restrict__ b, double gamma_eq,
-                                double *__restrict__ lam) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x)
-        lam[i] = lam[i] + gamma_eq * (w[i] - b[i]);
+                                double *__restrict__ lam, double *__restrict__ v1) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        const double l = lam[i] + gamma_eq * (w[i] - b[i]);
+        lam[i] = l;
+        if (v1) v1[i] = gamma_eq * w[i] + l;  // fused mode: A^T (g_eq A x + lambda) is one product in the next iteration
+    }
+}
+
+__global__ void k_cg_v1(i64 m, const double *__restrict__ w, const double *__restrict__ lam, double gamma_eq, double *__restrict__ v1) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) v1[i] = gamma_eq * w[i] + lam[i];
 }
 
 __global__ void k_cg_q(i64 N, i64 n_o, const double *__restrict__ c, const double *__restrict__ u, const double *__restrict__ sc,
@@ -272,11 +289,12 @@ struct slp_admm_cg {
     double gamma_eq = 2, gamma_ineq = 3, alpha = 1.4;
     int order = SLP_ORDER_AUTO, lanes_rows = 1, lanes_cols = 1;
     bool distributed = false;
-    bool reuse = false;   // 8 matrix passes instead of 10: the CG residual reuses M x and M dir of the line search
+    int reuse = 0;        // 0: ten products as written; 1: CG residual from the line search's products (8);
+                          // 2: additionally A^T (g_eq A x + lambda_eq) as one product (6 products, 4 passes with strips)
     DevBuf<double> sc, b, lam, w;                                         // rows
     DevBuf<double> c, lb, ub, x, xp, y, q, dir, xprev, r, lin, u, mx, md;        // unknowns (u: n_o)
     DevBuf<double> part, rowpart, colpart, scal, out;
-    DevBuf<double> wx, wd, u2;   // batched form: A x, A dir (rows) and [A^T A x | A^T A dir] (2 n_o)
+    DevBuf<double> wx, wd, u2, v1;   // batched form: A x, A dir, g_eq A x + lambda (rows) and the two A^T products (2 n_o)
     bool have_w = false;
 };
 
@@ -380,17 +398,39 @@ static void cg_elem(slp_admm_cg *s, int slot, const double *u = nullptr, const d
 // A^T (A x), A^T (A dir) in one two-vector pass: 5 passes over the matrix per iteration instead of 8.
 // Every product is the same arithmetic as in the unbatched form; only the passes are shared.
 static bool cg_batched(slp_admm_cg *s) {
-    return s->reuse && s->m > 0 && s->n_o > 0 && fast_format(s->a, false) && fast_format(s->a, true);
+    if (!s->reuse || s->m <= 0 || s->n_o <= 0) return false;
+    if (s->reuse >= 2) return true;  // the fused form is written on top of the shared products
+    return fast_format(s->a, false) && fast_format(s->a, true);
 }
 
 static void cg_refresh_products(slp_admm_cg *s) {  // wx = A x, wd = A dir
-    if (s->wx.n < (size_t)s->m) { s->wx.alloc((size_t)s->m); s->wd.alloc((size_t)s->m); s->u2.alloc(2 * (size_t)s->n_o); }
+    if (s->wx.n < (size_t)s->m) {
+        s->wx.alloc((size_t)s->m); s->wd.alloc((size_t)s->m); s->v1.alloc((size_t)s->m); s->u2.alloc(2 * (size_t)s->n_o);
+    }
     cg_rows2(s, s->x.p, s->dir.p, s->wx.p, s->wd.p);
     s->have_w = true;
 }
 
 // first half of an iteration: everything up to (and including) the over-relaxed x (:148-201)
 static void cg_xstep(slp_admm_cg *s) {
+    if (s->reuse >= 2 && cg_batched(s)) {
+        // fused: [A^T (g_eq A x + lambda), A^T (A dir)] in one two-vector pass; y is never formed
+        if (!s->have_w) {
+            cg_refresh_products(s);
+            hipLaunchKernelGGL(k_cg_v1, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->wx.p, s->lam.p,
+                               s->gamma_eq, s->v1.p);
+            SLP_HIP(hipGetLastError());
+        }
+        cg_cols2(s, s->v1.p, s->wd.p, s->u2.p);
+        cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p);
+        cg_elem<E_LINE_DMD>(s, S_DMD, s->u2.p + s->n_o, s->wd.p);
+        cg_elem<E_LINE_STEP>(s, -1);
+        cg_elem<E_RESID_FUSED>(s, S_RS);
+        cg_rows(s, s->r.p); cg_cols(s, s->w.p); cg_elem<E_PAP>(s, S_PAP);
+        cg_elem<E_UPDATE>(s, -1);
+        s->have_w = false;
+        return;
+    }
     cg_cols(s, s->lam.p);                                   // A^T lambda_eq over the original variables
     cg_elem<E_RHS>(s, -1, s->u.p, s->lam.p);                // slack part of A^T lambda: sc_i * lambda_i
     if (cg_batched(s)) {
@@ -427,7 +467,7 @@ static void cg_multipliers(slp_admm_cg *s) {
     }
     if (s->m) {
         hipLaunchKernelGGL(k_cg_multiplier, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, ax, s->b.p,
-                           s->gamma_eq, s->lam.p);
+                           s->gamma_eq, s->lam.p, (s->reuse >= 2 && ax == s->wx.p) ? s->v1.p : (double *)nullptr);
         SLP_HIP(hipGetLastError());
     }
 }
@@ -558,7 +598,7 @@ int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse) {
     SLP_API_INT({
         SLP_REQUIRE(s, "NULL handle");
         if (reuse && s->mx.n < (size_t)s->N) { s->mx.alloc((size_t)s->N); s->md.alloc((size_t)s->N); s->mx.zero(); s->md.zero(); }
-        s->reuse = reuse != 0;
+        s->reuse = reuse < 0 ? 0 : (reuse > 2 ? 2 : reuse);
         s->have_w = false;
     })
 }
