@@ -46,6 +46,9 @@ def parse():
     p.add_argument("--density", type=float, default=1e-3)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--method", default="admm", choices=["admm", "chambolle_pock_ppd"])
+    p.add_argument("--eq-frac", type=float, default=0.0,
+                   help="fraction of the constraint rows turned into equalities a_i x = a_i x_feasible (randomLP.py:62-68); "
+                        "the default all-inequality LP is the primary workload")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-n", type=int, default=100_000)
     return p.parse_args()
@@ -121,7 +124,13 @@ def main():
     nnz_local = a.nnz
     from pysparselp_amd.scale import make_solver
 
-    solver = make_solver(args.method, a, b, c, lb, ub)
+    m_eq_local = 0
+    if args.eq_frac > 0:  # the first eq_frac * m GLOBAL rows are equalities b_eq = A x_feasible; this rank holds its share
+        m_eq_global = int(round(args.eq_frac * args.m))
+        m_eq_local = max(0, min(rows, m_eq_global - r0))
+        if m_eq_local:
+            b[:m_eq_local] = a.matvec(xf)[:m_eq_local]
+    solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local)
     _lib.check(lib.slp_synchronize())
     t_gen = time.perf_counter() - t_gen
 
@@ -181,7 +190,7 @@ def main():
                 "workload": f"randomLP synthetic: {args.n} vars, {args.m} inequality rows, density {args.density}, "
                             f"{nnz_total} stored entries, method {args.method} ({solver.describe()}), "
                             f"rows partitioned over {world} GPU(s)",
-                "n": args.n, "m": args.m, "density": args.density, "seed": args.seed, "nnz": nnz_total,
+                "n": args.n, "m": args.m, "density": args.density, "seed": args.seed, "nnz": nnz_total, "eq_frac": args.eq_frac,
                 "method": args.method, "matrix_passes_per_iteration": passes,
             },
             "roofline": {

@@ -175,6 +175,11 @@ slp_admm_cg *slp_admm_cg_create(int64_t N, int64_t m, const int64_t *indptr, con
 slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, const double *c,
                                    const double *lb, const double *ub, double gamma_eq,
                                    double gamma_ineq, int order);
+/* Same with the first m_eq rows of the resident matrix being equalities a_i x = b_i (b = [b_eq; b_upper]):
+ * they get no slack entry (standard form [A_eq 0; A_ineq -I], tools.py:96-107). */
+slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a, int64_t m_eq, const double *b, const double *c,
+                                         const double *lb, const double *ub, double gamma_eq,
+                                         double gamma_ineq, int order);
 void slp_admm_cg_destroy(slp_admm_cg *s);
 /* Products of A per iteration (same mathematics, fp64 rounding differences only); default 0:
  * 0  ten, as the reference writes the iteration;

@@ -251,8 +251,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_report_final(int nr, const double
 // ---- device-side setup of the all-inequality standard form (ADMM.py:76-91, tools.py:272-290,88-127)
 // pass 1: inv1_i = 1/||a_i||_2 (0 -> 1);  a_ij *= inv1_i ; bu_i *= inv1_i
 // pass 2: inv2_i = 1/sqrt(sum_j a'_ij^2 + 1) ; a'_ij *= inv2_i ; sc_i = -1 * inv2_i   (the slack entry of [A' -I])
+// Rows i < m_eq are equalities [A_eq' 0] (tools.py:96-107): no slack entry (sc_i = 0, no "+ 1"), and their
+// right-hand side b_eq is scaled in both passes; inequality rows end with right-hand side 0 and the scaled
+// upper bound bu_i on their slack variable.
 template <int L>
-__global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, const i64 *__restrict__ ptr, double *__restrict__ val, int pass,
+__global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, i64 m_eq, const i64 *__restrict__ ptr, double *__restrict__ val, int pass,
                                                           double *__restrict__ bu, double *__restrict__ sc) {
     const int sub = threadIdx.x & (L - 1);
     const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
@@ -262,15 +265,27 @@ __global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, const i64 *__re
         double acc = 0.0;
         for (i64 k = s + sub; k < e; k += L) acc += (val[k] * val[k]) * 1.0;
         acc = group_sum<L>(acc);
-        if (pass == 2) acc = acc + 1.0;
+        if (pass == 2 && i >= m_eq) acc = acc + 1.0;
         double nrm = sqrt(acc);
         if (nrm == 0.0) nrm = 1.0;
         const double inv = 1.0 / nrm;
         for (i64 k = s + sub; k < e; k += L) val[k] = inv * val[k];
         if (sub == 0) {
             if (pass == 1) bu[i] = inv * bu[i];
-            else sc[i] = inv * -1.0;
+            else if (i >= m_eq) sc[i] = inv * -1.0;
+            else { sc[i] = 0.0; bu[i] = inv * bu[i]; }
         }
+    }
+}
+
+// after the two scaling passes: rhs_i = b_eq'' (equalities) or 0; slack bounds [0,0] (equalities) or [-inf, bu']
+__global__ void k_cg_split_rows(i64 m, i64 m_eq, const double *__restrict__ bu, double *__restrict__ rhs, double *__restrict__ slo,
+                                double *__restrict__ shi) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        const bool eq = i < m_eq;
+        rhs[i] = eq ? bu[i] : 0.0;
+        slo[i] = eq ? 0.0 : -__builtin_inf();
+        shi[i] = eq ? 0.0 : bu[i];
     }
 }
 
@@ -533,8 +548,14 @@ slp_admm_cg *slp_admm_cg_create(int64_t N, int64_t m, const int64_t *indptr, con
 
 slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, const double *c, const double *lb,
                                    const double *ub, double gamma_eq, double gamma_ineq, int order) {
+    return slp_admm_cg_create_on_mixed(a_ineq, 0, b_upper, c, lb, ub, gamma_eq, gamma_ineq, order);
+}
+
+slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a_ineq, int64_t m_eq, const double *b_upper, const double *c, const double *lb,
+                                         const double *ub, double gamma_eq, double gamma_ineq, int order) {
     SLP_API_PTR({
         SLP_REQUIRE(a_ineq && b_upper && c && lb && ub, "slp_admm_cg_create_on: NULL argument");
+        SLP_REQUIRE(m_eq >= 0 && m_eq <= a_ineq->a.nrow, "slp_admm_cg_create_on_mixed: m_eq out of range");
         auto *s = new slp_admm_cg();
         try {
             hipStream_t st = ctx().stream;
@@ -553,12 +574,12 @@ slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, co
                 const int lanes = lanes_for(a, SLP_ORDER_TREE);
                 for (int pass = 1; pass <= 2; ++pass) {
                     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_scale_rows<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0,
-                                                                 st, m, a.ptr.p, a.val.p, pass, bu.p, s->sc.p));
+                                                                 st, m, (i64)m_eq, a.ptr.p, a.val.p, pass, bu.p, s->sc.p));
                     SLP_HIP(hipGetLastError());
                 }
             }
             build_transpose(a_ineq);
-            // c2 = [c; 0]  lb2 = [lb; -inf]  ub2 = [ub; bu']  b = 0  x0 = 0
+            // c2 = [c; 0]  lb2 = [lb; -inf]  ub2 = [ub; bu']  b = 0  x0 = 0   (equality rows: b = b_eq'', slack pinned to 0)
             const size_t N = (size_t)s->N;
             s->c.alloc(N); s->lb.alloc(N); s->ub.alloc(N); s->x.alloc(N); s->b.alloc((size_t)m);
             s->c.zero(); s->x.zero(); s->b.zero();
@@ -566,8 +587,9 @@ slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, co
             SLP_HIP(hipMemcpyAsync(s->lb.p, lb, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
             SLP_HIP(hipMemcpyAsync(s->ub.p, ub, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
             if (m) {
-                hipLaunchKernelGGL(k_fill, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, st, m, s->lb.p + n, -__builtin_inf());
-                SLP_HIP(hipMemcpyAsync(s->ub.p + n, bu.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(k_cg_split_rows, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, st, m, (i64)m_eq, bu.p, s->b.p, s->lb.p + n,
+                                   s->ub.p + n);
+                SLP_HIP(hipGetLastError());
             }
             SLP_HIP(hipStreamSynchronize(st));
             cg_alloc_state(s);

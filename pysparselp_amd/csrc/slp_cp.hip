@@ -325,8 +325,11 @@ static void cp_primal(slp_cp *s, bool store_d) {
         hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
                            at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
                            s->m_ineq, opt, s->theta);
-    } else if (const StripJds *f = (s->m_eq == 0 || s->m_ineq == 0) ? fast_format(s->k, true) : nullptr) {
-        // long columns: LDS-tiled K^T y, then the elementwise update (the eq/ineq split is void with one kind of row)
+    } else if (const StripJds *f = (s->m_eq == 0 || s->m_ineq == 0 || s->order != SLP_ORDER_SEQUENTIAL) ? fast_format(s->k, true)
+                                                                                                        : nullptr) {
+        // long columns: LDS-tiled K^T y, then the elementwise update.  With both kinds of rows this adds the equality
+        // and inequality terms of a column in one chain instead of (c + s_eq) + s_ineq: rounding only, and only
+        // outside SEQUENTIAL order
         strip_spmv(*f, s->y.p, s->pre.p);
         hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
                            at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,

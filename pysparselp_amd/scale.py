@@ -13,13 +13,13 @@ from ._lib import ORDER_AUTO
 class DeviceCP:
     """Chambolle-Pock (reference ChambollePockPPD.py:195-343) on a DeviceMatrix."""
 
-    def __init__(self, a, b_upper, c, lb, ub, alpha=1.0, theta=1.0, order=ORDER_AUTO):
+    def __init__(self, a, b_upper, c, lb, ub, alpha=1.0, theta=1.0, order=ORDER_AUTO, m_eq=0):
         self._l = _lib.lib()
         self.a = a
         self.n = a.shape[1]
         self.c = _lib.f64(c)
         b_upper, lb, ub = _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
-        self._h = _lib.check_handle(self._l.slp_cp_create_on(a._h, 0, _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
+        self._h = _lib.check_handle(self._l.slp_cp_create_on(a._h, int(m_eq), _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
                                                              _lib.ptr(ub), None, float(alpha), float(theta), int(order)))
 
     def close(self):
@@ -52,11 +52,12 @@ class DeviceCP:
         return "diagonally preconditioned Chambolle-Pock, alpha=1, theta=1"
 
 
-def make_solver(method, a, b_upper, c, lb, ub):
+def make_solver(method, a, b_upper, c, lb, ub, m_eq=0):
+    """``b_upper[:m_eq]`` are equality right-hand sides (the first ``m_eq`` rows), the rest upper bounds."""
     if method == "chambolle_pock_ppd":
-        return DeviceCP(a, b_upper, c, lb, ub)
+        return DeviceCP(a, b_upper, c, lb, ub, m_eq=m_eq)
     if method == "admm":
         from .admm_cg import DeviceADMM
 
-        return DeviceADMM(a, b_upper, c, lb, ub)
+        return DeviceADMM(a, b_upper, c, lb, ub, m_eq=m_eq)
     raise ValueError(method)
