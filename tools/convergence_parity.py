@@ -1,4 +1,8 @@
-"""GPU vs CPU oracle over longer horizons on the benchmark distribution (mid size): objective and iterate\nagreement after 50 / 150 / 400 iterations of CP and of the matrix-free ADMM (reuse levels 0 and 2).\npython tools/convergence_parity.py"""
+"""GPU vs CPU oracle over longer horizons on the benchmark distribution (mid size): objective and iterate
+agreement after 50 / 150 / 400 iterations of CP and of the matrix-free ADMM (reuse levels 0 and 2).
+
+    python tools/convergence_parity.py
+"""
 import os, sys, json, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
