@@ -135,6 +135,12 @@ slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr,
                           const int32_t *m_indices, const double *m_data,
                           double gamma_eq, double gamma_ineq, int order);
 void slp_admm_destroy(slp_admm *s);
+/* x-step of the iteration; call before the first iteration.
+ * 0 (default): one projected Gauss-Seidel sweep, the flags the reference ships (ADMM.py:66-71,:162).
+ * 1: the reference's use_unbounded_gauss_siedel branch (ADMM.py:164-181, gaussSiedel.pyx:21-79): one plain
+ *    Gauss-Seidel sweep, x = 1.4 x - 0.4 xp, then xp = clip(x + lambda_ineq/g_ineq), lambda_ineq += g_ineq (x - xp)
+ *    (:253-256) before the lambda_eq update. */
+int slp_admm_set_xstep(slp_admm *s, int mode);
 int slp_admm_iterate(slp_admm *s, int64_t k);
 /* Halves of one iteration around the reference's report (:213-248). */
 int slp_admm_sweep_step(slp_admm *s);

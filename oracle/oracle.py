@@ -533,3 +533,52 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
         lambda_eq = lambda_eq + gamma_eq * (matvec(a, x) - b)  # :261-263
         i += 1
     return x[0:n]
+
+
+# --------------------------------------------------------------------------
+# ADMM, unbounded Gauss-Seidel x-step with over-relaxation (ADMM.py:164-181, :252-256): the third flag-selected
+# branch of the reference (use_unbounded_gauss_siedel=True, use_bounded_gauss_siedel=False).  One plain SOR sweep
+# of M x = y (gaussSiedel.pyx:21-79), x = 1.4 x - 0.4 xp, then the explicit projection / lambda_ineq update.
+# --------------------------------------------------------------------------
+def lp_admm_gs_unbounded(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq=2, gamma_ineq=3, nb_iter=100,
+                         callback_func=None, max_time=None, use_preconditioning=True, nb_iter_plot=10):
+    n = np.asarray(c).size
+    s = admm_setup(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0, gamma_eq, gamma_ineq, use_preconditioning)
+    c, a, b, lb, ub, x, m, atb = (s[k] for k in ("c", "a", "b", "lb", "ub", "x0", "m", "atb"))
+    x = x.copy()
+    xp = np.maximum(x, 0)
+    lambda_eq = np.zeros(a.shape[0])
+    lambda_ineq = np.zeros(x.shape)
+    d = diagonal(m)
+    invd = 1 / d
+    alpha = 1.4
+    lib = _lib()
+    lib.orc_gauss_seidel.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_double]
+    lib.orc_gauss_seidel.restype = None
+
+    def energy(x, xp, lambda_eq, lambda_ineq):
+        r = matvec(a, x) - b
+        return (c.dot(x) + 0.5 * gamma_eq * np.sum(r ** 2) + 0.5 * gamma_ineq * np.sum((x - xp) ** 2)
+                + lambda_eq.dot(matvec(a, x) - b) + lambda_ineq.dot(x - xp))
+
+    start = time.perf_counter()
+    i = 0
+    while i <= nb_iter:
+        y = -c + gamma_eq * atb + gamma_ineq * xp - rmatvec(a, lambda_eq) - lambda_ineq  # :148
+        lib.orc_gauss_seidel(m.shape[0], _p(m.indptr), _p(m.indices), _p(m.data), _p(d), _p(invd), _p(_f64(y)), _p(x), 1, 1.0)  # :179
+        x = alpha * x + (1 - alpha) * xp  # :181
+        if i % nb_iter_plot == 0:
+            elapsed = time.perf_counter() - start
+            if max_time is not None and elapsed > max_time:
+                break
+            energy1 = energy(x, xp, lambda_eq, lambda_ineq)
+            r = matvec(a, x) - b
+            if callback_func is not None:
+                callback_func(i, x[0:n], energy1, energy1, elapsed, np.max(np.abs(r)), max(0, -np.min(x)))
+        xp = x.copy() + lambda_ineq / gamma_ineq  # :253-256
+        xp = np.maximum(xp, lb)
+        xp = np.minimum(xp, ub)
+        lambda_ineq = lambda_ineq + gamma_ineq * (x - xp)
+        lambda_eq = lambda_eq + gamma_eq * (matvec(a, x) - b)
+        i += 1
+    return x[0:n]

@@ -210,3 +210,21 @@ void orc_row_scale_l2(i64 nrow, const i64 *indptr, const double *data, double *i
         inv_s[i] = 1.0 / s;
     }
 }
+
+/* Unbounded SOR sweep, gaussSiedel.pyx:21-79 (`GaussSeidel`), natural order (order=None -> arange):
+ * v = sum_k x[indices[k]] * data[k] ; nv = (b[i] - v + D[i]*x[i]) * invD[i] ; x[i] = w*nv + (1-w)*x[i].
+ * Only reached through the reference's flag-selected branch ADMM.py:164-181. */
+void orc_gauss_seidel(i64 n, const i64 *indptr, const i32 *indices, const double *data, const double *D,
+                      const double *invD, const double *b, double *x, int maxiter, double w)
+{
+    for (int it = 0; it < maxiter; ++it) {
+        for (i64 i = 0; i < n; ++i) {
+            double v = 0.0;
+            for (i64 k = indptr[i]; k < indptr[i + 1]; ++k)
+                v += x[indices[k]] * data[k];
+            double nv = (b[i] - v + D[i] * x[i]) * invD[i];
+            nv = w * nv + (1 - w) * x[i];
+            x[i] = nv;
+        }
+    }
+}

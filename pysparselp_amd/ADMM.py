@@ -42,6 +42,9 @@ class ADMMState:
 
     __del__ = close
 
+    def set_xstep(self, mode):
+        _lib.check(self._l.slp_admm_set_xstep(self._h, int(mode)))
+
     def iterate(self, k):
         _lib.check(self._l.slp_admm_iterate(self._h, int(k)))
 
@@ -100,7 +103,9 @@ def lp_admm(
 
     ``xstep`` (extension): ``"gauss_seidel"`` is the reference as shipped;
     ``"cg"`` is the reference's conjugate-gradient branch (flags at
-    ADMM.py:66-71), run matrix-free -- see ``admm_cg.py``.
+    ADMM.py:66-71), run matrix-free -- see ``admm_cg.py``;
+    ``"gauss_seidel_unbounded"`` is its plain Gauss-Seidel + over-relaxation
+    branch (ADMM.py:164-181).
     """
     if xstep == "cg":
         from .admm_cg import lp_admm_cg
@@ -108,7 +113,7 @@ def lp_admm(
         return lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=x0, gamma_eq=gamma_eq, gamma_ineq=gamma_ineq,
                           nb_iter=nb_iter, callback_func=callback_func, max_time=max_time,
                           use_preconditioning=use_preconditioning, nb_iter_plot=nb_iter_plot, order=order)
-    if xstep != "gauss_seidel":
+    if xstep not in ("gauss_seidel", "gauss_seidel_unbounded"):
         raise ValueError(f"unknown xstep {xstep!r}")
     c = _lib.f64(c)
     n = c.size
@@ -125,6 +130,8 @@ def lp_admm(
     m_mat = normal_matrix(a, gamma_eq, gamma_ineq)  # ADMM.py:93-101
 
     state = ADMMState(a, b, c2, lb2, ub2, x_init, m_mat, gamma_eq, gamma_ineq, order)
+    if xstep == "gauss_seidel_unbounded":  # the reference's use_unbounded_gauss_siedel flags (ADMM.py:164-181)
+        state.set_xstep(1)
     try:
         start = time.perf_counter()
         i = 0

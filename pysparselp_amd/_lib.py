@@ -56,6 +56,7 @@ _SIGNATURES = {
     "slp_gs_solve": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_dbl]),
     "slp_admm_create": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_admm_destroy": (None, [c_vp]),
+    "slp_admm_set_xstep": (c_int, [c_vp, c_int]),
     "slp_admm_iterate": (c_int, [c_vp, c_i64]),
     "slp_admm_sweep_step": (c_int, [c_vp]),
     "slp_admm_multiplier_step": (c_int, [c_vp]),

@@ -41,6 +41,9 @@ __device__ __forceinline__ double gs_row_dot(i64 s, i64 e, const i32 *__restrict
 
 // One level of one sweep.  The matrix is stored in LEVEL ORDER: position t (first..first+count) holds row rows[t];
 // its entries are ptr[t]..ptr[t+1], so pointer and entry loads do not wait for the row id.
+// BOUNDED: boundedGaussSeidelClass.solve (:131-152).  !BOUNDED: GaussSeidel (:58-69), the plain SOR update
+// nv = (b - v + D x_i) / D ; x_i = w nv + (1 - w) x_i, no clamp.
+template <bool BOUNDED>
 __global__ __launch_bounds__(kBlock) void k_gs_level(i64 first, i64 count, const i32 *__restrict__ rows, const i64 *__restrict__ ptr,
                                                      const i32 *__restrict__ idx, const double *__restrict__ val,
                                                      const double *__restrict__ invd, const double *__restrict__ b,
@@ -51,17 +54,25 @@ __global__ __launch_bounds__(kBlock) void k_gs_level(i64 first, i64 count, const
     const i64 pos = first + t;
     const i32 i = rows[pos];
     const i64 s = ptr[pos], e = ptr[pos + 1];
-    const double bi = b[i], inv = invd[pos], l = lo[i], u = hi[i], xi = x[i];  // independent of the row walk
+    const double bi = b[i], inv = invd[pos], xi = x[i];  // independent of the row walk
     double v = gs_row_dot(s, e, idx, val, x);
-    v = w * (bi - v) * inv + xi;                                         // :145
-    if (v < l) v = l;                                                    // :148-151
-    else if (v > u) v = u;
+    if (BOUNDED) {
+        const double l = lo[i], u = hi[i];
+        v = w * (bi - v) * inv + xi;                                     // :145
+        if (v < l) v = l;                                                // :148-151
+        else if (v > u) v = u;
+    } else {
+        const double d = lo[pos];                                        // diagonal, level-ordered (passed in `lo`)
+        const double nv = (bi - v + d * xi) * inv;                       // :67
+        v = w * nv + (1 - w) * xi;                                       // :68
+    }
     x[i] = v;
 }
 
 // Small systems: the whole sweep inside ONE workgroup, levels separated by a
 // workgroup barrier instead of a kernel boundary (launch latency dominates
 // otherwise: SC105 has 41 levels of ~4 rows).
+template <bool BOUNDED>
 __global__ __launch_bounds__(1024) void k_gs_sweep_one_block(i64 nlevels, const i64 *__restrict__ lptr,
                                                              const i32 *__restrict__ rows, const i64 *__restrict__ ptr,
                                                              const i32 *__restrict__ idx, const double *__restrict__ val,
@@ -75,10 +86,16 @@ __global__ __launch_bounds__(1024) void k_gs_sweep_one_block(i64 nlevels, const 
                 const i32 i = rows[t];
                 double v = 0.0;
                 for (i64 k = ptr[t]; k < ptr[t + 1]; ++k) v += __hip_atomic_load(&x[idx[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * val[k];
-                v = w * (b[i] - v) * invd[t] + x[i];
-                const double lw = lo[i], u = hi[i];
-                if (v < lw) v = lw;
-                else if (v > u) v = u;
+                if (BOUNDED) {
+                    v = w * (b[i] - v) * invd[t] + x[i];
+                    const double lw = lo[i], u = hi[i];
+                    if (v < lw) v = lw;
+                    else if (v > u) v = u;
+                } else {
+                    const double xi = x[i];
+                    const double nv = (b[i] - v + lo[t] * xi) * invd[t];  // lo = level-ordered diagonal
+                    v = w * nv + (1 - w) * xi;
+                }
                 x[i] = v;
             }
             __syncthreads();  // same CU: stores of this level are visible to the next one
@@ -87,13 +104,14 @@ __global__ __launch_bounds__(1024) void k_gs_sweep_one_block(i64 nlevels, const 
 }
 
 __global__ void k_invert_diag(i64 n, const i32 *__restrict__ rows, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
-                              const double *__restrict__ val, double *__restrict__ invd) {
+                              const double *__restrict__ val, double *__restrict__ invd, double *__restrict__ diag) {
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
         const i32 i = rows[t];
         double d = 0.0;  // A.diagonal(): 0 where no entry is stored
         for (i64 k = ptr[t]; k < ptr[t + 1]; ++k)
             if (idx[k] == i) d += val[k];
         invd[t] = 1.0 / d;  // gaussSiedel.pyx:91-92
+        diag[t] = d;
     }
 }
 
@@ -101,7 +119,7 @@ struct GsPlan {
     i64 n = 0, nnz = 0, nlevels = 0, max_width = 0;
     DevBuf<i64> ptr;         // level-ordered storage: position t holds row rows[t], entries ptr[t]..ptr[t+1]
     DevBuf<i32> idx;
-    DevBuf<double> val, invd; // invd[t] = 1 / M[rows[t], rows[t]]
+    DevBuf<double> val, invd, diag; // invd[t] = 1 / M[rows[t], rows[t]], diag[t] = M[rows[t], rows[t]]
     DevBuf<i32> rows;        // rows sorted by level (stable: increasing row inside a level)
     DevBuf<i64> lptr_dev;    // level pointer on the device (single-workgroup path)
     std::vector<i64> lptr;   // level pointer on the host (launch sizes)
@@ -165,30 +183,42 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
     g.rows.upload(rows.data(), (size_t)n);
     g.lptr_dev.upload(g.lptr.data(), g.lptr.size());
     g.invd.alloc((size_t)n);
+    g.diag.alloc((size_t)n);
     if (n) {
         hipLaunchKernelGGL(k_invert_diag, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, g.rows.p, g.ptr.p, g.idx.p,
-                           g.val.p, g.invd.p);
+                           g.val.p, g.invd.p, g.diag.p);
         SLP_HIP(hipGetLastError());
     }
     // a single workgroup wins while the per-level launch cost (>= ~1.5 us) exceeds the work of a level
     g.one_block = (g.max_width <= 2048) && (g.nnz <= 200000);
 }
 
-static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const double *hi, double *x, double w, int sweeps) {
+// bounded = false: plain SOR sweep (no bounds); the kernels then read the diagonal through the `lo` argument
+static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const double *hi, double *x, double w, int sweeps,
+                     bool bounded = true) {
     if (g.n == 0 || sweeps <= 0) return;
     hipStream_t st = ctx().stream;
+    if (!bounded) { lo = g.diag.p; hi = g.diag.p; }
     if (g.one_block) {
         const int threads = g.max_width <= 64 ? 64 : (g.max_width <= 256 ? 256 : 1024);
-        hipLaunchKernelGGL(k_gs_sweep_one_block, dim3(1), dim3(threads), 0, st, g.nlevels, g.lptr_dev.p, g.rows.p, g.ptr.p, g.idx.p,
-                           g.val.p, g.invd.p, b, lo, hi, x, w, sweeps);
+        if (bounded)
+            hipLaunchKernelGGL(k_gs_sweep_one_block<true>, dim3(1), dim3(threads), 0, st, g.nlevels, g.lptr_dev.p, g.rows.p, g.ptr.p,
+                               g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w, sweeps);
+        else
+            hipLaunchKernelGGL(k_gs_sweep_one_block<false>, dim3(1), dim3(threads), 0, st, g.nlevels, g.lptr_dev.p, g.rows.p, g.ptr.p,
+                               g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w, sweeps);
         SLP_HIP(hipGetLastError());
         return;
     }
     for (int s = 0; s < sweeps; ++s)
         for (i64 l = 0; l < g.nlevels; ++l) {
             const i64 beg = g.lptr[(size_t)l], cnt = g.lptr[(size_t)l + 1] - beg;
-            hipLaunchKernelGGL(k_gs_level, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, beg, cnt, g.rows.p,
-                               g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
+            if (bounded)
+                hipLaunchKernelGGL(k_gs_level<true>, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, beg, cnt,
+                                   g.rows.p, g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
+            else
+                hipLaunchKernelGGL(k_gs_level<false>, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, beg, cnt,
+                                   g.rows.p, g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
         }
     SLP_HIP(hipGetLastError());
 }
@@ -207,13 +237,13 @@ template <int L>
 __global__ __launch_bounds__(kBlock) void k_admm_rhs(i64 n, const i64 *__restrict__ tptr, const i32 *__restrict__ tidx,
                                                      const double *__restrict__ tval, const double *__restrict__ lam,
                                                      const double *__restrict__ q, const double *__restrict__ xp,
-                                                     double gamma_ineq, double *__restrict__ y) {
+                                                     double gamma_ineq, const double *__restrict__ lin, double *__restrict__ y) {
     const int sub = threadIdx.x & (L - 1);
     const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
     const i64 ngroups = (i64)gridDim.x * kBlock / L;
     for (i64 j = group; j < n; j += ngroups) {
         const double s = row_dot<L>(tptr, tidx, tval, lam, j, sub);
-        if (sub == 0) y[j] = ((q[j] + gamma_ineq * xp[j]) - s) - 0.0;
+        if (sub == 0) y[j] = ((q[j] + gamma_ineq * xp[j]) - s) - lin[j];  // lambda_ineq stays 0 on the shipped branch
     }
 }
 
@@ -306,6 +336,36 @@ __global__ __launch_bounds__(kBlock) void k_admm_report_final(int nr, const doub
     }
 }
 
+// unbounded-GS branch: x = alpha x + (1 - alpha) xp   (ADMM.py:181)
+__global__ void k_admm_relax(i64 n, double alpha, double one_minus_alpha, const double *__restrict__ xp, double *__restrict__ x) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x)
+        x[j] = alpha * x[j] + one_minus_alpha * xp[j];
+}
+
+// xp = clip(x + lambda_ineq / g_ineq, lb, ub) ; lambda_ineq += g_ineq (x - xp)   (ADMM.py:253-256)
+__global__ void k_admm_project(i64 n, double gamma_ineq, const double *__restrict__ x, const double *__restrict__ lb,
+                               const double *__restrict__ ub, double *__restrict__ xp, double *__restrict__ lin) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        const double xj = x[j];
+        double p = xj + lin[j] / gamma_ineq;
+        const double l = lb[j], u = ub[j];
+        p = (p < l) ? l : p;
+        p = (p > u) ? u : p;
+        xp[j] = p;
+        lin[j] = lin[j] + gamma_ineq * (xj - p);
+    }
+}
+
+// sum_j lambda_ineq_j (x_j - xp_j), one workgroup, fixed order (report term of the unbounded-GS branch)
+__global__ __launch_bounds__(kBlock) void k_admm_lin_term(i64 n, const double *__restrict__ lin, const double *__restrict__ x,
+                                                          const double *__restrict__ xp, double *__restrict__ out) {
+    __shared__ double lds[kBlock / kWave];
+    double s = 0.0;
+    for (i64 j = threadIdx.x; j < n; j += kBlock) s += lin[j] * (x[j] - xp[j]);
+    const double r = block_reduce<false>(s, lds);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
 __global__ void k_max0(i64 n, const double *__restrict__ x, double *__restrict__ xp) {
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x)
         xp[j] = (x[j] < 0.0) ? 0.0 : x[j];  // np.maximum(x, 0)  (ADMM.py:98)
@@ -327,6 +387,9 @@ struct slp_admm {
     double gamma_eq = 2, gamma_ineq = 3;
     int order = SLP_ORDER_AUTO, lanes_rows = 1, lanes_cols = 1;
     bool xp_is_x = false;     // false only before the first multiplier step (:98 vs :259)
+    int xstep = 0;            // 0: projected Gauss-Seidel (shipped flags); 1: plain Gauss-Seidel + over-relaxation (:164-181)
+    double alpha = 1.4;       // :140
+    DevBuf<double> lin;       // lambda_ineq (stays 0 for xstep 0)
     IterGraph graph;
     DevBuf<double> b, c, lb, ub, x, xp0, lam, q, y, rowparts, colparts, out;
 };
@@ -340,14 +403,27 @@ static void admm_sweep(slp_admm *s) {
     const double *xp = s->xp_is_x ? s->x.p : s->xp0.p;
     const int lanes = s->lanes_cols;
     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_admm_rhs<L>), dim3(grid_for(s->N * lanes, kBlock)), dim3(kBlock), 0, st, s->N,
-                                                 at.ptr.p, at.idx.p, at.val.p, s->lam.p, s->q.p, xp, s->gamma_ineq, s->y.p));
+                                                 at.ptr.p, at.idx.p, at.val.p, s->lam.p, s->q.p, xp, s->gamma_ineq, s->lin.p, s->y.p));
     SLP_HIP(hipGetLastError());
-    gs_sweep(s->plan, s->y.p, s->lb.p, s->ub.p, s->x.p, 1.0, 1);  // :162 maxiter=1, w=1
+    if (s->xstep == 0) {
+        gs_sweep(s->plan, s->y.p, s->lb.p, s->ub.p, s->x.p, 1.0, 1);  // :162 maxiter=1, w=1
+    } else {
+        gs_sweep(s->plan, s->y.p, nullptr, nullptr, s->x.p, 1.0, 1, false);  // :179 GaussSeidel(m, y, x, maxiter=1, w=1.0)
+        hipLaunchKernelGGL(k_admm_relax, dim3(grid_for(s->N, kBlock)), dim3(kBlock), 0, st, s->N, s->alpha, 1.0 - s->alpha, s->xp0.p,
+                           s->x.p);  // :181
+        SLP_HIP(hipGetLastError());
+    }
 }
 
 static void admm_multiplier(slp_admm *s) {
     const CsrDev &a = s->a->a;
-    s->xp_is_x = true;  // :259
+    if (s->xstep == 0) {
+        s->xp_is_x = true;  // :259
+    } else if (s->N) {       // :253-256: xp stays a vector of its own
+        hipLaunchKernelGGL(k_admm_project, dim3(grid_for(s->N, kBlock)), dim3(kBlock), 0, ctx().stream, s->N, s->gamma_ineq, s->x.p,
+                           s->lb.p, s->ub.p, s->xp0.p, s->lin.p);
+        SLP_HIP(hipGetLastError());
+    }
     if (s->m == 0) return;
     const int lanes = s->lanes_rows;
     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_admm_multiplier<L>), dim3(grid_for(s->m * lanes, kBlock)), dim3(kBlock), 0,
@@ -404,6 +480,7 @@ slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr, const i
             s->b.upload(b, (size_t)m); s->c.upload(c, (size_t)N); s->lb.upload(lb, (size_t)N); s->ub.upload(ub, (size_t)N);
             s->x.upload(x0, (size_t)N);
             s->xp0.alloc((size_t)N); s->lam.alloc((size_t)m); s->lam.zero();
+            s->lin.alloc((size_t)N); s->lin.zero();
             s->q.alloc((size_t)N); s->y.alloc((size_t)N);
             s->rowparts.alloc((size_t)kAdmmPartials * 3); s->colparts.alloc((size_t)kAdmmPartials * 3); s->out.alloc(8);
             hipStream_t st = ctx().stream;
@@ -430,13 +507,22 @@ int slp_admm_iterate(slp_admm *s, int64_t k) {
     SLP_API_INT({
         SLP_REQUIRE(s && k >= 0, "slp_admm_iterate: bad arguments");
         auto one = [&]() { admm_sweep(s); admm_multiplier(s); };
-        if (k > 0 && !s->xp_is_x) {  // the first iteration reads xp0 instead of x: not part of the replayed graph
+        if (k > 0 && !s->xp_is_x && s->xstep == 0) {  // the first iteration reads xp0 instead of x: not part of the replayed graph
             one();
             --k;
         }
         // one launch per dependency level is launch-latency bound: replay the iteration as a captured graph
         if (s->a->a.nnz <= 20000000) s->graph.run(k, s->plan.nlevels > 64 || s->plan.one_block ? 1 : 8, one);
         else for (i64 it = 0; it < k; ++it) one();
+    })
+}
+
+int slp_admm_set_xstep(slp_admm *s, int mode) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && (mode == 0 || mode == 1), "slp_admm_set_xstep: mode must be 0 or 1");
+        SLP_REQUIRE(!s->xp_is_x, "slp_admm_set_xstep: must be called before the first iteration");
+        s->xstep = mode;
+        s->graph.reset();
     })
 }
 
@@ -458,10 +544,15 @@ int slp_admm_report(slp_admm *s, double out[3]) {
                                                      a.val.p, s->x.p, s->b.p, s->lam.p, s->rowparts.p));
         hipLaunchKernelGGL(k_admm_report_final, dim3(1), dim3(kBlock), 0, st, gr, s->rowparts.p, gc, s->colparts.p, s->out.p);
         SLP_HIP(hipGetLastError());
-        double h[6];
-        s->out.download(h, 6);
-        // c.x + 0.5*g_eq*sum r^2 + 0.5*g_ineq*sum (x-xp)^2 + lambda.r + lambda_ineq.(x-xp)[=0]   (:124-132)
-        out[0] = h[3] + 0.5 * s->gamma_eq * h[0] + 0.5 * s->gamma_ineq * h[4] + h[1] + 0.0;
+        double h[7];
+        h[6] = 0.0;
+        if (s->xstep != 0 && s->N) {
+            hipLaunchKernelGGL(k_admm_lin_term, dim3(1), dim3(kBlock), 0, st, s->N, s->lin.p, s->x.p, xp, s->out.p + 6);
+            SLP_HIP(hipGetLastError());
+        }
+        s->out.download(h, s->xstep != 0 ? 7 : 6);
+        // c.x + 0.5*g_eq*sum r^2 + 0.5*g_ineq*sum (x-xp)^2 + lambda.r + lambda_ineq.(x-xp)   (:124-132)
+        out[0] = h[3] + 0.5 * s->gamma_eq * h[0] + 0.5 * s->gamma_ineq * h[4] + h[1] + h[6];
         out[1] = h[2];                                // :221
         out[2] = (h[5] > 0.0) ? h[5] : 0.0;           // :222 max(0, -min x)
     })

@@ -54,6 +54,11 @@ def build_reference():
     s = s.replace("    use_cg = False\n    use_bounded_gauss_siedel = True\n",
                   "    use_cg = True\n    use_bounded_gauss_siedel = False\n")
     open(os.path.join(REF_TMP, "pysparselp", "ADMM_cgflags.py"), "w").write(s)
+    s = open(os.path.join(REF_TMP, "pysparselp", "ADMM.py")).read()
+    assert "    use_bounded_gauss_siedel = True\n    use_unbounded_gauss_siedel = False\n" in s
+    s = s.replace("    use_bounded_gauss_siedel = True\n    use_unbounded_gauss_siedel = False\n",
+                  "    use_bounded_gauss_siedel = False\n    use_unbounded_gauss_siedel = True\n")
+    open(os.path.join(REF_TMP, "pysparselp", "ADMM_ugsflags.py"), "w").write(s)
 
 
 def install_shims():
@@ -220,6 +225,20 @@ def run_case(name, lp, keep_iters, nb_iter, ground_truth=None, gt_indices=None, 
     out.update(admmcg_it=np.array(rec["it"]), admmcg_x=np.array(rec["x"]), admmcg_e1=np.array(rec["e1"]),
                admmcg_veq=np.array(rec["veq"]), admmcg_vineq=np.array(rec["vineq"]),
                admmcg_matrix_free_drift=np.array(worst))
+    # --- ADMM with the unbounded Gauss-Seidel x-step + over-relaxation (flag-flipped copy, ADMM.py:164-181)
+    from pysparselp.ADMM_ugsflags import lp_admm as lp_admm_ugs
+
+    with contextlib.redirect_stdout(sink):
+        rec = capture(lambda cb: lp_admm_ugs(*args, nb_iter=nb_iter, x0=None, callback_func=cb,
+                                             max_time=None, nb_iter_plot=1), keep)
+    orc = capture(lambda cb: oracle.lp_admm_gs_unbounded(*args, nb_iter=nb_iter, x0=None, callback_func=cb, max_time=None,
+                                                         nb_iter_plot=1), keep)
+    assert rec["it"] == orc["it"]
+    for a, b in zip(rec["x"], orc["x"]):
+        assert np.array_equal(a, b), f"{name}: admm unbounded-GS oracle differs from reference, max {np.max(np.abs(a-b))}"
+    assert np.array_equal(rec["veq"], orc["veq"]) and np.array_equal(rec["vineq"], orc["vineq"])
+    out.update(admmugs_it=np.array(rec["it"]), admmugs_x=np.array(rec["x"]), admmugs_e1=np.array(rec["e1"]),
+               admmugs_veq=np.array(rec["veq"]), admmugs_vineq=np.array(rec["vineq"]))
     # --- CP: SparseLP.py:1244-1288 (remove_fixed_variables, then the solver)
     lp_red = copy.deepcopy(lp)
     m_change, shift = lp_red.remove_fixed_variables()

@@ -355,3 +355,28 @@ def test_admm_cg_on_device_generated_lp_matches_oracle():
     xo = oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
     assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < TREE_RTOL
     assert abs(c.dot(x) - c.dot(xo)) <= 1e-6 * abs(c.dot(xo))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_admm_unbounded_gauss_seidel_iterates_bit_exact(case):
+    """xstep="gauss_seidel_unbounded": plain Gauss-Seidel + 1.4 over-relaxation + explicit lambda_ineq (ADMM.py:164-181,:252-256)."""
+    lp_admm = _mods()[0]
+    d = load_golden("lp_" + case)
+    rec = Recorder(d["admmugs_it"])
+    x = lp_admm(*solver_args(d), nb_iter=int(d["admmugs_it"][-1]), callback_func=rec, nb_iter_plot=1, order=_mods()[3],
+                xstep="gauss_seidel_unbounded")
+    assert rec.it == list(d["admmugs_it"])
+    assert np.array_equal(np.array(rec.x), d["admmugs_x"])
+    assert np.array_equal(x, d["admmugs_x"][-1])
+    assert np.array_equal(rec.veq, d["admmugs_veq"]) and np.array_equal(rec.vineq, d["admmugs_vineq"])
+    np.testing.assert_allclose(rec.e1, d["admmugs_e1"], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("case", ["sc105", "potts50"])
+def test_admm_unbounded_gauss_seidel_graph_replay(case):
+    """Reporting every 7 iterations (graph-replayed stretches in between) gives the same iterates as reporting every one."""
+    lp_admm = _mods()[0]
+    d = load_golden("lp_" + case)
+    last = int(d["admmugs_it"][-1])
+    x = lp_admm(*solver_args(d), nb_iter=last, nb_iter_plot=7, order=_mods()[3], xstep="gauss_seidel_unbounded")
+    assert np.array_equal(x, d["admmugs_x"][-1])
