@@ -91,7 +91,7 @@ class DeviceADMM(_CGBase):
         """A [x, dir] and the two A^T products of the line search share one sweep over the matrix each
         when both orientations run on the strip kernel."""
         l = self._l
-        return bool(self.reuse and l.slp_matrix_spmv_kernel(self.a._h, 0) == 1 and l.slp_matrix_spmv_kernel(self.a._h, 1) == 1)
+        return bool(self.reuse and l.slp_matrix_spmv_kernel(self.a._h, 0) >= 1 and l.slp_matrix_spmv_kernel(self.a._h, 1) >= 1)
 
     def matrix_products_per_iteration(self):
         return {0: 10, 1: 8, 2: 6}[self.reuse]

@@ -278,6 +278,43 @@ __global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, i64 m_eq, const
     }
 }
 
+// The same two passes WITHOUT touching the matrix: rs_i = inv2_i * inv1_i is kept as a row-scale vector and
+// applied around the products (A v = rs o (A0 v), A^T w = A0^T (rs o w)).  Used when the unscaled matrix has few
+// distinct values and runs on the value-dictionary strips (slp_strip.hip): scaling the entries would
+// make every row's values unique.  Differs from the in-place form by the rounding of rs_i * sum versus
+// sum of (rs_i * a_ij) terms only.
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_cg_row_scales(i64 m, i64 m_eq, const i64 *__restrict__ ptr, const double *__restrict__ val,
+                                                          double *__restrict__ bu, double *__restrict__ sc, double *__restrict__ rs) {
+    const int sub = threadIdx.x & (L - 1);
+    const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
+    const i64 ngroups = (i64)gridDim.x * kBlock / L;
+    for (i64 i = group; i < m; i += ngroups) {
+        const i64 s = ptr[i], e = ptr[i + 1];
+        double acc = 0.0;
+        for (i64 k = s + sub; k < e; k += L) acc += (val[k] * val[k]) * 1.0;
+        acc = group_sum<L>(acc);
+        double nrm = sqrt(acc);
+        if (nrm == 0.0) nrm = 1.0;
+        const double inv1 = 1.0 / nrm;
+        acc = 0.0;
+        for (i64 k = s + sub; k < e; k += L) {
+            const double v = inv1 * val[k];
+            acc += (v * v) * 1.0;
+        }
+        acc = group_sum<L>(acc);
+        if (i >= m_eq) acc = acc + 1.0;
+        nrm = sqrt(acc);
+        if (nrm == 0.0) nrm = 1.0;
+        const double inv2 = 1.0 / nrm;
+        if (sub == 0) {
+            rs[i] = inv2 * inv1;
+            if (i >= m_eq) { sc[i] = inv2 * -1.0; bu[i] = inv1 * bu[i]; }
+            else { sc[i] = 0.0; bu[i] = inv2 * (inv1 * bu[i]); }
+        }
+    }
+}
+
 // after the two scaling passes: rhs_i = b_eq'' (equalities) or 0; slack bounds [0,0] (equalities) or [-inf, bu']
 __global__ void k_cg_split_rows(i64 m, i64 m_eq, const double *__restrict__ bu, double *__restrict__ rhs, double *__restrict__ slo,
                                 double *__restrict__ shi) {
@@ -307,6 +344,7 @@ struct slp_admm_cg {
     int reuse = 0;        // 0: ten products as written; 1: CG residual from the line search's products (8);
                           // 2: additionally A^T (g_eq A x + lambda_eq) as one product (6 products, 4 passes with strips)
     DevBuf<double> sc, b, lam, w;                                         // rows
+    DevBuf<double> rs, ws0, ws1;   // deferred row scaling (value-dictionary strips): A = diag(rs) A0; scratch rs o w
     DevBuf<double> c, lb, ub, x, xp, y, q, dir, xprev, r, lin, u, mx, md;        // unknowns (u: n_o)
     DevBuf<double> part, rowpart, colpart, scal, out;
     DevBuf<double> wx, wd, u2, v1;   // batched form: A x, A dir, g_eq A x + lambda (rows) and the two A^T products (2 n_o)
@@ -315,8 +353,35 @@ struct slp_admm_cg {
 
 namespace slp {
 
-__global__ void k_cg_add_slack(i64 m, const double *__restrict__ sc, const double *__restrict__ vs, double *__restrict__ w) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) w[i] = w[i] + sc[i] * vs[i];
+// w = rs o w (deferred row scale, optional) + sc o vs (the slack column, optional)
+__global__ void k_cg_add_slack(i64 m, const double *__restrict__ rs, const double *__restrict__ sc, const double *__restrict__ vs,
+                               double *__restrict__ w) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        double v = w[i];
+        if (rs) v = rs[i] * v;
+        if (sc) v = v + sc[i] * vs[i];
+        w[i] = v;
+    }
+}
+
+__global__ void k_cg_row_scaled(i64 m, const double *__restrict__ rs, const double *__restrict__ w, double *__restrict__ out) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) out[i] = rs[i] * w[i];
+}
+
+static void cg_finish_rows(slp_admm_cg *s, const double *v, double *w) {
+    if (!s->ns && !s->rs.p) return;
+    hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->rs.p,
+                       s->ns ? s->sc.p : (double *)nullptr, v + s->n_o, w);
+    SLP_HIP(hipGetLastError());
+}
+
+// rs o w in scratch (deferred row scaling) or w itself
+static const double *cg_scaled_rows(slp_admm_cg *s, const double *w, DevBuf<double> &tmp) {
+    if (!s->rs.p) return w;
+    if (tmp.n < (size_t)s->m) tmp.alloc((size_t)s->m);
+    hipLaunchKernelGGL(k_cg_row_scaled, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->rs.p, w, tmp.p);
+    SLP_HIP(hipGetLastError());
+    return tmp.p;
 }
 
 // w_out = A v   (v over the N unknowns: original part, then this rank's slack part)
@@ -326,12 +391,10 @@ static void cg_rows(slp_admm_cg *s, const double *v, double *w_out = nullptr) {
     const CsrDev &a = s->a->a;
     if (const StripJds *f = fast_format(s->a, false)) {  // long rows: LDS-tiled product, then the slack column
         strip_spmv(*f, v, w);
-        if (s->ns) {
-            hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->sc.p, v + s->n_o, w);
-            SLP_HIP(hipGetLastError());
-        }
+        cg_finish_rows(s, v, w);
         return;
     }
+    SLP_REQUIRE(!s->rs.p, "deferred row scaling needs the strip format in both orientations");
     const int lanes = s->lanes_rows;
     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_rows<L>), dim3(grid_for(s->m * lanes, kBlock)), dim3(kBlock), 0, ctx().stream,
                                                  s->m, a.ptr.p, a.idx.p, a.val.p, v, s->ns ? s->sc.p : nullptr, s->n_o, w));
@@ -343,11 +406,8 @@ static void cg_rows2(slp_admm_cg *s, const double *v0, const double *v1, double 
     if (s->m == 0) return;
     if (const StripJds *f = fast_format(s->a, false)) {
         strip_spmv2(*f, v0, v1, w0, w1);
-        if (s->ns) {
-            hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->sc.p, v0 + s->n_o, w0);
-            hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->sc.p, v1 + s->n_o, w1);
-            SLP_HIP(hipGetLastError());
-        }
+        cg_finish_rows(s, v0, w0);
+        cg_finish_rows(s, v1, w1);
         return;
     }
     cg_rows(s, v0, w0);
@@ -360,8 +420,9 @@ static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr) {
     double *u = u_out ? u_out : s->u.p;
     const CsrDev &at = s->a->at;
     if (const StripJds *f = fast_format(s->a, true)) {
-        strip_spmv(*f, w, u);
+        strip_spmv(*f, cg_scaled_rows(s, w, s->ws0), u);
     } else {
+        SLP_REQUIRE(!s->rs.p, "deferred row scaling needs the strip format in both orientations");
         const int lanes = s->lanes_cols;
         SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_cols<L>), dim3(grid_for(s->n_o * lanes, kBlock)), dim3(kBlock), 0,
                                                      ctx().stream, s->n_o, at.ptr.p, at.idx.p, at.val.p, w, u));
@@ -379,7 +440,7 @@ static void cg_cols2(slp_admm_cg *s, const double *w0, const double *w1, double 
         cg_cols(s, w1, u2 + s->n_o);
         return;
     }
-    strip_spmv2(*f, w0, w1, u2, u2 + s->n_o);
+    strip_spmv2(*f, cg_scaled_rows(s, w0, s->ws0), cg_scaled_rows(s, w1, s->ws1), u2, u2 + s->n_o);
     if (s->distributed) comm_allreduce_dev(u2, 2 * s->n_o, 0);
 }
 
@@ -565,12 +626,26 @@ slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a_ineq, int64_t m_eq, const
             const i64 m = a.nrow, n = a.ncol;
             s->n_o = n; s->m = m; s->ns = m; s->N = n + m;
             s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
-            // rows scaled in place, twice; the transposed copy is (re)built from the scaled values
-            invalidate_derived(a_ineq);
             DevBuf<double> bu((size_t)m);
             bu.upload(b_upper, (size_t)m);
             s->sc.alloc((size_t)m);
-            if (m) {
+            // Few distinct stored values and long rows: keep the matrix as it is (value-dictionary strips) and carry
+            // the two row scalings as a vector.  Otherwise: rows scaled in place, twice; the transposed copy is
+            // (re)built from the scaled values.
+            bool deferred = false;
+            if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1)) && value_dictionary(a, a_ineq->vdict)) {
+                build_transpose(a_ineq);
+                const StripJds *f0 = fast_format(a_ineq, false), *f1 = fast_format(a_ineq, true);
+                deferred = f0 && f1 && f0->D > 0 && f1->D > 0;
+            }
+            if (deferred) {
+                s->rs.alloc((size_t)m);
+                const int lanes = lanes_for(a, SLP_ORDER_TREE);
+                SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_row_scales<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0, st,
+                                                             m, (i64)m_eq, a.ptr.p, a.val.p, bu.p, s->sc.p, s->rs.p));
+                SLP_HIP(hipGetLastError());
+            } else if (m) {
+                invalidate_derived(a_ineq);
                 const int lanes = lanes_for(a, SLP_ORDER_TREE);
                 for (int pass = 1; pass <= 2; ++pass) {
                     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_scale_rows<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0,
@@ -578,7 +653,7 @@ slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a_ineq, int64_t m_eq, const
                     SLP_HIP(hipGetLastError());
                 }
             }
-            build_transpose(a_ineq);
+            if (!deferred) build_transpose(a_ineq);
             // c2 = [c; 0]  lb2 = [lb; -inf]  ub2 = [ub; bu']  b = 0  x0 = 0   (equality rows: b = b_eq'', slack pinned to 0)
             const size_t N = (size_t)s->N;
             s->c.alloc(N); s->lb.alloc(N); s->ub.alloc(N); s->x.alloc(N); s->b.alloc((size_t)m);

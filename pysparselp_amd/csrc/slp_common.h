@@ -182,9 +182,24 @@ struct StripJds {
     DevBuf<unsigned int> soff;    // [B*T*256] offset of jagged diagonal s inside the cell
     DevBuf<double> val;           // [nnz]
     DevBuf<unsigned short> col;   // [nnz] column inside the strip
+    // value-dictionary variant (matrices with few distinct stored values): an entry is (uint16 value id,
+    // uint16 column) = 4 B; pairs of entries are packed as {id0, id1, col0, col1}; the D values sit in LDS
+    int C = 0;                    // columns per strip of this copy
+    int D = 0;                    // 0: fp64 values in `val`; > 0: `ent` + `dict`
+    int rpl = 2;                  // sorted positions per lane: 2 (pairs, 2048-row blocks) or 4 (quads, 4096-row blocks)
+    DevBuf<unsigned short> ent;   // [2 * nnz]
+    const double *dict = nullptr; // [D] sorted distinct values (owned by the slp_matrix)
 };
-bool strip_wanted(const CsrDev &a);
-bool strip_build(const CsrDev &a, StripJds &f);
+// sorted distinct stored values of a matrix, when there are at most kDictMax of them
+struct ValueDict {
+    int state = -1;                       // -1 not looked at, 0 too many distinct values, 1 available
+    int D = 0;
+    DevBuf<double> values;                // [D] ascending (total order on the bit patterns: -0.0 < +0.0)
+    DevBuf<unsigned long long> keys;      // [D] order-preserving integer image of `values`
+};
+bool value_dictionary(const CsrDev &a, ValueDict &d);
+bool strip_wanted(const CsrDev &a, int variant);   // variant: 0 fp64 entries, 1 dictionary pairs, 2 dictionary quads
+bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int variant);
 void strip_spmv(const StripJds &f, const double *x, double *out);
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1);  // one pass, two vectors
 
@@ -196,6 +211,7 @@ struct slp_matrix {
     bool have_at = false;
     slp::StripJds fa, fat;            // LDS-tiled copies of a / at, built on first use when they pay
     bool tried_fa = false, tried_fat = false;
+    slp::ValueDict vdict;             // shared by both orientations
     slp::DevBuf<double> vx, vy;  // scratch vectors for the host-vector entry points
 };
 

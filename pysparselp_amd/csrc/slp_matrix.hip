@@ -105,7 +105,15 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
     bool &tried = transposed ? m->tried_fat : m->tried_fa;
     if (!tried) {
         tried = true;
-        if (strip_wanted(a)) strip_build(a, f);
+        // few distinct stored values (rounded coefficients, +-1 patterns): 4-byte entries, values looked up in LDS
+        // quads (4096-row blocks, 3-byte entries) when that still leaves enough row blocks to fill the chip without
+        // splitting strips (a split changes the association of the row sums); else pairs.  SLP_DICT_VARIANT=1|2 forces.
+        const char *ev = getenv("SLP_DICT_VARIANT");
+        int variant = (a.nrow + 4095) / 4096 >= 384 ? 2 : 1;
+        if (ev && (ev[0] == '1' || ev[0] == '2')) variant = ev[0] - '0';
+        const bool dict = strip_wanted(a, variant) && value_dictionary(m->a, m->vdict);
+        if (dict) strip_build(a, f, &m->vdict, variant);
+        else if (strip_wanted(a, 0)) strip_build(a, f, nullptr, 0);
     }
     return f.ok ? &f : nullptr;
 }
@@ -125,6 +133,7 @@ void invalidate_derived(slp_matrix *m) {
     m->fa = StripJds();
     m->fat = StripJds();
     m->tried_fa = m->tried_fat = false;
+    m->vdict = ValueDict();
 }
 
 static void finish_stats(CsrDev &a) {
@@ -313,7 +322,24 @@ int slp_matrix_download(slp_matrix *m, int transposed, int64_t *indptr, int32_t 
 int slp_matrix_spmv_kernel(slp_matrix *m, int transposed) {
     try {
         SLP_REQUIRE(m, "slp_matrix_spmv_kernel: NULL matrix");
-        return fast_format(m, transposed != 0) ? 1 : 0;
+        const StripJds *f = fast_format(m, transposed != 0);
+        return f ? (f->D > 0 ? (f->rpl == 4 ? 3 : 2) : 1) : 0;
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return -1;
+    }
+}
+
+int64_t slp_matrix_format_bytes(slp_matrix *m, int transposed) {
+    try {
+        SLP_REQUIRE(m, "slp_matrix_format_bytes: NULL matrix");
+        const StripJds *f = fast_format(m, transposed != 0);
+        const CsrDev &a = transposed ? m->at : m->a;
+        if (!f) return (int64_t)(12 * a.nnz + 8 * (a.nrow + 1));
+        const size_t entries = f->D > 0 ? f->ent.n * sizeof(unsigned short) + (size_t)f->D * sizeof(double)
+                                        : f->val.n * sizeof(double) + f->col.n * sizeof(unsigned short);
+        return (int64_t)(entries + f->perm.n * sizeof(unsigned short) + f->slen.n + f->soff.n * sizeof(unsigned int) +
+                         f->base.n * sizeof(i64));
     } catch (const std::exception &e) {
         set_error(e.what());
         return -1;

@@ -24,8 +24,10 @@
 // the result equals the SEQUENTIAL single-accumulator sum of the CSR row -- bit
 // for bit (rows must be sorted by column, which holds for generated matrices
 // and for every device-built transpose).
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -35,31 +37,78 @@
 namespace slp {
 
 constexpr int kStripC = 7680;    // columns per strip: 60 KB of x in LDS
+constexpr int kDictC = 5888;     // value-dictionary variant: 46 KB of x + 16 KB of distinct values in LDS
+constexpr int kDictMax = 2048;   // most distinct stored values the dictionary variant takes
+constexpr int kDictHash = 16384; // slots of the detection hash set
+constexpr unsigned long long kDictEmpty = ~0ull;
+constexpr int kQuadC = 3968;     // quad variant: 4 rows per lane (4096-row blocks), 31 KB of x, 12-bit column + 12-bit value id
+constexpr int kQuadR = 4 * 1024;
+constexpr int kQuadU1 = 4, kQuadU2 = 6;  // 12-byte quad loads in flight per lane (64 VGPRs at two workgroups per CU: 6 would spill)
+constexpr int kDictU1 = 8, kDictU2 = 8;  // entry-pair loads in flight per lane (one / two right-hand sides)
 constexpr int kStripT = 1024;    // threads per workgroup
 constexpr int kStripR = 2048;    // rows per block (two per thread)
 constexpr int kStripSL = 256;    // slots (max entries of one row inside one strip)
-static_assert(kStripC % 2 == 0 && kStripR == 2 * kStripT, "strip geometry");
+static_assert(kStripC % 2 == 0 && kDictC % 2 == 0 && kStripR == 2 * kStripT, "strip geometry");
+
+// ---- distinct stored values ------------------------------------------------------
+// order-preserving map of fp64 bit patterns to unsigned integers (-0.0 sorts right below +0.0)
+__host__ __device__ inline unsigned long long value_key(unsigned long long bits) {
+    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+}
+
+// Insert every stored value's bit pattern into an open-addressing hash set; `count` = distinct values so
+// far.  Gives up (count > limit) as soon as the matrix turns out to have too many.
+__global__ __launch_bounds__(kBlock) void k_value_set(i64 nnz, const double *__restrict__ val, unsigned long long *table,
+                                                      unsigned int *count, unsigned int limit) {
+    i64 it = 0;
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (i64)gridDim.x * blockDim.x, ++it) {
+        if ((it & 63) == 0 && __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit) return;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(val[k]);
+        if (bits == kDictEmpty || val[k] != val[k]) {  // NaN entries (or the sentinel): no dictionary
+            atomicAdd(count, limit + 1);
+            return;
+        }
+        unsigned int h = (unsigned int)((bits * 0x9E3779B97F4A7C15ull) >> 40) & (kDictHash - 1);
+        for (int probes = 0;; ++probes) {
+            if (probes >= 64) {  // a set this crowded holds far more than `limit` values: give up (never spins on a full table)
+                atomicAdd(count, limit + 1);
+                return;
+            }
+            unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == bits) break;
+            if (cur == kDictEmpty) {
+                cur = atomicCAS(&table[h], kDictEmpty, bits);
+                if (cur == kDictEmpty) { atomicAdd(count, 1u); break; }
+                if (cur == bits) break;
+            }
+            h = (h + 1) & (kDictHash - 1);
+        }
+    }
+}
 
 // ---- conversion -------------------------------------------------------------
 // pass 1: per (block, strip): every row's entry count (uint8) and the padded cell size
 //         sum_s even(cnt[s]),  cnt[s] = rows of the cell with more than s entries
+template <int C, int RPL>
 __global__ __launch_bounds__(kStripT) void k_strip_count(i64 nrow, i64 T, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
                                                          unsigned char *__restrict__ len, unsigned long long *__restrict__ total,
                                                          int *__restrict__ bad) {
     __shared__ unsigned int hist[kStripSL];
+    constexpr int R = RPL * kStripT;  // rows per block, RPL per thread
     const i64 b = blockIdx.x;
-    i64 k[2], e[2];
-    i32 prev[2] = {-1, -1};
-    for (int h = 0; h < 2; ++h) {
-        const i64 row = b * kStripR + h * kStripT + threadIdx.x;
+    i64 k[RPL], e[RPL];
+    i32 prev[RPL];
+    for (int h = 0; h < RPL; ++h) {
+        const i64 row = b * R + h * kStripT + threadIdx.x;
         k[h] = e[h] = 0;
+        prev[h] = -1;
         if (row < nrow) { k[h] = ptr[row]; e[h] = ptr[row + 1]; }
     }
     for (i64 t = 0; t < T; ++t) {
         if (threadIdx.x < kStripSL) hist[threadIdx.x] = 0;
         __syncthreads();
-        const i64 hi = (t + 1) * (i64)kStripC;
-        for (int h = 0; h < 2; ++h) {
+        const i64 hi = (t + 1) * (i64)C;
+        for (int h = 0; h < RPL; ++h) {
             i64 c = 0;
             while (k[h] < e[h]) {
                 const i32 j = idx[k[h]];
@@ -69,7 +118,7 @@ __global__ __launch_bounds__(kStripT) void k_strip_count(i64 nrow, i64 T, const 
                 ++k[h]; ++c;
             }
             if (c >= kStripSL) { atomicOr(bad, 2); c = kStripSL - 1; }
-            len[(b * T + t) * kStripR + h * kStripT + threadIdx.x] = (unsigned char)c;
+            len[(b * T + t) * R + h * kStripT + threadIdx.x] = (unsigned char)c;
             atomicAdd(&hist[c], 1u);
         }
         __syncthreads();
@@ -77,7 +126,7 @@ __global__ __launch_bounds__(kStripT) void k_strip_count(i64 nrow, i64 T, const 
             unsigned int above = 0;  // rows with a count > l
             unsigned long long sum = 0;
             for (int l = kStripSL - 1; l >= 0; --l) {
-                sum += (above + 1u) & ~1u;  // slot l holds `above` entries, padded to even (0 stays 0)
+                sum += (above + (RPL - 1u)) & ~(RPL - 1u);  // slot l holds `above` entries, padded to a multiple of RPL
                 above += hist[l];
             }
             total[b * T + t] = sum;
@@ -88,27 +137,37 @@ __global__ __launch_bounds__(kStripT) void k_strip_count(i64 nrow, i64 T, const 
 
 // pass 2: sort the rows of every cell by count, write perm / sorted len / slot offsets and the entries
 // (the output arrays are zero-filled beforehand: the pad entries stay (0.0, column 0))
+// D > 0: value-dictionary output -- `keys` are the D sorted value keys, entries go to `oent` as packed pairs
+// {id(2p), id(2p+1), col(2p), col(2p+1)} of uint16 (pair index = entry index / 2) instead of oval / ocol
+// RPL == 4 (always with a dictionary): entries are 24-bit (id | column << 12), four of them -- sorted positions
+// 4p .. 4p+3 of one slot -- form a 12-byte quad; offsets and `base` still count entries.
+template <int C, int RPL>
 __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
                                                         const double *__restrict__ val, const unsigned char *__restrict__ len,
                                                         const i64 *__restrict__ base, unsigned short *__restrict__ perm,
                                                         unsigned char *__restrict__ slen, unsigned int *__restrict__ soff,
-                                                        double *__restrict__ oval, unsigned short *__restrict__ ocol) {
+                                                        double *__restrict__ oval, unsigned short *__restrict__ ocol, int D,
+                                                        const unsigned long long *__restrict__ keys,
+                                                        unsigned short *__restrict__ oent) {
     __shared__ unsigned int hist[kStripSL];   // rows with exactly this count, then the per-count cursor
     __shared__ unsigned int start[kStripSL];  // rows with a larger count  (= first sorted position of this count)
     __shared__ unsigned int offs[kStripSL];   // slot offsets
+    __shared__ unsigned long long skey[kDictMax];
+    for (int q = threadIdx.x; q < D; q += kStripT) skey[q] = keys[q];
+    constexpr int R = RPL * kStripT;
     const i64 b = blockIdx.x;
-    i64 k[2];
-    for (int h = 0; h < 2; ++h) {
-        const i64 row = b * kStripR + h * kStripT + threadIdx.x;
+    i64 k[RPL];
+    for (int h = 0; h < RPL; ++h) {
+        const i64 row = b * R + h * kStripT + threadIdx.x;
         k[h] = (row < nrow) ? ptr[row] : 0;
     }
     for (i64 t = 0; t < T; ++t) {
         const i64 cell = b * T + t;
         if (threadIdx.x < kStripSL) hist[threadIdx.x] = 0;
         __syncthreads();
-        unsigned int c[2];
-        for (int h = 0; h < 2; ++h) {
-            c[h] = len[cell * kStripR + h * kStripT + threadIdx.x];
+        unsigned int c[RPL];
+        for (int h = 0; h < RPL; ++h) {
+            c[h] = len[cell * R + h * kStripT + threadIdx.x];
             atomicAdd(&hist[c[h]], 1u);
         }
         __syncthreads();
@@ -116,7 +175,7 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
             unsigned int above = 0;
             for (int l = kStripSL - 1; l >= 0; --l) { start[l] = above; above += hist[l]; }
             unsigned int o = 0;  // cnt[s] = start[s]; slot s occupies even(cnt[s]) entries
-            for (int s = 0; s < kStripSL; ++s) { offs[s] = o; o += (start[s] + 1u) & ~1u; }
+            for (int s = 0; s < kStripSL; ++s) { offs[s] = o; o += (start[s] + (RPL - 1u)) & ~(RPL - 1u); }
         }
         __syncthreads();
         if (threadIdx.x < kStripSL) {
@@ -125,15 +184,36 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
         }
         __syncthreads();
         const i64 bs = base[cell];
-        const i32 col0 = (i32)(t * (i64)kStripC);
-        for (int h = 0; h < 2; ++h) {
+        const i32 col0 = (i32)(t * (i64)C);
+        for (int h = 0; h < RPL; ++h) {
             const unsigned int pos = start[c[h]] + atomicAdd(&hist[c[h]], 1u);
-            perm[cell * kStripR + pos] = (unsigned short)(h * kStripT + threadIdx.x);
-            slen[cell * kStripR + pos] = (unsigned char)c[h];
+            perm[cell * R + pos] = (unsigned short)(h * kStripT + threadIdx.x);
+            slen[cell * R + pos] = (unsigned char)c[h];
             for (unsigned int s = 0; s < c[h]; ++s) {
                 const i64 o = bs + offs[s] + pos;
-                oval[o] = val[k[h] + s];
-                ocol[o] = (unsigned short)(idx[k[h] + s] - col0);
+                const unsigned short jc = (unsigned short)(idx[k[h] + s] - col0);
+                if (D > 0) {
+                    const unsigned long long key = value_key((unsigned long long)__double_as_longlong(val[k[h] + s]));
+                    int lo = 0, hi = D - 1;  // the value is in the dictionary: plain binary search
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (skey[mid] < key) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    if (RPL == 4) {
+                        const unsigned int e24 = (unsigned int)lo | ((unsigned int)jc << 12);
+                        unsigned char *o8 = reinterpret_cast<unsigned char *>(oent) + o * 3;
+                        o8[0] = (unsigned char)e24;
+                        o8[1] = (unsigned char)(e24 >> 8);
+                        o8[2] = (unsigned char)(e24 >> 16);
+                    } else {
+                        oent[(o >> 1) * 4 + (o & 1)] = (unsigned short)lo;
+                        oent[(o >> 1) * 4 + 2 + (o & 1)] = jc;
+                    }
+                } else {
+                    oval[o] = val[k[h] + s];
+                    ocol[o] = jc;
+                }
             }
             k[h] += c[h];
         }
@@ -299,6 +379,238 @@ __global__ __launch_bounds__(kStripT, 4) void k_strip_spmv2(i64 nrow, i64 ncol, 
     }
 }
 
+// Value-dictionary variant, NV = 1 or 2 right-hand sides per pass.  An entry pair is one 8-byte load
+// {id0, id1, col0, col1}; the value is dict[id] read from LDS -- the same fp64 number the CSR holds, so every
+// row sum is still the sequential single-accumulator sum, bit for bit.  NV = 1: 46 KB x-tile + 16 KB sums
+// + 16 KB dictionary + 1 KB offsets = 79 KB (two workgroups per CU); NV = 2: 141 KB (one per CU).
+template <int NV>
+__global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
+                                                                         const unsigned short *__restrict__ perm,
+                                                                         const unsigned char *__restrict__ slen,
+                                                                         const unsigned int *__restrict__ soff,
+                                                                         const unsigned short *__restrict__ ent,
+                                                                         const double *__restrict__ dict, int D, int cap,
+                                                                         const double *__restrict__ x0, const double *__restrict__ x1,
+                                                                         double *__restrict__ out0, double *__restrict__ out1) {
+    __shared__ double xt[NV][kDictC];
+    __shared__ double acc[NV][kStripR];
+    __shared__ double dv[kDictMax];
+    const i64 b = blockIdx.x;
+    const int p = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { acc[v][p] = 0.0; acc[v][p + kStripT] = 0.0; }
+    for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
+    const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
+    // Software pipeline: the x-tile and the per-strip row metadata of strip t + 1 are loaded into registers
+    // while strip t's entries stream, so the tile's L2 / Infinity-Cache latency is off the critical path.
+    constexpr int kTileQ = (kDictC / 2 + kStripT - 1) / kStripT;
+    double2 tv[NV][kTileQ];
+    ushort2 r_next = make_ushort2(0, 0);
+    uchar2 nn_next = make_uchar2(0, 0);
+    i64 base_next = 0;
+    auto prefetch = [&](i64 t) {
+        const i64 cell = b * T + t;
+        const i64 c0 = t * (i64)kDictC;
+        const double *__restrict__ xa = x0 + c0, *__restrict__ xb = x1 + c0;
+        const int live = (int)((ncol - c0 < (i64)kDictC) ? ncol - c0 : (i64)kDictC);  // columns of this strip (uniform)
+#pragma unroll
+        for (int q = 0; q < kTileQ; ++q) {
+            const int j = (q * kStripT + p) * 2;
+            double2 v = make_double2(0.0, 0.0), u = make_double2(0.0, 0.0);
+            if (j + 1 < live) {
+                v = *reinterpret_cast<const double2 *>(xa + j);
+                if (NV == 2) u = *reinterpret_cast<const double2 *>(xb + j);
+            } else if (j < live) {
+                v.x = xa[j];
+                if (NV == 2) u.x = xb[j];
+            }
+            tv[0][q] = v;
+            if (NV == 2) tv[NV - 1][q] = u;
+        }
+        r_next = reinterpret_cast<const ushort2 *>(perm + cell * kStripR)[p];
+        nn_next = reinterpret_cast<const uchar2 *>(slen + cell * kStripR)[p];
+        base_next = base[cell];
+    };
+    if (t_begin < t_end) prefetch(t_begin);
+    for (i64 t = t_begin; t < t_end; ++t) {
+        const i64 cell = b * T + t;
+#pragma unroll
+        for (int q = 0; q < kTileQ; ++q) {
+            const int j = (q * kStripT + p) * 2;
+            if (j < kDictC) {
+                *reinterpret_cast<double2 *>(&xt[0][j]) = tv[0][q];
+                if (NV == 2) *reinterpret_cast<double2 *>(&xt[NV - 1][j]) = tv[NV - 1][q];
+            }
+        }
+        const ushort2 r = r_next;
+        unsigned int n0 = nn_next.x, n1 = nn_next.y;  // n0 >= n1 (sorted)
+        if (n0 > (unsigned int)cap) n0 = cap;  // timing experiments only (SLP_DSTRIP_CAP): wrong sums
+        const uint2 *__restrict__ e2 = reinterpret_cast<const uint2 *>(ent) + (base_next >> 1);
+        __syncthreads();
+        if (t + 1 < t_end) prefetch(t + 1);
+        double a0 = acc[0][r.x], a1 = acc[0][r.y], b0 = 0.0, b1 = 0.0;
+        if (NV == 2) { b0 = acc[NV - 1][r.x]; b1 = acc[NV - 1][r.y]; }
+#define SLP_DSTRIP_STEP(q, live1)                                                   \
+    {                                                                               \
+        const double w0 = dv[(q).x & 0xffffu];                                      \
+        const unsigned int ja = (q).y & 0xffffu;                                    \
+        a0 += w0 * xt[0][ja];                                                       \
+        if (NV == 2) b0 += w0 * xt[NV - 1][ja];                                     \
+        if (live1) {                                                                \
+            const double w1 = dv[(q).x >> 16];                                      \
+            const unsigned int jb = (q).y >> 16;                                    \
+            a1 += w1 * xt[0][jb];                                                   \
+            if (NV == 2) b1 += w1 * xt[NV - 1][jb];                                 \
+        }                                                                           \
+    }
+        // kDictU independent 8-byte loads in flight per lane; slots past the lane's count read the pair at
+        // offset p (always inside the array, see strip_build) and are skipped in the sums
+        // Rows are sorted by count, so a wave's first lane holds the wave's largest count: the loop is wave-uniform
+        // and the slot offsets come through the scalar cache.
+        constexpr int kDictU = NV == 1 ? kDictU1 : kDictU2;
+        const unsigned int n0w = (unsigned int)__builtin_amdgcn_readfirstlane((int)n0);
+        const unsigned int *__restrict__ so = soff + cell * kStripSL;
+        for (unsigned int s = 0; s < n0w; s += kDictU) {
+            uint2 q[kDictU];
+            unsigned int of[kDictU];  // s + i <= 255: counts are < 256 and s is a multiple of kDictU
+#pragma unroll
+            for (int i = 0; i < kDictU; ++i) of[i] = so[s + i];
+#pragma unroll
+            for (int i = 0; i < kDictU; ++i) q[i] = e2[(s + i < n0) ? (of[i] >> 1) + p : p];
+#pragma unroll
+            for (int i = 0; i < kDictU; ++i)
+                if (s + i < n0) SLP_DSTRIP_STEP(q[i], s + i < n1)
+        }
+#undef SLP_DSTRIP_STEP
+        acc[0][r.x] = a0;
+        acc[0][r.y] = a1;
+        if (NV == 2) { acc[NV - 1][r.x] = b0; acc[NV - 1][r.y] = b1; }
+        __syncthreads();
+    }
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + p;
+        if (row < nrow) {
+            out0[(i64)blockIdx.y * nrow + row] = acc[0][h * kStripT + p];
+            if (NV == 2) out1[(i64)blockIdx.y * nrow + row] = acc[NV - 1][h * kStripT + p];
+        }
+    }
+}
+
+// Quad variant of the value-dictionary kernel: 4096-row blocks, lane p owns sorted positions 4p .. 4p+3,
+// one 12-byte load brings slot s of all four rows (24-bit entries: 12-bit value id, 12-bit column).
+// Against the pair variant: 3 instead of 4 bytes per stored entry, and half the x-tile staging per entry
+// (the tile is shared by twice as many rows).  NV = 1: 31 KB x-tile + 32 KB sums + 16 KB dictionary
+// (two workgroups per CU); NV = 2: 142 KB.  Same single-accumulator, storage-order row sums.
+struct alignas(4) Quad12 { unsigned int x, y, z; };
+
+template <int NV>
+__global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
+                                                                         const unsigned short *__restrict__ perm,
+                                                                         const unsigned char *__restrict__ slen,
+                                                                         const unsigned int *__restrict__ soff,
+                                                                         const unsigned short *__restrict__ ent,
+                                                                         const double *__restrict__ dict, int D,
+                                                                         const double *__restrict__ x0, const double *__restrict__ x1,
+                                                                         double *__restrict__ out0, double *__restrict__ out1) {
+    __shared__ double xt[NV][kQuadC];
+    __shared__ double acc[NV][kQuadR];
+    __shared__ double dv[kDictMax];
+    const i64 b = blockIdx.x;
+    const int p = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) acc[v][p + h * kStripT] = 0.0;
+    for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
+    const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
+    constexpr int kTileQ = (kQuadC / 2 + kStripT - 1) / kStripT;
+    double2 tv[NV][kTileQ];
+    ushort4 r_next = make_ushort4(0, 0, 0, 0);
+    uchar4 nn_next = make_uchar4(0, 0, 0, 0);
+    i64 base_next = 0;
+    auto prefetch = [&](i64 t) {
+        const i64 cell = b * T + t;
+        const i64 c0 = t * (i64)kQuadC;
+        const double *__restrict__ xa = x0 + c0, *__restrict__ xb = x1 + c0;
+        const int live = (int)((ncol - c0 < (i64)kQuadC) ? ncol - c0 : (i64)kQuadC);
+#pragma unroll
+        for (int q = 0; q < kTileQ; ++q) {
+            const int j = (q * kStripT + p) * 2;
+            double2 v = make_double2(0.0, 0.0), u = make_double2(0.0, 0.0);
+            if (j + 1 < live) {
+                v = *reinterpret_cast<const double2 *>(xa + j);
+                if (NV == 2) u = *reinterpret_cast<const double2 *>(xb + j);
+            } else if (j < live) {
+                v.x = xa[j];
+                if (NV == 2) u.x = xb[j];
+            }
+            tv[0][q] = v;
+            if (NV == 2) tv[NV - 1][q] = u;
+        }
+        r_next = reinterpret_cast<const ushort4 *>(perm + cell * kQuadR)[p];
+        nn_next = reinterpret_cast<const uchar4 *>(slen + cell * kQuadR)[p];
+        base_next = base[cell];
+    };
+    if (t_begin < t_end) prefetch(t_begin);
+    for (i64 t = t_begin; t < t_end; ++t) {
+        const i64 cell = b * T + t;
+#pragma unroll
+        for (int q = 0; q < kTileQ; ++q) {
+            const int j = (q * kStripT + p) * 2;
+            if (j < kQuadC) {
+                *reinterpret_cast<double2 *>(&xt[0][j]) = tv[0][q];
+                if (NV == 2) *reinterpret_cast<double2 *>(&xt[NV - 1][j]) = tv[NV - 1][q];
+            }
+        }
+        const ushort4 r = r_next;
+        const unsigned int n0 = nn_next.x, n1 = nn_next.y, n2 = nn_next.z, n3 = nn_next.w;  // n0 >= n1 >= n2 >= n3
+        const Quad12 *__restrict__ e4 = reinterpret_cast<const Quad12 *>(ent) + (base_next >> 2);
+        __syncthreads();
+        if (t + 1 < t_end) prefetch(t + 1);
+        double a[NV][4];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { a[v][0] = acc[v][r.x]; a[v][1] = acc[v][r.y]; a[v][2] = acc[v][r.z]; a[v][3] = acc[v][r.w]; }
+#define SLP_QSTRIP_TERM(h, e24)                                     \
+    {                                                               \
+        const double w = dv[(e24) & 0xfffu];                        \
+        const unsigned int j = ((e24) >> 12) & 0xfffu;              \
+        a[0][h] += w * xt[0][j];                                    \
+        if (NV == 2) a[NV - 1][h] += w * xt[NV - 1][j];             \
+    }
+        constexpr int kU = NV == 1 ? kQuadU1 : kQuadU2;
+        const unsigned int n0w = (unsigned int)__builtin_amdgcn_readfirstlane((int)n0);  // sorted: the wave's largest count
+        const unsigned int *__restrict__ so = soff + cell * kStripSL;
+        for (unsigned int s = 0; s < n0w; s += kU) {
+            Quad12 q[kU];
+            unsigned int of[kU];
+#pragma unroll
+            for (int i = 0; i < kU; ++i) of[i] = so[(s + i) & (kStripSL - 1)];
+#pragma unroll
+            for (int i = 0; i < kU; ++i) q[i] = e4[(s + i < n0) ? (of[i] >> 2) + p : p];
+#pragma unroll
+            for (int i = 0; i < kU; ++i) {
+                if (s + i < n0) {
+                    SLP_QSTRIP_TERM(0, q[i].x)
+                    if (s + i < n1) SLP_QSTRIP_TERM(1, (q[i].x >> 24) | (q[i].y << 8))
+                    if (s + i < n2) SLP_QSTRIP_TERM(2, (q[i].y >> 16) | (q[i].z << 16))
+                    if (s + i < n3) SLP_QSTRIP_TERM(3, q[i].z >> 8)
+                }
+            }
+        }
+#undef SLP_QSTRIP_TERM
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { acc[v][r.x] = a[v][0]; acc[v][r.y] = a[v][1]; acc[v][r.z] = a[v][2]; acc[v][r.w] = a[v][3]; }
+        __syncthreads();
+    }
+    for (int h = 0; h < 4; ++h) {
+        const i64 row = b * kQuadR + h * kStripT + p;
+        if (row < nrow) {
+            out0[(i64)blockIdx.y * nrow + row] = acc[0][h * kStripT + p];
+            if (NV == 2) out1[(i64)blockIdx.y * nrow + row] = acc[NV - 1][h * kStripT + p];
+        }
+    }
+}
+
 // out[row] = ((part[0][row] + part[1][row]) + ...) in strip order (deterministic)
 __global__ void k_strip_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
@@ -309,20 +621,59 @@ __global__ void k_strip_combine(i64 nrow, int S, const double *__restrict__ part
 }
 
 // ---- host side ------------------------------------------------------------------
+// The sorted distinct stored values of `a`, if there are at most kDictMax (SLP_VALUE_DICT=0 turns the
+// variant off).  One pass over the values; gives up early on matrices with many distinct values.
+bool value_dictionary(const CsrDev &a, ValueDict &d) {
+    if (d.state >= 0) return d.state == 1;
+    d.state = 0;
+    const char *e = getenv("SLP_VALUE_DICT");
+    if ((e && e[0] == '0') || a.nnz == 0) return false;
+    hipStream_t st = ctx().stream;
+    DevBuf<unsigned long long> table((size_t)kDictHash);
+    DevBuf<unsigned int> count(1);
+    SLP_HIP(hipMemsetAsync(table.p, 0xff, (size_t)kDictHash * sizeof(unsigned long long), st));
+    count.zero();
+    hipLaunchKernelGGL(k_value_set, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, a.val.p, table.p, count.p,
+                       (unsigned int)kDictMax);
+    SLP_HIP(hipGetLastError());
+    unsigned int n = 0;
+    count.download(&n, 1);
+    if (n == 0 || n > (unsigned int)kDictMax) return false;
+    std::vector<unsigned long long> h((size_t)kDictHash), keys;
+    table.download(h.data(), h.size());
+    for (unsigned long long bits : h)
+        if (bits != kDictEmpty) keys.push_back(value_key(bits));
+    if (keys.size() != n) return false;
+    std::sort(keys.begin(), keys.end());
+    std::vector<double> vals(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        const unsigned long long k = keys[i], bits = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        std::memcpy(&vals[i], &bits, sizeof(double));
+    }
+    d.keys.upload(keys.data(), keys.size());
+    d.values.upload(vals.data(), vals.size());
+    d.D = (int)n;
+    d.state = 1;
+    return true;
+}
+
 // Builds the strip format of `a` (rows sorted by column).  Returns false (and leaves f.ok == false)
 // when the matrix does not qualify: unsorted rows, or a row with >= 256 entries inside one strip.
-bool strip_build(const CsrDev &a, StripJds &f) {
+// dict != NULL: the value-dictionary variant (narrower strips, 4-byte entries).
+template <int C, int RPL>
+static bool strip_build_c(const CsrDev &a, StripJds &f, const ValueDict *dict) {
+    constexpr int kStripR = RPL * kStripT;  // rows per block of this variant
     hipStream_t st = ctx().stream;
     f = StripJds();
     if (a.nrow == 0 || a.nnz == 0) return false;
-    const i64 T = (a.ncol + kStripC - 1) / kStripC, B = (a.nrow + kStripR - 1) / kStripR;
+    const i64 T = (a.ncol + C - 1) / C, B = (a.nrow + kStripR - 1) / kStripR;
     const size_t cells = (size_t)(B * T);
     DevBuf<unsigned char> len(cells * kStripR);
     DevBuf<unsigned long long> total(cells + 1);
     DevBuf<int> bad(1);
     total.zero();
     bad.zero();
-    hipLaunchKernelGGL(k_strip_count, dim3((unsigned)B), dim3(kStripT), 0, st, a.nrow, T, a.ptr.p, a.idx.p, len.p, total.p, bad.p);
+    hipLaunchKernelGGL((k_strip_count<C, RPL>), dim3((unsigned)B), dim3(kStripT), 0, st, a.nrow, T, a.ptr.p, a.idx.p, len.p, total.p, bad.p);
     SLP_HIP(hipGetLastError());
     int hbad = 0;
     bad.download(&hbad, 1);
@@ -343,15 +694,24 @@ bool strip_build(const CsrDev &a, StripJds &f) {
     f.perm.alloc(cells * kStripR);
     f.slen.alloc(cells * kStripR);
     f.soff.alloc(cells * kStripSL);
-    f.val.alloc((size_t)padded);
-    f.col.alloc((size_t)padded);
-    f.val.zero();
-    f.col.zero();
-    hipLaunchKernelGGL(k_strip_fill, dim3((unsigned)B), dim3(kStripT), 0, st, a.nrow, T, a.ptr.p, a.idx.p, a.val.p, len.p, f.base.p,
-                       f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p);
+    if (dict) {
+        // pair variant: 2 uint16 per entry; quad variant: 3 bytes per entry; + one row of pairs / quads for the
+        // kernel's masked-off loads
+        f.ent.alloc(RPL == 4 ? (3 * (size_t)padded + 1) / 2 + 6 * (size_t)kStripT : 2 * (size_t)padded + 4 * (size_t)kStripT);
+        f.ent.zero();
+        f.D = dict->D;
+        f.dict = dict->values.p;
+    } else {
+        f.val.alloc((size_t)padded);
+        f.col.alloc((size_t)padded);
+        f.val.zero();
+        f.col.zero();
+    }
+    hipLaunchKernelGGL((k_strip_fill<C, RPL>), dim3((unsigned)B), dim3(kStripT), 0, st, a.nrow, T, a.ptr.p, a.idx.p, a.val.p, len.p,
+                       f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, f.D, dict ? dict->keys.p : nullptr, f.ent.p);
     SLP_HIP(hipGetLastError());
     SLP_HIP(hipStreamSynchronize(st));
-    f.nrow = a.nrow; f.ncol = a.ncol; f.nnz = a.nnz; f.T = T; f.B = B;
+    f.nrow = a.nrow; f.ncol = a.ncol; f.nnz = a.nnz; f.T = T; f.B = B; f.C = C; f.rpl = RPL;
     // Few row blocks (a 1/4 or 1/8 row partition of the constraints): split every block's strips over S
     // workgroups so that the launch still fills the 256 CUs x 2 resident workgroups.
     const char *es = getenv("SLP_STRIP_SPLIT");
@@ -365,7 +725,32 @@ bool strip_build(const CsrDev &a, StripJds &f) {
     return true;
 }
 
+// dict: 0 = fp64 entries, 1 = value dictionary with pairs of rows per lane, 2 = value dictionary, quads
+bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int variant) {
+    if (!dict) return strip_build_c<kStripC, 2>(a, f, nullptr);
+    return variant == 2 ? strip_build_c<kQuadC, 4>(a, f, dict) : strip_build_c<kDictC, 2>(a, f, dict);
+}
+
+static int dstrip_cap() {
+    const char *e = getenv("SLP_DSTRIP_CAP");
+    return e ? atoi(e) : 255;
+}
+
 void strip_spmv(const StripJds &f, const double *x, double *out) {
+    if (f.D > 0) {
+        if (f.rpl == 4)
+            hipLaunchKernelGGL((k_qstrip_spmv<1>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
+                               f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
+                               (double *)nullptr);
+        else
+        hipLaunchKernelGGL((k_dstrip_spmv<1>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T,
+                           f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, dstrip_cap(), x, x, f.S > 1 ? f.part.p : out,
+                           (double *)nullptr);
+        if (f.S > 1)
+            hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
+        SLP_HIP(hipGetLastError());
+        return;
+    }
     const char *e = getenv("SLP_STRIP_ABLATE");
     const int ab = e ? atoi(e) : 0;
 #define SLP_STRIP_LAUNCH(A)                                                                                                        \
@@ -388,8 +773,15 @@ void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *
         o0 = f.part2.p;
         o1 = f.part2.p + (size_t)f.S * (size_t)f.nrow;
     }
-    hipLaunchKernelGGL(k_strip_spmv2, dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p,
-                       f.slen.p, f.soff.p, f.val.p, f.col.p, x0, x1, o0, o1);
+    if (f.D > 0 && f.rpl == 4)
+        hipLaunchKernelGGL((k_qstrip_spmv<2>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
+                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1);
+    else if (f.D > 0)
+        hipLaunchKernelGGL((k_dstrip_spmv<2>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
+                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, dstrip_cap(), x0, x1, o0, o1);
+    else
+        hipLaunchKernelGGL(k_strip_spmv2, dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
+                           f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x0, x1, o0, o1);
     if (f.S > 1) {
         hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, st, f.nrow, f.S, o0, out0);
         hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, st, f.nrow, f.S, o1, out1);
@@ -399,11 +791,12 @@ void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *
 
 // Does the format pay?  Long rows (the gather-bound regime) and enough entries per (row, strip) to amortise
 // the 3 bytes of per-(row, strip) metadata and the x-tile staging.
-bool strip_wanted(const CsrDev &a) {
+bool strip_wanted(const CsrDev &a, int variant) {
     const char *e = getenv("SLP_STRIP_MIN_NNZ");  // below this size launch latency, not the gathers, dominates
     const i64 min_nnz = e ? atoll(e) : 30000000ll;  // measured cross-over vs the CSR kernel (tools/strip_threshold.py)
     if (a.nnz < min_nnz) return false;
-    const double per_cell = a.mean_row_len() / (double)((a.ncol + kStripC - 1) / kStripC);
+    const int C = variant == 2 ? kQuadC : (variant == 1 ? kDictC : kStripC);
+    const double per_cell = a.mean_row_len() / (double)((a.ncol + C - 1) / C);
     return per_cell >= 3.0 && per_cell <= 64.0;
 }
 

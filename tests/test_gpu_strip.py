@@ -11,12 +11,26 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def strips_everywhere(monkeypatch):
-    """Force the strip format on small matrices (it normally starts at 2e7 stored entries)."""
+KERNEL_CODE = {"quads": 3, "pairs": 2, "fp64": 1}
+
+
+@pytest.fixture(params=["quads", "pairs", "fp64"])
+def strips_everywhere(monkeypatch, request):
+    """Force the strip format on small matrices (it normally starts at 3e7 stored entries): the two
+    value-dictionary variants (the generated coefficients are rounded to 0.01: ~1000 distinct values; quads =
+    4096-row blocks with 3-byte entries, pairs = 2048-row blocks with 4-byte entries) and fp64 entries."""
     monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
-    yield
-    monkeypatch.delenv("SLP_STRIP_MIN_NNZ", raising=False)
+    monkeypatch.setenv("SLP_VALUE_DICT", "0" if request.param == "fp64" else "1")
+    monkeypatch.setenv("SLP_DICT_VARIANT", "1" if request.param == "pairs" else "2")
+    yield request.param
+    for k in ("SLP_STRIP_MIN_NNZ", "SLP_VALUE_DICT", "SLP_DICT_VARIANT"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def _kernel(dm, transposed=0):
+    from pysparselp_amd import _lib
+
+    return _lib.lib().slp_matrix_spmv_kernel(dm._h, transposed)
 
 
 @pytest.mark.parametrize("n,m,p", [(30000, 2500, 0.001), (20000, 3000, 0.002), (70000, 1100, 0.0008), (8192, 1024, 0.004)])
@@ -31,6 +45,30 @@ def test_strip_spmv_bit_exact(strips_everywhere, n, m, p):
     x, y = rng.randn(n), rng.randn(m)
     assert np.array_equal(a.matvec(x), oracle.matvec(oa, x))
     assert np.array_equal(a.rmatvec(y), oracle.rmatvec(oa, y))
+    want = KERNEL_CODE[strips_everywhere]
+    assert _kernel(a, 0) == want and _kernel(a, 1) in (0, want)  # short transposed rows stay on the CSR kernel
+
+
+def test_value_dictionary_only_when_few_distinct_values(monkeypatch):
+    """Continuous coefficients (more than 2048 distinct values): fp64 strips.  +-0.0 and denormals are kept apart."""
+    import scipy.sparse
+    from pysparselp_amd.device import DeviceMatrix
+
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
+    rng = np.random.RandomState(5)
+    a = scipy.sparse.random(3000, 20000, density=0.002, random_state=rng, format="csr")
+    a.sort_indices()
+    x = rng.randn(20000)
+    dm = DeviceMatrix.from_csr(a)
+    assert np.array_equal(dm.matvec(x, 1), oracle.matvec(oracle.as_csr(a), x))
+    assert _kernel(dm) == 1
+    b = a.copy()
+    b.data = rng.choice(np.array([1.0, -1.0, 0.5, -0.0, 0.0, 5e-324, 1e300, -2.5]), size=b.nnz)
+    dm = DeviceMatrix.from_csr(b)
+    y = rng.randn(3000)
+    assert np.array_equal(dm.matvec(x, 1), oracle.matvec(oracle.as_csr(b), x))
+    assert np.array_equal(dm.rmatvec(y, 1), oracle.rmatvec(oracle.as_csr(b), y))
+    assert _kernel(dm) == 2 and _kernel(dm, 1) == 2  # few row blocks: the pair variant
 
 
 def test_strip_falls_back_when_a_row_is_too_dense(strips_everywhere):

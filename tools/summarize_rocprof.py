@@ -2,6 +2,7 @@
 
   python tools/summarize_rocprof.py stats  <kernel_stats.csv>            > profiles/rNN_<what>_kernel_stats.csv
   python tools/summarize_rocprof.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/rNN_pmc.json
+  python tools/summarize_rocprof.py db-stats <results.db>   /   db-pmc <fetch_results.db> <write_results.db>   (rocpd SQLite output)
 
 PMC units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are in KiB; FETCH_SIZE reports one half of the bytes of a coalesced streaming read on gfx950, so it is
@@ -45,5 +46,38 @@ def pmc(fetch_path, write_path):
     print(json.dumps({"correction": "FETCH_SIZE x2 (gfx950, coalesced streaming reads), KiB -> bytes x1024", "kernels": keep}, indent=1))
 
 
+def db_stats(path):
+    """rocprofv3's default output is a rocpd SQLite file; `top_kernels` is its --stats summary (durations in ns)."""
+    import sqlite3
+
+    w = csv.writer(sys.stdout)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+    cur = sqlite3.connect(path).cursor()
+    for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 25"):
+        w.writerow([short(name)[:90], calls, int(total), int(avg), round(pct, 3)])
+
+
+def db_pmc(fetch_path, write_path):
+    import sqlite3
+
+    out = collections.defaultdict(dict)
+    for path, counter in ((fetch_path, "FETCH_SIZE"), (write_path, "WRITE_SIZE")):
+        cur = sqlite3.connect(path).cursor()
+        agg = collections.defaultdict(list)
+        for name, value in cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            agg[short(name)].append(float(value))
+        for k, v in agg.items():
+            out[k][counter + "_KiB_mean_per_launch"] = sum(v) / len(v)
+            out[k][counter + "_launches"] = len(v)
+    res = {}
+    for k, d in out.items():
+        f = d.get("FETCH_SIZE_KiB_mean_per_launch", 0.0)
+        w = d.get("WRITE_SIZE_KiB_mean_per_launch", 0.0)
+        d["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
+        res[k] = d
+    keep = {k: v for k, v in res.items() if v["hbm_bytes_per_launch_corrected"] > 1e8}
+    print(json.dumps({"correction": "FETCH_SIZE x2 (gfx950, coalesced streaming reads), KiB -> bytes x1024", "kernels": keep}, indent=1))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "db-stats": db_stats, "db-pmc": db_pmc}[sys.argv[1]](*sys.argv[2:])
