@@ -103,6 +103,113 @@ __global__ __launch_bounds__(1024) void k_gs_sweep_one_block(i64 nlevels, const 
     }
 }
 
+// Single-workgroup sweep for systems with many narrow dependency levels (image grids: Potts 256^2 has 512
+// levels of ~900 rows).  One launch per level costs a kernel boundary plus three dependent memory hops
+// (row pointer -> entries -> x) per level; here a level costs one workgroup barrier and ONE hop on the
+// critical path: the x gather.  The other hops are taken ahead of time, one per step, into a register
+// ring: step s issues (1) the x gathers of step s, (2) the entry / right-hand side / bound loads of step
+// s + 1 from the lane-slot record that arrived a step earlier, (3) the slot record of step s + 2.  (A wave's
+// loads return in order, so a deeper ring would not hide more: the wait for step s + 1's gathers also waits
+// for everything issued before them.)  All loads are unconditional (idle lanes and short rows read harmless
+// addresses) so the loop is straight-line code.
+// A step is up to 1024 lane slots of one level.  A row takes ceil(len / kGsEntries) neighbouring lanes of
+// one wave; lane j gathers x for entries [j E, (j+1) E), then the row's single accumulator travels from
+// lane to lane (__shfl_up) in entry order: the same sequential, storage-order sum as in k_gs_level, bit for
+// bit, while no lane holds more than E entries.
+constexpr int kGsEntries = 4;  // entries of a row per lane
+constexpr int kGsMaxSeg = 16;  // lanes per row at most (longer rows: the per-level kernels are used instead)
+constexpr int kGsRing = 3;
+
+struct GsStep { int first, count, maxseg, barrier; };  // lane slots [first, first + count), chain rounds, barrier after the step
+// lane slot: row id, row position in level order, seg | lanes << 8 | entries of this lane << 16 | idle << 24
+struct alignas(16) GsSlot { i32 row; i32 t; int info; int pad; };
+// the lane's entries, stored per lane slot so that a step streams them with three 16-byte loads per lane
+struct alignas(16) GsEnt { i32 idx[kGsEntries]; double val[kGsEntries]; };
+// per row position, packed before every sweep (k_gs_pack): right-hand side, bounds and the row's own x
+struct alignas(16) GsRow { double b, lo, hi, xi; };
+
+template <bool BOUNDED>
+__global__ void k_gs_pack(i64 n, const i32 *__restrict__ rows, const double *__restrict__ b, const double *__restrict__ lo,
+                          const double *__restrict__ hi, const double *__restrict__ x, GsRow *__restrict__ out) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i32 i = rows[t];
+        GsRow r;
+        r.b = b[i];
+        r.lo = BOUNDED ? lo[i] : lo[t];  // unbounded: the level-ordered diagonal
+        r.hi = BOUNDED ? hi[i] : 0.0;
+        r.xi = x[i];                      // only the row's own update writes x[i]
+        out[t] = r;
+    }
+}
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(1024) void k_gs_sweep_pipelined(int nsteps, const GsStep *__restrict__ steps, const GsSlot *__restrict__ slots,
+                                                             const GsEnt *__restrict__ ents, const double *__restrict__ invd,
+                                                             const GsRow *__restrict__ packed, double *__restrict__ x, double w) {
+    struct Stage {
+        GsSlot sl;
+        int live;  // kept apart from the loaded record: touching `sl` right after its load would wait for it
+        GsEnt en;
+        GsRow rw;
+        double invd;
+    };
+    Stage st[kGsRing];
+    const int tid = threadIdx.x;
+    auto load_slot = [&](Stage &g, int s) {  // hop 1: slot record and (addressed by the slot index) the lane's entries
+        const int sc = s < nsteps ? s : nsteps - 1;  // past the end: a harmless reload, marked dead
+        const GsStep sd = steps[sc];
+        g.live = (s < nsteps && tid < sd.count) ? 1 : 0;
+        const i64 i = (i64)sd.first + (tid < sd.count ? tid : 0);
+        g.sl = slots[i];
+        g.en = ents[i];
+    };
+    auto load_data = [&](Stage &g) {  // hop 2: addressed by the row position
+        g.rw = packed[g.sl.t];
+        g.invd = invd[g.sl.t];
+    };
+    auto process = [&](const Stage &g, int s, Stage &g2, Stage &g3) {
+        const GsStep sd = steps[s];
+        double xg[kGsEntries];
+#pragma unroll
+        for (int e = 0; e < kGsEntries; ++e) xg[e] = __hip_atomic_load(&x[g.en.idx[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        load_data(g2);            // step s + 1
+        load_slot(g3, s + 2);     // step s + 2
+        const int seg = (!g.live || (g.sl.info >> 24)) ? -1 : (g.sl.info & 0xff);
+        const int nlane = (g.sl.info >> 8) & 0xff, len = (g.sl.info >> 16) & 0xff;
+        double v = 0.0, carry = 0.0;
+        for (int r = 0; r < sd.maxseg; ++r) {
+            if (seg == r) {
+                v = carry;
+#pragma unroll
+                for (int e = 0; e < kGsEntries; ++e)
+                    if (e < len) v += xg[e] * g.en.val[e];
+            }
+            const double up = __shfl_up(v, 1);
+            if (seg == r + 1) carry = up;
+        }
+        if (seg >= 0 && seg == nlane - 1) {
+            if (BOUNDED) {
+                v = w * (g.rw.b - v) * g.invd + g.rw.xi;
+                if (v < g.rw.lo) v = g.rw.lo;
+                else if (v > g.rw.hi) v = g.rw.hi;
+            } else {
+                const double nv = (g.rw.b - v + g.rw.lo * g.rw.xi) * g.invd;
+                v = w * nv + (1 - w) * g.rw.xi;
+            }
+            x[g.sl.row] = v;
+        }
+        if (sd.barrier) __syncthreads();  // last step of a level: the next level reads these x
+    };
+    load_slot(st[0], 0);
+    load_slot(st[1], 1);
+    load_data(st[0]);
+    for (int s = 0; s < nsteps; s += kGsRing) {
+#pragma unroll
+        for (int j = 0; j < kGsRing; ++j)
+            if (s + j < nsteps) process(st[j], s + j, st[(j + 1) % kGsRing], st[(j + 2) % kGsRing]);
+    }
+}
+
 __global__ void k_invert_diag(i64 n, const i32 *__restrict__ rows, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
                               const double *__restrict__ val, double *__restrict__ invd, double *__restrict__ diag) {
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
@@ -124,6 +231,13 @@ struct GsPlan {
     DevBuf<i64> lptr_dev;    // level pointer on the device (single-workgroup path)
     std::vector<i64> lptr;   // level pointer on the host (launch sizes)
     bool one_block = false;
+    bool pipelined = false;  // runs of narrow levels go through the single-workgroup kernel with the register ring
+    struct Segment { bool launch; i64 first, count; };  // launch: level `first` with k_gs_level; else steps [first, first + count)
+    std::vector<Segment> segments;
+    DevBuf<GsStep> steps;
+    DevBuf<GsSlot> slots;
+    DevBuf<GsEnt> ents;               // per lane slot
+    mutable DevBuf<GsRow> packed;     // per row position, refreshed before every sweep
 };
 
 static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, const double *data) {
@@ -164,8 +278,8 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
     }
     {   // permute the matrix into level order on the host (one O(nnz) pass)
         std::vector<i64> p2((size_t)n + 1, 0);
-        std::vector<i32> j2((size_t)g.nnz);
-        std::vector<double> v2((size_t)g.nnz);
+        std::vector<i32> j2((size_t)g.nnz + kGsEntries, 0);   // padded: the pipelined sweep reads kGsEntries per lane unconditionally
+        std::vector<double> v2((size_t)g.nnz + kGsEntries, 0.0);
         i64 o = 0;
         for (i64 t = 0; t < n; ++t) {
             const i64 i = rows[(size_t)t];
@@ -177,8 +291,8 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         }
         p2[(size_t)n] = o;
         g.ptr.upload(p2.data(), (size_t)n + 1);
-        g.idx.upload(j2.data(), (size_t)g.nnz);
-        g.val.upload(v2.data(), (size_t)g.nnz);
+        g.idx.upload(j2.data(), j2.size());
+        g.val.upload(v2.data(), v2.size());
     }
     g.rows.upload(rows.data(), (size_t)n);
     g.lptr_dev.upload(g.lptr.data(), g.lptr.size());
@@ -191,6 +305,89 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
     }
     // a single workgroup wins while the per-level launch cost (>= ~1.5 us) exceeds the work of a level
     g.one_block = (g.max_width <= 2048) && (g.nnz <= 200000);
+    // Runs of narrow levels: one CU with a barrier per level beats a launch per level (~5.6 us each).  Wide levels
+    // (Potts: the first level holds a third of the unknowns) and levels with a very long row keep the per-level
+    // kernel, which spreads over the chip.  The sweep is then a sequence of segments.
+    // SLP_GS_PIPELINED=0/1 overrides the choice (tests, timing): 1 = every level through the single-workgroup kernel.
+    const char *ep = getenv("SLP_GS_PIPELINED");
+    const bool forced = ep && ep[0] == '1';
+    const i64 wide = forced ? ((i64)1 << 40) : 4096;
+    g.pipelined = false;
+    if (n > 0 && g.nnz < ((i64)1 << 31) && !(ep && ep[0] == '0') && (forced || !g.one_block)) {
+        std::vector<GsStep> st;
+        std::vector<GsSlot> slots;
+        std::vector<GsPlan::Segment> segs;
+        std::vector<GsEnt> ents;
+        const GsSlot idle = {0, 0, 1 << 24, 0};
+        GsEnt noent;
+        for (int e = 0; e < kGsEntries; ++e) { noent.idx[e] = 0; noent.val[e] = 0.0; }
+        std::vector<i64> kpos((size_t)n + 1, 0);  // level-ordered entry offset of every row position
+        for (i64 t = 0; t < n; ++t) kpos[(size_t)t + 1] = kpos[(size_t)t] + (indptr[rows[(size_t)t] + 1] - indptr[rows[(size_t)t]]);
+        i64 narrow_levels = 0;
+        for (i64 l = 0; l < g.nlevels; ++l) {
+            const i64 beg = g.lptr[(size_t)l], end = g.lptr[(size_t)l + 1];
+            bool launch = end - beg > wide;
+            for (i64 t = beg; t < end && !launch; ++t)
+                if (kpos[(size_t)t + 1] - kpos[(size_t)t] > (i64)kGsMaxSeg * kGsEntries) launch = true;  // a very long row
+            if (launch) {
+                GsPlan::Segment sg;
+                sg.launch = true; sg.first = l; sg.count = 1;
+                segs.push_back(sg);
+                continue;
+            }
+            ++narrow_levels;
+            const size_t step0 = st.size();
+            size_t first = slots.size();
+            int maxseg = 1;
+            auto close_step = [&](bool barrier) {
+                GsStep sd;
+                sd.first = (int)first; sd.count = (int)(slots.size() - first); sd.maxseg = maxseg; sd.barrier = barrier ? 1 : 0;
+                st.push_back(sd);
+                first = slots.size();
+                maxseg = 1;
+            };
+            for (i64 t = beg; t < end; ++t) {
+                const i64 len = kpos[(size_t)t + 1] - kpos[(size_t)t];
+                const int nl = (int)std::max<i64>(1, (len + kGsEntries - 1) / kGsEntries);
+                size_t used = slots.size() - first;
+                if ((used & 63) + (size_t)nl > 64) {  // a row's lanes stay inside one wave
+                    while ((slots.size() - first) & 63) { slots.push_back(idle); ents.push_back(noent); }
+                    used = slots.size() - first;
+                }
+                if (used + (size_t)nl > 1024) close_step(false);  // next step of the same level: no barrier in between
+                for (int j = 0; j < nl; ++j) {
+                    const i64 left = len - (i64)j * kGsEntries;
+                    const int cnt = (int)std::max<i64>(0, std::min<i64>(kGsEntries, left));
+                    GsSlot sl;
+                    sl.row = rows[(size_t)t]; sl.t = (i32)t; sl.pad = 0;
+                    sl.info = j | (nl << 8) | (cnt << 16);
+                    slots.push_back(sl);
+                    GsEnt en = noent;
+                    const i64 src = indptr[rows[(size_t)t]] + (i64)j * kGsEntries;  // the row's entries in storage order
+                    for (int e = 0; e < cnt; ++e) { en.idx[e] = indices[src + e]; en.val[e] = data[src + e]; }
+                    ents.push_back(en);
+                }
+                maxseg = std::max(maxseg, nl);
+            }
+            close_step(true);
+            if (!segs.empty() && !segs.back().launch) {
+                segs.back().count += (i64)(st.size() - step0);
+            } else {
+                GsPlan::Segment sg;
+                sg.launch = false; sg.first = (i64)step0; sg.count = (i64)(st.size() - step0);
+                segs.push_back(sg);
+            }
+        }
+        if ((forced || narrow_levels >= 16) && !st.empty() && slots.size() < ((size_t)1 << 31)) {
+            g.pipelined = true;
+            g.one_block = false;
+            g.steps.upload(st.data(), st.size());
+            g.slots.upload(slots.data(), slots.size());
+            g.ents.upload(ents.data(), ents.size());
+            g.packed.alloc((size_t)n);
+            g.segments = segs;
+        }
+    }
 }
 
 // bounded = false: plain SOR sweep (no bounds); the kernels then read the diagonal through the `lo` argument
@@ -210,16 +407,40 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
         SLP_HIP(hipGetLastError());
         return;
     }
-    for (int s = 0; s < sweeps; ++s)
-        for (i64 l = 0; l < g.nlevels; ++l) {
-            const i64 beg = g.lptr[(size_t)l], cnt = g.lptr[(size_t)l + 1] - beg;
+    auto level_launch = [&](i64 l) {
+        const i64 beg = g.lptr[(size_t)l], cnt = g.lptr[(size_t)l + 1] - beg;
+        if (cnt <= 0) return;
+        if (bounded)
+            hipLaunchKernelGGL(k_gs_level<true>, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, beg, cnt,
+                               g.rows.p, g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
+        else
+            hipLaunchKernelGGL(k_gs_level<false>, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, beg, cnt,
+                               g.rows.p, g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
+    };
+    if (g.pipelined) {
+        for (int s = 0; s < sweeps; ++s) {
+            // right-hand side, bounds and own x of every row, in level order (x[row] only changes in the row's own step)
             if (bounded)
-                hipLaunchKernelGGL(k_gs_level<true>, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, beg, cnt,
-                                   g.rows.p, g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
+                hipLaunchKernelGGL(k_gs_pack<true>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.packed.p);
             else
-                hipLaunchKernelGGL(k_gs_level<false>, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, beg, cnt,
-                                   g.rows.p, g.ptr.p, g.idx.p, g.val.p, g.invd.p, b, lo, hi, x, w);
+                hipLaunchKernelGGL(k_gs_pack<false>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.packed.p);
+            for (const GsPlan::Segment &sg : g.segments) {
+                if (sg.launch) {
+                    level_launch(sg.first);
+                } else if (bounded) {
+                    hipLaunchKernelGGL(k_gs_sweep_pipelined<true>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
+                                       g.slots.p, g.ents.p, g.invd.p, g.packed.p, x, w);
+                } else {
+                    hipLaunchKernelGGL(k_gs_sweep_pipelined<false>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
+                                       g.slots.p, g.ents.p, g.invd.p, g.packed.p, x, w);
+                }
+            }
         }
+        SLP_HIP(hipGetLastError());
+        return;
+    }
+    for (int s = 0; s < sweeps; ++s)
+        for (i64 l = 0; l < g.nlevels; ++l) level_launch(l);
     SLP_HIP(hipGetLastError());
 }
 
@@ -512,7 +733,7 @@ int slp_admm_iterate(slp_admm *s, int64_t k) {
             --k;
         }
         // one launch per dependency level is launch-latency bound: replay the iteration as a captured graph
-        if (s->a->a.nnz <= 20000000) s->graph.run(k, s->plan.nlevels > 64 || s->plan.one_block ? 1 : 8, one);
+        if (s->a->a.nnz <= 20000000) s->graph.run(k, (s->plan.pipelined ? (i64)s->plan.segments.size() : s->plan.nlevels) > 64 || s->plan.one_block ? 1 : 8, one);
         else for (i64 it = 0; it < k; ++it) one();
     })
 }

@@ -1,0 +1,68 @@
+"""The single-workgroup, software-pipelined Gauss-Seidel sweep (k_gs_sweep_pipelined: register ring of
+prefetched rows, a row's accumulator handed from lane to lane) against the oracle's sequential sweep,
+bit for bit.  The library picks it for systems with many narrow dependency levels; SLP_GS_PIPELINED=1
+forces it here on every size.  -m gpu."""
+import numpy as np
+import pytest
+import scipy.sparse
+
+from conftest import Recorder, load_golden, solver_args
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["sc50a", "sc105", "potts8", "potts50", "random0", "random1", "random2"]
+
+
+@pytest.fixture()
+def pipelined(monkeypatch):
+    monkeypatch.setenv("SLP_GS_PIPELINED", "1")
+    yield
+    monkeypatch.delenv("SLP_GS_PIPELINED", raising=False)
+
+
+@pytest.mark.parametrize("n,density", [(1, 1.0), (700, 0.004), (700, 0.03), (700, 0.25), (5000, 0.0008), (40000, 0.00005), (3000, 0.4)])
+def test_sweep_random_against_oracle(pipelined, n, density):
+    """Rows of 1 ... 64 entries: one lane or up to 16 chained lanes (with longer rows -- the last two cases -- the library
+    keeps the per-level kernels); levels wider than 1024 lane slots (several steps per level); +-inf bounds; w != 1; two sweeps."""
+    from pysparselp_amd.gaussSiedel import boundedGaussSeidelClass
+
+    rng = np.random.RandomState(n)
+    b0 = scipy.sparse.random(n, n, density=density, random_state=rng, format="csr")
+    b0.data = rng.randn(b0.nnz)
+    m = (b0 + scipy.sparse.diags(np.abs(b0).sum(axis=1).A1 + 1.0)).tocsr()
+    rhs = rng.randn(n)
+    lo = np.where(rng.rand(n) < 0.3, -np.inf, -rng.rand(n))
+    hi = np.where(rng.rand(n) < 0.3, np.inf, rng.rand(n))
+    x0 = rng.randn(n)
+    xo = x0.copy()
+    oracle.BoundedGaussSeidel(m).solve(rhs, lo, hi, xo, maxiter=2, w=1.1)
+    xg = x0.copy()
+    boundedGaussSeidelClass(m).solve(rhs, lo, hi, xg, maxiter=2, w=1.1)
+    assert np.array_equal(xg, xo)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("xstep,key", [("gauss_seidel", "admm"), ("gauss_seidel_unbounded", "admmugs")])
+def test_admm_iterates_bit_exact(pipelined, case, xstep, key):
+    from pysparselp_amd._lib import ORDER_SEQUENTIAL
+    from pysparselp_amd.ADMM import lp_admm
+
+    d = load_golden("lp_" + case)
+    rec = Recorder(d[key + "_it"])
+    x = lp_admm(*solver_args(d), nb_iter=int(d[key + "_it"][-1]), callback_func=rec, nb_iter_plot=1, order=ORDER_SEQUENTIAL, xstep=xstep)
+    assert rec.it == list(d[key + "_it"])
+    assert np.array_equal(np.array(rec.x), d[key + "_x"])
+    assert np.array_equal(x, d[key + "_x"][-1])
+
+
+def test_potts_grid_takes_the_pipelined_sweep_by_default():
+    """Potts 96 x 96: ~190 levels of ~330 rows -- chosen without the override; 12 ADMM iterations against the oracle."""
+    from pysparselp_amd.ADMM import lp_admm
+    from pysparselp_amd.problems import potts_lp
+
+    lp = potts_lp(96)[0]
+    args = (lp.costsvector, None, None, lp.a_inequalities, lp.b_lower, lp.b_upper, lp.lower_bounds, lp.upper_bounds)
+    x = lp_admm(*args, nb_iter=12, nb_iter_plot=5)
+    xo = oracle.lp_admm(*args, nb_iter=12, nb_iter_plot=5)
+    assert np.array_equal(x, xo)
