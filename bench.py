@@ -162,7 +162,9 @@ def main():
         gbs_aty = b_aty / (ms_aty * 1e-3) / 1e9
         passes = solver.matrix_passes_per_iteration()
         which = lib.slp_matrix_spmv_kernel(a._h, 0)
-        kernel = {3: "k_qstrip_spmv<1> (LDS-tiled strip-JDS SpMV y = A x over the value-dictionary copy: 12-bit value id + "
+        kernel = {4: "k_wstrip_spmv<true, 1> (wide strips: x gathered from L2, value-dictionary entries; rank 0's row block)",
+                  5: "k_wstrip_spmv<false, 1> (wide strips: x gathered from L2, fp64 entries; rank 0's row block)",
+                  3: "k_qstrip_spmv<1> (LDS-tiled strip-JDS SpMV y = A x over the value-dictionary copy: 12-bit value id + "
                      "12-bit column per stored entry, lossless; rank 0's row block)",
                   2: "k_dstrip_spmv<1> (LDS-tiled strip-JDS SpMV y = A x over the value-dictionary copy: uint16 value id + "
                      "uint16 column per stored entry, lossless; rank 0's row block)",

@@ -70,7 +70,9 @@ int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, do
 /* Which kernel serves that orientation: 1 = LDS-tiled strip kernel (k_strip_spmv; long sorted rows,
  * >= 3e7 stored entries), 3 / 2 = the same over a value-dictionary copy (at most 2048 distinct stored values):
  * 3 = k_qstrip_spmv (4096-row blocks, 3-byte entries), 2 = k_dstrip_spmv (2048-row blocks, 4-byte entries;
- * SLP_DICT_VARIANT=1), 0 = row-per-lane-group CSR kernel (k_spmv), -1 = error. */
+ * SLP_DICT_VARIANT=1), 4 / 5 = wide strips (k_wstrip_spmv: strips of 131072 columns, x gathered from L2; rows too sparse
+ * for the LDS tile over a width far beyond an L2) with value-dictionary / fp64 entries,
+ * 0 = row-per-lane-group CSR kernel (k_spmv), -1 = error. */
 int slp_matrix_spmv_kernel(slp_matrix *a, int transposed);
 /* Bytes of the matrix copy that kernel reads per product (entries + per-strip metadata; CSR: 12 nnz + 8 (rows + 1)),
  * i.e. the matrix part of the HBM traffic one launch must generate; -1 = error. */

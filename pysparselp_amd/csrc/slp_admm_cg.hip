@@ -633,7 +633,7 @@ slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a_ineq, int64_t m_eq, const
             // the two row scalings as a vector.  Otherwise: rows scaled in place, twice; the transposed copy is
             // (re)built from the scaled values.
             bool deferred = false;
-            if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1)) && value_dictionary(a, a_ineq->vdict)) {
+            if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1) || strip_wanted(a, 3)) && value_dictionary(a, a_ineq->vdict)) {
                 build_transpose(a_ineq);
                 const StripJds *f0 = fast_format(a_ineq, false), *f1 = fast_format(a_ineq, true);
                 deferred = f0 && f1 && f0->D > 0 && f1->D > 0;

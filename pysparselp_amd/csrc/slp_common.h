@@ -186,6 +186,7 @@ struct StripJds {
     // uint16 column) = 4 B; pairs of entries are packed as {id0, id1, col0, col1}; the D values sit in LDS
     int C = 0;                    // columns per strip of this copy
     int D = 0;                    // 0: fp64 values in `val`; > 0: `ent` + `dict`
+    bool wide = false;            // strips of 131072 columns, x gathered from L2 instead of an LDS tile (32-bit columns)
     int rpl = 2;                  // sorted positions per lane: 2 (pairs, 2048-row blocks) or 4 (quads, 4096-row blocks)
     DevBuf<unsigned short> ent;   // [2 * nnz]
     const double *dict = nullptr; // [D] sorted distinct values (owned by the slp_matrix)
@@ -198,7 +199,7 @@ struct ValueDict {
     DevBuf<unsigned long long> keys;      // [D] order-preserving integer image of `values`
 };
 bool value_dictionary(const CsrDev &a, ValueDict &d);
-bool strip_wanted(const CsrDev &a, int variant);   // variant: 0 fp64 entries, 1 dictionary pairs, 2 dictionary quads
+bool strip_wanted(const CsrDev &a, int variant);   // variant: 0 fp64 entries, 1 dictionary pairs, 2 dictionary quads, 3 wide strips
 bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int variant);
 void strip_spmv(const StripJds &f, const double *x, double *out);
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1);  // one pass, two vectors

@@ -114,6 +114,8 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
         const bool dict = strip_wanted(a, variant) && value_dictionary(m->a, m->vdict);
         if (dict) strip_build(a, f, &m->vdict, variant);
         else if (strip_wanted(a, 0)) strip_build(a, f, nullptr, 0);
+        else if (strip_wanted(a, 3))  // long rows over a width far beyond an L2: wide strips, x gathered from L2
+            strip_build(a, f, value_dictionary(m->a, m->vdict) ? &m->vdict : nullptr, 3);
     }
     return f.ok ? &f : nullptr;
 }
@@ -323,7 +325,9 @@ int slp_matrix_spmv_kernel(slp_matrix *m, int transposed) {
     try {
         SLP_REQUIRE(m, "slp_matrix_spmv_kernel: NULL matrix");
         const StripJds *f = fast_format(m, transposed != 0);
-        return f ? (f->D > 0 ? (f->rpl == 4 ? 3 : 2) : 1) : 0;
+        if (!f) return 0;
+        if (f->wide) return f->D > 0 ? 4 : 5;
+        return f->D > 0 ? (f->rpl == 4 ? 3 : 2) : 1;
     } catch (const std::exception &e) {
         set_error(e.what());
         return -1;

@@ -44,6 +44,8 @@ constexpr unsigned long long kDictEmpty = ~0ull;
 constexpr int kQuadC = 3968;     // quad variant: 4 rows per lane (4096-row blocks), 31 KB of x, 12-bit column + 12-bit value id
 constexpr int kQuadR = 4 * 1024;
 constexpr int kQuadU1 = 4, kQuadU2 = 6;  // 12-byte quad loads in flight per lane (64 VGPRs at two workgroups per CU: 6 would spill)
+constexpr int kWideC = 131072;   // wide strips: 1 MB of x per strip, gathered from L2 (no LDS tile): rows too sparse for the LDS strips
+constexpr int kWideColShift = 11; // wide dictionary entry: value id in the low 11 bits, column inside the strip above
 constexpr int kDictU1 = 8, kDictU2 = 8;  // entry-pair loads in flight per lane (one / two right-hand sides)
 constexpr int kStripT = 1024;    // threads per workgroup
 constexpr int kStripR = 2048;    // rows per block (two per thread)
@@ -141,7 +143,9 @@ __global__ __launch_bounds__(kStripT) void k_strip_count(i64 nrow, i64 T, const 
 // {id(2p), id(2p+1), col(2p), col(2p+1)} of uint16 (pair index = entry index / 2) instead of oval / ocol
 // RPL == 4 (always with a dictionary): entries are 24-bit (id | column << 12), four of them -- sorted positions
 // 4p .. 4p+3 of one slot -- form a 12-byte quad; offsets and `base` still count entries.
-template <int C, int RPL>
+// WIDE (strips of kWideC columns, RPL == 2): 32-bit columns -- dictionary entries are one uint32 (id | column << 11) in
+// `oent`, fp64 entries keep `oval` and a uint32 column array in `ocol`.
+template <int C, int RPL, bool WIDE>
 __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
                                                         const double *__restrict__ val, const unsigned char *__restrict__ len,
                                                         const i64 *__restrict__ base, unsigned short *__restrict__ perm,
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
             slen[cell * R + pos] = (unsigned char)c[h];
             for (unsigned int s = 0; s < c[h]; ++s) {
                 const i64 o = bs + offs[s] + pos;
-                const unsigned short jc = (unsigned short)(idx[k[h] + s] - col0);
+                const unsigned int jw = (unsigned int)(idx[k[h] + s] - col0);
+                const unsigned short jc = (unsigned short)jw;
                 if (D > 0) {
                     const unsigned long long key = value_key((unsigned long long)__double_as_longlong(val[k[h] + s]));
                     int lo = 0, hi = D - 1;  // the value is in the dictionary: plain binary search
@@ -200,7 +205,9 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
                         if (skey[mid] < key) lo = mid + 1;
                         else hi = mid;
                     }
-                    if (RPL == 4) {
+                    if (WIDE) {
+                        reinterpret_cast<unsigned int *>(oent)[o] = (unsigned int)lo | (jw << kWideColShift);
+                    } else if (RPL == 4) {
                         const unsigned int e24 = (unsigned int)lo | ((unsigned int)jc << 12);
                         unsigned char *o8 = reinterpret_cast<unsigned char *>(oent) + o * 3;
                         o8[0] = (unsigned char)e24;
@@ -210,6 +217,9 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
                         oent[(o >> 1) * 4 + (o & 1)] = (unsigned short)lo;
                         oent[(o >> 1) * 4 + 2 + (o & 1)] = jc;
                     }
+                } else if (WIDE) {
+                    oval[o] = val[k[h] + s];
+                    reinterpret_cast<unsigned int *>(ocol)[o] = jw;
                 } else {
                     oval[o] = val[k[h] + s];
                     ocol[o] = jc;
@@ -611,6 +621,106 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nr
     }
 }
 
+// Wide strips: rows too sparse for the LDS tile (fewer than ~3 entries per 6 K columns) but long over the whole
+// width -- e.g. 250-1000 entries over 10^7 columns.  The plain CSR kernel then gathers x from a vector far larger
+// than an L2 (80 MB) and runs at the fabric's line rate (8-9 % of the HBM peak).  Here the matrix is cut into
+// strips of kWideC columns (1 MB of x): all workgroups walk the strips in the same order, so the strip of x they
+// gather from stays L2-resident, and inside a (row block, strip) cell the entries are stored as jagged diagonals
+// exactly like in the LDS strips (coalesced entry stream).  Row sums keep the sequential storage order.
+// DICT: 4-byte entries (value id | column << 11) + value table in LDS; else fp64 value + uint32 column.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <bool DICT>
+__global__ __launch_bounds__(kStripT, 8) void k_wstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
+                                                            const unsigned short *__restrict__ perm,
+                                                            const unsigned char *__restrict__ slen,
+                                                            const unsigned int *__restrict__ soff, const unsigned int *__restrict__ ent,
+                                                            const double *__restrict__ val, const unsigned int *__restrict__ col,
+                                                            const double *__restrict__ dict, int D, const double *__restrict__ x0,
+                                                            const double *__restrict__ x1, double *__restrict__ out0,
+                                                            double *__restrict__ out1) {
+    // one right-hand side per pass: two strips of x would compete for the L2 (a two-vector version measured 50 ms for the
+    // pair against 2 x 12.5 ms on the 2.5e6 x 1e7 slice)
+    constexpr int NV = 1;
+    __shared__ double acc[NV][kStripR];
+    __shared__ double dv[DICT ? kDictMax : 1];
+    const i64 b = blockIdx.x;
+    const int p = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { acc[v][p] = 0.0; acc[v][p + kStripT] = 0.0; }
+    if (DICT)
+        for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
+    constexpr int kU = DICT ? 6 : 4;  // entry pairs in flight per lane; each brings two gathers per right-hand side
+    const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
+    for (i64 t = t_begin; t < t_end; ++t) {
+        const i64 cell = b * T + t;
+        const double *__restrict__ xa = x0 + t * (i64)kWideC, *__restrict__ xb = x1 + t * (i64)kWideC;
+        const ushort2 r = reinterpret_cast<const ushort2 *>(perm + cell * kStripR)[p];
+        const uchar2 nn = reinterpret_cast<const uchar2 *>(slen + cell * kStripR)[p];
+        const unsigned int n0 = nn.x, n1 = nn.y;  // n0 >= n1 (sorted)
+        const i64 e0 = base[cell] >> 1;            // pair index of the cell's first entry
+        const uint2 *__restrict__ e2 = reinterpret_cast<const uint2 *>(DICT ? ent : col) + e0;
+        const double2 *__restrict__ v2 = reinterpret_cast<const double2 *>(val) + e0;
+        __syncthreads();  // the sums written in the previous strip (by other lanes: rows are re-sorted per cell)
+        double a0 = acc[0][r.x], a1 = acc[0][r.y], b0 = 0.0, b1 = 0.0;
+        if (NV == 2) { b0 = acc[NV - 1][r.x]; b1 = acc[NV - 1][r.y]; }
+        const unsigned int n0w = (unsigned int)__builtin_amdgcn_readfirstlane((int)n0);  // sorted: the wave's largest count
+        const unsigned int *__restrict__ so = soff + cell * kStripSL;
+        for (unsigned int s = 0; s < n0w; s += kU) {
+            uint2 q[kU];
+            double2 w[kU];
+            unsigned int of[kU];
+#pragma unroll
+            for (int i = 0; i < kU; ++i) of[i] = so[(s + i) & (kStripSL - 1)];
+#pragma unroll
+            for (int i = 0; i < kU; ++i) {
+                const unsigned int o = (s + i < n0) ? (of[i] >> 1) + p : p;  // masked slots read a harmless pair
+                // streamed once: non-temporal, so that the L2 keeps the strip of x
+                const u32x2 qq = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(e2) + o);
+                q[i] = make_uint2(qq.x, qq.y);
+                if (!DICT) {
+                    const f64x2 ww = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(v2) + o);
+                    w[i] = make_double2(ww.x, ww.y);
+                }
+            }
+            double g0[kU], g1[kU], h0[kU], h1[kU];
+#pragma unroll
+            for (int i = 0; i < kU; ++i) {  // the x gathers: L2 hits while the workgroups walk the strips together
+                const unsigned int ja = (s + i < n0) ? (DICT ? q[i].x >> kWideColShift : q[i].x) : 0u;
+                const unsigned int jb = (s + i < n1) ? (DICT ? q[i].y >> kWideColShift : q[i].y) : 0u;
+                g0[i] = xa[ja];
+                g1[i] = xa[jb];
+                if (NV == 2) { h0[i] = xb[ja]; h1[i] = xb[jb]; }
+            }
+#pragma unroll
+            for (int i = 0; i < kU; ++i) {
+                if (s + i < n0) {
+                    const double wa = DICT ? dv[q[i].x & ((1u << kWideColShift) - 1)] : w[i].x;
+                    a0 += wa * g0[i];
+                    if (NV == 2) b0 += wa * h0[i];
+                    if (s + i < n1) {
+                        const double wb = DICT ? dv[q[i].y & ((1u << kWideColShift) - 1)] : w[i].y;
+                        a1 += wb * g1[i];
+                        if (NV == 2) b1 += wb * h1[i];
+                    }
+                }
+            }
+        }
+        acc[0][r.x] = a0;
+        acc[0][r.y] = a1;
+        if (NV == 2) { acc[NV - 1][r.x] = b0; acc[NV - 1][r.y] = b1; }
+    }
+    __syncthreads();
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + p;
+        if (row < nrow) {
+            out0[(i64)blockIdx.y * nrow + row] = acc[0][h * kStripT + p];
+            if (NV == 2) out1[(i64)blockIdx.y * nrow + row] = acc[NV - 1][h * kStripT + p];
+        }
+    }
+}
+
 // out[row] = ((part[0][row] + part[1][row]) + ...) in strip order (deterministic)
 __global__ void k_strip_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
@@ -660,7 +770,7 @@ bool value_dictionary(const CsrDev &a, ValueDict &d) {
 // Builds the strip format of `a` (rows sorted by column).  Returns false (and leaves f.ok == false)
 // when the matrix does not qualify: unsorted rows, or a row with >= 256 entries inside one strip.
 // dict != NULL: the value-dictionary variant (narrower strips, 4-byte entries).
-template <int C, int RPL>
+template <int C, int RPL, bool WIDE = false>
 static bool strip_build_c(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     constexpr int kStripR = RPL * kStripT;  // rows per block of this variant
     hipStream_t st = ctx().stream;
@@ -702,12 +812,13 @@ static bool strip_build_c(const CsrDev &a, StripJds &f, const ValueDict *dict) {
         f.D = dict->D;
         f.dict = dict->values.p;
     } else {
-        f.val.alloc((size_t)padded);
-        f.col.alloc((size_t)padded);
+        f.val.alloc((size_t)padded + 2 * (size_t)kStripT);              // + one row of pairs for masked-off loads (wide kernel)
+        f.col.alloc((WIDE ? 2 : 1) * ((size_t)padded + 2 * (size_t)kStripT));  // wide: uint32 columns
         f.val.zero();
         f.col.zero();
     }
-    hipLaunchKernelGGL((k_strip_fill<C, RPL>), dim3((unsigned)B), dim3(kStripT), 0, st, a.nrow, T, a.ptr.p, a.idx.p, a.val.p, len.p,
+    f.wide = WIDE;
+    hipLaunchKernelGGL((k_strip_fill<C, RPL, WIDE>), dim3((unsigned)B), dim3(kStripT), 0, st, a.nrow, T, a.ptr.p, a.idx.p, a.val.p, len.p,
                        f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, f.D, dict ? dict->keys.p : nullptr, f.ent.p);
     SLP_HIP(hipGetLastError());
     SLP_HIP(hipStreamSynchronize(st));
@@ -725,8 +836,10 @@ static bool strip_build_c(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     return true;
 }
 
-// dict: 0 = fp64 entries, 1 = value dictionary with pairs of rows per lane, 2 = value dictionary, quads
+// variant: 0 = fp64 entries, 1 = value dictionary with pairs of rows per lane, 2 = value dictionary, quads,
+// 3 = wide strips (x gathered from L2; with or without a dictionary)
 bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int variant) {
+    if (variant == 3) return strip_build_c<kWideC, 2, true>(a, f, dict);
     if (!dict) return strip_build_c<kStripC, 2>(a, f, nullptr);
     return variant == 2 ? strip_build_c<kQuadC, 4>(a, f, dict) : strip_build_c<kDictC, 2>(a, f, dict);
 }
@@ -736,7 +849,27 @@ static int dstrip_cap() {
     return e ? atoi(e) : 255;
 }
 
+static void wide_launch(const StripJds &f, int nv, const double *x0, const double *x1, double *o0, double *o1) {
+    const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
+    hipStream_t st = ctx().stream;
+    const unsigned int *ent = reinterpret_cast<const unsigned int *>(f.ent.p), *col = reinterpret_cast<const unsigned int *>(f.col.p);
+#define SLP_WIDE(DICT)                                                                                                          \
+    hipLaunchKernelGGL((k_wstrip_spmv<DICT>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, ent, \
+                       f.val.p, col, f.dict, f.D, x0, x1, o0, o1)
+    (void)nv;
+    if (f.D > 0) SLP_WIDE(true);
+    else SLP_WIDE(false);
+#undef SLP_WIDE
+}
+
 void strip_spmv(const StripJds &f, const double *x, double *out) {
+    if (f.wide) {
+        wide_launch(f, 1, x, x, f.S > 1 ? f.part.p : out, nullptr);
+        if (f.S > 1)
+            hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
+        SLP_HIP(hipGetLastError());
+        return;
+    }
     if (f.D > 0) {
         if (f.rpl == 4)
             hipLaunchKernelGGL((k_qstrip_spmv<1>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
@@ -766,6 +899,12 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
 }
 
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1) {
+    if (f.wide) {
+        // two strips of x would compete for the L2: two passes
+        strip_spmv(f, x0, out0);
+        strip_spmv(f, x1, out1);
+        return;
+    }
     hipStream_t st = ctx().stream;
     double *o0 = out0, *o1 = out1;
     if (f.S > 1) {
@@ -795,8 +934,9 @@ bool strip_wanted(const CsrDev &a, int variant) {
     const char *e = getenv("SLP_STRIP_MIN_NNZ");  // below this size launch latency, not the gathers, dominates
     const i64 min_nnz = e ? atoll(e) : 30000000ll;  // measured cross-over vs the CSR kernel (tools/strip_threshold.py)
     if (a.nnz < min_nnz) return false;
-    const int C = variant == 2 ? kQuadC : (variant == 1 ? kDictC : kStripC);
+    const int C = variant == 3 ? kWideC : (variant == 2 ? kQuadC : (variant == 1 ? kDictC : kStripC));
     const double per_cell = a.mean_row_len() / (double)((a.ncol + C - 1) / C);
+    if (variant == 3) return a.ncol > 2 * (i64)kWideC && per_cell >= 2.0 && per_cell <= 160.0;  // x far larger than an L2
     return per_cell >= 3.0 && per_cell <= 64.0;
 }
 

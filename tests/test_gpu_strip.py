@@ -127,3 +127,37 @@ def test_strip_split_over_workgroups(strips_everywhere, monkeypatch, split):
     assert not np.array_equal(ax, ref) or split == "1"
     aty, ref = a.rmatvec(y), oracle.rmatvec(oracle.as_csr(s), y)
     assert np.max(np.abs(aty - ref)) <= 1e-13 * max(1e-300, np.max(np.abs(s).T.dot(np.abs(y))))
+
+
+@pytest.mark.parametrize("dict_on", ["1", "0"])
+def test_wide_strips_bit_exact(monkeypatch, dict_on):
+    """Rows too sparse for the LDS tile over a width far beyond an L2 (here 4 x 10^5 columns, ~40 entries per row): strips of
+    131072 columns with x gathered from L2 (k_wstrip_spmv), with the value dictionary (kernel code 4) and with fp64 entries (5)."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
+    monkeypatch.setenv("SLP_VALUE_DICT", dict_on)
+    n, m, p = 400000, 300000, 1e-4
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=2)
+    s = a.download()
+    oa = oracle.as_csr(s)
+    rng = np.random.RandomState(3)
+    x, y = rng.randn(n), rng.randn(m)
+    assert np.array_equal(a.matvec(x), oracle.matvec(oa, x))
+    assert np.array_equal(a.rmatvec(y), oracle.rmatvec(oa, y))
+    want = 4 if dict_on == "1" else 5
+    assert _kernel(a, 0) == want and _kernel(a, 1) == want
+    cp = DeviceCP(a, b, c, lb, ub)
+    cp.iterate(10)
+    xg = cp.x()
+    cp.close()
+    xo, _ = oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=10, nb_iter_plot=10 ** 9)
+    assert np.array_equal(xg, xo)
+    admm = DeviceADMM(a, b, c, lb, ub)   # two-vector passes of the wide kernel
+    admm.iterate(6)
+    xg = admm.x(n)
+    admm.close()
+    xo = oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=5, nb_iter_plot=10 ** 9)
+    assert np.max(np.abs(xg - xo) / (1 + np.abs(xo))) < 1e-9
