@@ -380,3 +380,32 @@ def test_admm_unbounded_gauss_seidel_graph_replay(case):
     last = int(d["admmugs_it"][-1])
     x = lp_admm(*solver_args(d), nb_iter=last, nb_iter_plot=7, order=_mods()[3], xstep="gauss_seidel_unbounded")
     assert np.array_equal(x, d["admmugs_x"][-1])
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "KB2", "SC50B"])
+def test_netlib_files_through_reader_and_solvers(name):
+    """The three netlib problems of the reference's data folder that have no iterate fixture: read with the MPS reader, built like
+    tests/test_netlib.py:19-48, solved with both methods -- iterates against the oracle, bit for bit."""
+    import os
+
+    from conftest import GOLDEN
+    from pysparselp_amd.netlib import get_problem
+    from pysparselp_amd.SparseLP import SparseLP
+
+    lp_admm, chambolle_pock_ppd, _, order, _ = _mods()
+    d = get_problem(name, data_dir=os.path.join(GOLDEN, "netlib"))
+    gt = d["solution"]
+    lp = SparseLP()
+    lp.add_variables_array(len(d["cost_vector"]), lower_bounds=d["lower_bounds"],
+                           upper_bounds=np.minimum(d["upper_bounds"], np.max(gt) * 2), costs=d["cost_vector"])
+    lp.add_equality_constraints_sparse(d["a_eq"], d["b_eq"])
+    lp.add_inequality_constraints_sparse(d["a_ineq"], d["b_lower"], d["b_upper"])
+    lp.convert_to_one_sided_inequality_system()
+    args = (lp.costsvector, lp.a_equalities, lp.b_equalities, lp.a_inequalities, lp.b_lower, lp.b_upper, lp.lower_bounds,
+            lp.upper_bounds)
+    x = lp_admm(*args, nb_iter=300, nb_iter_plot=100, order=order)
+    xo = oracle.lp_admm(*args, nb_iter=300, nb_iter_plot=100)
+    assert np.array_equal(x, xo)
+    x, _ = chambolle_pock_ppd(*args, nb_max_iter=300, nb_iter_plot=100, order=order)
+    xo, _ = oracle.chambolle_pock_ppd(*args, nb_max_iter=300, nb_iter_plot=100)
+    assert np.array_equal(x, xo)
