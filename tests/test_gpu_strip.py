@@ -161,3 +161,30 @@ def test_wide_strips_bit_exact(monkeypatch, dict_on):
     admm.close()
     xo = oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=5, nb_iter_plot=10 ** 9)
     assert np.max(np.abs(xg - xo) / (1 + np.abs(xo))) < 1e-9
+
+
+@pytest.mark.parametrize("ndistinct,want", [(1, 2), (2048, 2), (2049, 1)])
+def test_value_dictionary_size_limit(monkeypatch, ndistinct, want):
+    """At most 2048 distinct stored values go to the dictionary variant; one more and the fp64 strips take over.
+    NaN entries never use the dictionary (NaN != NaN would break the table lookup)."""
+    import scipy.sparse
+    from pysparselp_amd.device import DeviceMatrix
+
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
+    rng = np.random.RandomState(ndistinct)
+    a = scipy.sparse.random(2500, 24000, density=0.002, random_state=rng, format="csr")
+    a.sort_indices()
+    assert a.nnz > 3 * ndistinct
+    vals = np.linspace(-3.0, 3.0, ndistinct) if ndistinct > 1 else np.array([0.25])
+    a.data = np.concatenate([vals, rng.choice(vals, size=a.nnz - ndistinct)])  # every value occurs
+    x = rng.randn(24000)
+    dm = DeviceMatrix.from_csr(a)
+    assert np.array_equal(dm.matvec(x, 1), oracle.matvec(oracle.as_csr(a), x))
+    assert _kernel(dm) == want
+    if ndistinct == 1:
+        b = a.copy()
+        b.data[5] = np.nan
+        dm = DeviceMatrix.from_csr(b)
+        got, ref = dm.matvec(x, 1), oracle.matvec(oracle.as_csr(b), x)
+        assert _kernel(dm) == 1 and np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
