@@ -193,6 +193,12 @@ slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, co
 slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a, int64_t m_eq, const double *b, const double *c,
                                          const double *lb, const double *ub, double gamma_eq,
                                          double gamma_ineq, int order);
+/* The same with two-sided inequality rows  b_lower_i <= a_i x <= b_upper_i  (b_lower may be NULL = all -inf; entries of
+ * the m_eq equality rows are ignored): b_lower is scaled with its row like b_upper (tools.py:286-288) and becomes the
+ * lower bound of the row's slack variable (tools.py:117-121). */
+slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a, int64_t m_eq, const double *b_lower, const double *b_upper,
+                                             const double *c, const double *lb, const double *ub, double gamma_eq,
+                                             double gamma_ineq, int order);
 void slp_admm_cg_destroy(slp_admm_cg *s);
 /* Products of A per iteration (same mathematics, fp64 rounding differences only); default 0:
  * 0  ten, as the reference writes the iteration;

@@ -72,16 +72,18 @@ class DeviceADMM(_CGBase):
     ``a_i x <= b_i``.  Setup transforms run on the device and scale the matrix IN PLACE (the DeviceMatrix then
     holds the row-normalised values)."""
 
-    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO, reuse=2, m_eq=0):
+    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO, reuse=2, m_eq=0, b_lower=None):
         self._l = _lib.lib()
         self.a = a
         self.n = a.shape[1]
         self.N = a.shape[1] + a.shape[0]
         self.c = _lib.f64(c)
         b_upper, lb, ub = _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
-        self._h = _lib.check_handle(self._l.slp_admm_cg_create_on_mixed(
-            a._h, int(m_eq), _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb), _lib.ptr(ub), float(gamma_eq), float(gamma_ineq),
-            int(order)))
+        b_lower = None if b_lower is None else _lib.f64(b_lower)  # two-sided rows b_lower <= a_i x <= b_upper
+        assert b_lower is None or b_lower.size == b_upper.size
+        self._h = _lib.check_handle(self._l.slp_admm_cg_create_on_two_sided(
+            a._h, int(m_eq), None if b_lower is None else _lib.ptr(b_lower), _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
+            _lib.ptr(ub), float(gamma_eq), float(gamma_ineq), int(order)))
         self.set_reuse(reuse)
 
     def objective(self):

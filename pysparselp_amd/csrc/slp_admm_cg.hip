@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_report_final(int nr, const double
 // upper bound bu_i on their slack variable.
 template <int L>
 __global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, i64 m_eq, const i64 *__restrict__ ptr, double *__restrict__ val, int pass,
-                                                          double *__restrict__ bu, double *__restrict__ sc) {
+                                                          double *__restrict__ bu, double *__restrict__ sc, double *__restrict__ bl) {
     const int sub = threadIdx.x & (L - 1);
     const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
     const i64 ngroups = (i64)gridDim.x * kBlock / L;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, i64 m_eq, const
         const double inv = 1.0 / nrm;
         for (i64 k = s + sub; k < e; k += L) val[k] = inv * val[k];
         if (sub == 0) {
-            if (pass == 1) bu[i] = inv * bu[i];
+            if (pass == 1) { bu[i] = inv * bu[i]; if (bl && i >= m_eq) bl[i] = inv * bl[i]; }  // b_lower is scaled like b_upper (tools.py:286-288)
             else if (i >= m_eq) sc[i] = inv * -1.0;
             else { sc[i] = 0.0; bu[i] = inv * bu[i]; }
         }
@@ -285,7 +285,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, i64 m_eq, const
 // sum of (rs_i * a_ij) terms only.
 template <int L>
 __global__ __launch_bounds__(kBlock) void k_cg_row_scales(i64 m, i64 m_eq, const i64 *__restrict__ ptr, const double *__restrict__ val,
-                                                          double *__restrict__ bu, double *__restrict__ sc, double *__restrict__ rs) {
+                                                          double *__restrict__ bu, double *__restrict__ sc, double *__restrict__ rs,
+                                                          double *__restrict__ bl) {
     const int sub = threadIdx.x & (L - 1);
     const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
     const i64 ngroups = (i64)gridDim.x * kBlock / L;
@@ -309,19 +310,19 @@ __global__ __launch_bounds__(kBlock) void k_cg_row_scales(i64 m, i64 m_eq, const
         const double inv2 = 1.0 / nrm;
         if (sub == 0) {
             rs[i] = inv2 * inv1;
-            if (i >= m_eq) { sc[i] = inv2 * -1.0; bu[i] = inv1 * bu[i]; }
+            if (i >= m_eq) { sc[i] = inv2 * -1.0; bu[i] = inv1 * bu[i]; if (bl) bl[i] = inv1 * bl[i]; }
             else { sc[i] = 0.0; bu[i] = inv2 * (inv1 * bu[i]); }
         }
     }
 }
 
-// after the two scaling passes: rhs_i = b_eq'' (equalities) or 0; slack bounds [0,0] (equalities) or [-inf, bu']
-__global__ void k_cg_split_rows(i64 m, i64 m_eq, const double *__restrict__ bu, double *__restrict__ rhs, double *__restrict__ slo,
-                                double *__restrict__ shi) {
+// after the two scaling passes: rhs_i = b_eq'' (equalities) or 0; slack bounds [0,0] (equalities) or [bl' (default -inf), bu']
+__global__ void k_cg_split_rows(i64 m, i64 m_eq, const double *__restrict__ bu, const double *__restrict__ bl, double *__restrict__ rhs,
+                                double *__restrict__ slo, double *__restrict__ shi) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
         const bool eq = i < m_eq;
         rhs[i] = eq ? bu[i] : 0.0;
-        slo[i] = eq ? 0.0 : -__builtin_inf();
+        slo[i] = eq ? 0.0 : (bl ? bl[i] : -__builtin_inf());
         shi[i] = eq ? 0.0 : bu[i];
     }
 }
@@ -614,6 +615,12 @@ slp_admm_cg *slp_admm_cg_create_on(slp_matrix *a_ineq, const double *b_upper, co
 
 slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a_ineq, int64_t m_eq, const double *b_upper, const double *c, const double *lb,
                                          const double *ub, double gamma_eq, double gamma_ineq, int order) {
+    return slp_admm_cg_create_on_two_sided(a_ineq, m_eq, nullptr, b_upper, c, lb, ub, gamma_eq, gamma_ineq, order);
+}
+
+slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, const double *b_lower, const double *b_upper,
+                                             const double *c, const double *lb, const double *ub, double gamma_eq, double gamma_ineq,
+                                             int order) {
     SLP_API_PTR({
         SLP_REQUIRE(a_ineq && b_upper && c && lb && ub, "slp_admm_cg_create_on: NULL argument");
         SLP_REQUIRE(m_eq >= 0 && m_eq <= a_ineq->a.nrow, "slp_admm_cg_create_on_mixed: m_eq out of range");
@@ -628,6 +635,8 @@ slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a_ineq, int64_t m_eq, const
             s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
             DevBuf<double> bu((size_t)m);
             bu.upload(b_upper, (size_t)m);
+            DevBuf<double> bl;  // optional lower bounds of the inequality rows (entries of equality rows are ignored)
+            if (b_lower) bl.upload(b_lower, (size_t)m);
             s->sc.alloc((size_t)m);
             // Few distinct stored values and long rows: keep the matrix as it is (value-dictionary strips) and carry
             // the two row scalings as a vector.  Otherwise: rows scaled in place, twice; the transposed copy is
@@ -642,14 +651,14 @@ slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a_ineq, int64_t m_eq, const
                 s->rs.alloc((size_t)m);
                 const int lanes = lanes_for(a, SLP_ORDER_TREE);
                 SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_row_scales<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0, st,
-                                                             m, (i64)m_eq, a.ptr.p, a.val.p, bu.p, s->sc.p, s->rs.p));
+                                                             m, (i64)m_eq, a.ptr.p, a.val.p, bu.p, s->sc.p, s->rs.p, bl.p));
                 SLP_HIP(hipGetLastError());
             } else if (m) {
                 invalidate_derived(a_ineq);
                 const int lanes = lanes_for(a, SLP_ORDER_TREE);
                 for (int pass = 1; pass <= 2; ++pass) {
                     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_scale_rows<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0,
-                                                                 st, m, (i64)m_eq, a.ptr.p, a.val.p, pass, bu.p, s->sc.p));
+                                                                 st, m, (i64)m_eq, a.ptr.p, a.val.p, pass, bu.p, s->sc.p, bl.p));
                     SLP_HIP(hipGetLastError());
                 }
             }
@@ -662,7 +671,7 @@ slp_admm_cg *slp_admm_cg_create_on_mixed(slp_matrix *a_ineq, int64_t m_eq, const
             SLP_HIP(hipMemcpyAsync(s->lb.p, lb, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
             SLP_HIP(hipMemcpyAsync(s->ub.p, ub, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
             if (m) {
-                hipLaunchKernelGGL(k_cg_split_rows, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, st, m, (i64)m_eq, bu.p, s->b.p, s->lb.p + n,
+                hipLaunchKernelGGL(k_cg_split_rows, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, st, m, (i64)m_eq, bu.p, bl.p, s->b.p, s->lb.p + n,
                                    s->ub.p + n);
                 SLP_HIP(hipGetLastError());
             }

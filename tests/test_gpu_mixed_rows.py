@@ -43,3 +43,32 @@ def test_mixed_rows_match_oracle(monkeypatch, min_nnz):
         assert abs(c.dot(x) - c.dot(xo)) <= 1e-6 * abs(c.dot(xo))
         assert np.all(np.isfinite(rep[:3]))
     a.close()
+
+
+@pytest.mark.parametrize("min_nnz", ["1", "100000000000"])  # (value-dictionary) strip kernels with the row-scale vector / CSR kernels, scaled in place
+def test_two_sided_rows_admm_match_oracle(monkeypatch, min_nnz):
+    """b_lower <= A x <= b_upper on the at-scale ADMM: the lower bounds are scaled with their rows and bound the slack variables
+    from below (tools.py:117-121,286-288); a third of the rows keep b_lower = -inf, some are equalities."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.problems import random_lp_on_device
+
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", min_nnz)
+    n, m, p, m_eq = 30000, 40000, 0.001, 3000
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=11)
+    s = a.download()
+    ax = a.matvec(xf)
+    rng = np.random.RandomState(4)
+    b = b.copy()
+    b[:m_eq] = ax[:m_eq]
+    bl = np.where(rng.rand(m) < 0.33, -np.inf, ax - rng.rand(m))  # feasible: b_lower <= A xf <= b_upper
+    ae, ai = s[:m_eq], s[m_eq:]
+    admm = DeviceADMM(a, b, c, lb, ub, m_eq=m_eq, b_lower=bl)
+    admm.iterate(25)
+    x = admm.x(n)
+    slack = admm.x(n + m)[n + m_eq:]
+    admm.close()
+    a.close()
+    xo = oracle.lp_admm_cg(c, ae, b[:m_eq], ai, bl[m_eq:], b[m_eq:], lb, ub, nb_iter=24, nb_iter_plot=10 ** 9)
+    assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-9
+    assert abs(c.dot(x) - c.dot(xo)) <= 1e-6 * abs(c.dot(xo))
+    assert np.sum(np.isfinite(bl[m_eq:])) > 20000 and np.all(np.isfinite(slack))
