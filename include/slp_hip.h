@@ -215,6 +215,26 @@ int slp_admm_cg_multiplier_step(slp_admm_cg *s);
 int slp_admm_cg_report(slp_admm_cg *s, double out[3]);
 int slp_admm_cg_get_x(slp_admm_cg *s, double *x, int64_t count);
 
+/* ---- ADMM with one copy of the variables per constraint block ------------ *
+ * Replaces the loop of lp_admm_block_decomposition (ADMMBlocks.py:264-307) and its per-block sparse LU
+ * factorisations (:178-243): the per-block projections onto {A_g x = b_g} are computed matrix-free, all blocks
+ * together, by conjugate gradients on A^ A^T (A^ = the constraint matrix with one column per (block, variable)
+ * copy, m x P).  The host passes A^ in CSR, `owner[p]` = the variable a copy belongs to, and the copies of every
+ * variable in block order as a CSR list (copy_ptr[N+1], copy_idx[P]).  xp0 = the initial consensus variable
+ * (clamped to the bounds, :84-86).  Parity with the LU form is a tolerance (slp_blocks_set_cg: relative residual
+ * of the projection systems, default 1e-13, at most max_steps CG steps per iteration). */
+typedef struct slp_blocks slp_blocks;
+slp_blocks *slp_blocks_create(int64_t P, int64_t m, int64_t N, const int64_t *indptr, const int32_t *indices,
+                              const double *data, const double *b, const double *c, const double *lb, const double *ub,
+                              const double *xp0, const int32_t *owner, const int64_t *copy_ptr, const int32_t *copy_idx,
+                              double gamma);
+void slp_blocks_destroy(slp_blocks *s);
+int slp_blocks_set_cg(slp_blocks *s, double tol, int max_steps);
+int slp_blocks_iterate(slp_blocks *s, int64_t k);
+/* out[0] = the augmented-Lagrangian energy of ADMMBlocks.py:246-253, out[1] = CG steps taken so far. */
+int slp_blocks_report(slp_blocks *s, double out[2]);
+int slp_blocks_get_xp(slp_blocks *s, double *xp, int64_t count);
+
 /* ---- synthetic random LP on the device (randomLP.py:14-75) -------------- *
  * Row r of A_ineq (global row index row_offset + r): every entry is non-zero
  * with probability `density`, value round(N(0,1)*100)/100, exact zeros

@@ -582,3 +582,89 @@ def lp_admm_gs_unbounded(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None
         lambda_eq = lambda_eq + gamma_eq * (matvec(a, x) - b)
         i += 1
     return x[0:n]
+
+
+# ---------------------------------------------------------------------------------------------------
+# ADMM with one copy of the variables per block of constraints (ADMMBlocks.py:45-352).
+# The per-block equality-constrained least-squares problems are solved exactly with scipy's SuperLU
+# (scipy.sparse.linalg.splu), like in the reference (:224): third-party code, present on the GPU box.
+def _blocks_of(a, given):
+    if given is not None:
+        return [tuple(int(v) for v in b) for b in given]
+    return [tuple(int(v) for v in b) for b in getattr(a, "blocks", [])] if a is not None else []
+
+
+def standard_form_blocks(blocks_eq, blocks_ineq, m_eq):
+    """tools.py:104-111: the blocks of [A_eq 0; A_ineq -I] are those of A_eq followed by those of A_ineq shifted by the
+    number of equality rows."""
+    return list(blocks_eq) + [(lo + m_eq, hi + m_eq) for lo, hi in blocks_ineq]
+
+
+def lp_admm_block_decomposition(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_ineq=0.7, nb_iter=100,
+                                callback_func=None, max_time=None, use_preconditioning=True, use_lu=True, nb_iter_plot=10,
+                                blocks_eq=None, blocks_ineq=None):
+    """ADMMBlocks.py:45-352 (``blocks_*``: the (first_row, last_row) groups the modelling layer records, SparseLP.py:93-95;
+    read from the matrices' ``blocks`` attribute when not given).  ``max_time=None`` means no limit (the reference
+    compares ``elapsed > None``, :312, which raises in Python 3)."""
+    import time
+
+    import scipy.sparse
+    import scipy.sparse.linalg
+
+    blocks_eq, blocks_ineq = _blocks_of(a_eq, blocks_eq), _blocks_of(a_ineq, blocks_ineq)
+    n = np.asarray(c).size
+    if x0 is None:
+        x0 = np.zeros(n)
+    m_eq = 0 if a_eq is None else as_csr(a_eq).shape[0]
+    c, a, b, lb, ub, x0 = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)  # :79-81
+    blocks = standard_form_blocks(blocks_eq, blocks_ineq, m_eq)
+    a_sp = scipy.sparse.csr_matrix((a.data, a.indices, a.indptr), shape=a.shape)
+    xp = np.minimum(np.maximum(x0.copy(), lb), ub)  # :84-86
+    nb_used = np.zeros(x0.shape)
+    ids_of, lus, beqs = [], [], []
+    for lo, hi in blocks:  # :178-243, one group per block (:119)
+        id_rows = np.arange(lo, hi + 1)
+        sub_a = a_sp[id_rows, :]
+        t = np.array(np.abs(sub_a).sum(axis=0)).ravel()
+        ids = np.nonzero(t)[0]
+        ids_of.append(ids)
+        nb_used[ids] += 1
+        sub_a2 = sub_a[:, ids]
+        m = scipy.sparse.vstack((
+            scipy.sparse.hstack((gamma_ineq * scipy.sparse.eye(sub_a2.shape[1], sub_a2.shape[1]), sub_a2.T)),
+            scipy.sparse.hstack((sub_a2, scipy.sparse.csc_matrix((sub_a2.shape[0], sub_a2.shape[0])))),
+        )).tocsr()
+        lus.append(scipy.sparse.linalg.splu(m.tocsc()))
+        beqs.append(b[id_rows])
+    nb = len(blocks)
+    x = [x0[ids_of[k]] for k in range(nb)]
+    lam = [np.zeros(ids_of[k].shape) for k in range(nb)]
+    alpha = 1.95  # :262
+    start = time.perf_counter()
+    i = 0
+    while i <= nb_iter:
+        for k in range(nb):  # :268-284
+            y = np.hstack((gamma_ineq * xp[ids_of[k]] - lam[k], beqs[k]))
+            xv = lus[k].solve(y)
+            x[k] = alpha * xv[: x[k].shape[0]] + (1 - alpha) * xp[ids_of[k]]
+        xp[nb_used > 0] = 0  # :290-299
+        for k in range(nb):
+            xp[ids_of[k]] += x[k] + lam[k] / gamma_ineq
+        xp = xp - c / gamma_ineq
+        xp = xp / np.maximum(nb_used, 1)
+        xp = np.maximum(xp, lb)
+        xp = np.minimum(xp, ub)
+        for k in range(nb):  # :302-307
+            lam[k] = lam[k] + gamma_ineq * (x[k] - xp[ids_of[k]])
+        if i % nb_iter_plot == 0:  # :309-350
+            elapsed = time.perf_counter() - start
+            if max_time is not None and elapsed > max_time:
+                break
+            en = c.dot(xp)  # :246-253
+            for k in range(nb):
+                diff = x[k] - xp[ids_of[k]]
+                en += 0.5 * gamma_ineq * np.sum(diff ** 2) + lam[k].dot(diff)
+            if callback_func is not None:
+                callback_func(i, xp[0:n], en, en, elapsed, 0, 0)
+        i += 1
+    return xp[0:n]

@@ -10,8 +10,8 @@ first-order solvers need (reference SparseLP.py:162-1383): the LP is held as
 
 with scipy CSR matrices, and ``solve`` (reference :990-1002, :1064-1093,
 :1193-1208, :1243-1288, :1378-1383) runs one of the GPU solvers and fills the
-same convergence-curve attributes.  Only the two hot-path methods exist here:
-``"admm"`` and ``"chambolle_pock_ppd"``; the other solvers of the reference
+same convergence-curve attributes.  The hot-path methods ``"admm"`` and
+``"chambolle_pock_ppd"`` and the block-splitting ``"admm_blocks"`` exist here; the other solvers of the reference
 (interior point, dual ascent, external solver bridges, rounding heuristics,
 MPS export) are out of scope.
 """
@@ -26,7 +26,7 @@ from .ADMM import lp_admm
 from .ChambollePockPPD import chambolle_pock_ppd
 from ._lib import ORDER_AUTO
 
-solving_methods = ("chambolle_pock_ppd", "admm")
+solving_methods = ("chambolle_pock_ppd", "admm", "admm_blocks")
 
 _SCALARS = (int, float, np.integer, np.floating)
 
@@ -315,6 +315,12 @@ class SparseLP:
             x = lp_admm(self.costsvector, a_eq, b_eq, a_ineq, self.b_lower, self.b_upper, self.lower_bounds,
                         self.upper_bounds, nb_iter=nb_iter, x0=x0, callback_func=record, max_time=max_time,
                         nb_iter_plot=nb_iter_plot, order=order)
+        elif method == "admm_blocks":  # reference :1210-1225
+            from .ADMMBlocks import lp_admm_block_decomposition
+
+            x = lp_admm_block_decomposition(self.costsvector, a_eq, b_eq, a_ineq, self.b_lower, self.b_upper, self.lower_bounds,
+                                            self.upper_bounds, nb_iter=nb_iter, nb_iter_plot=nb_iter_plot, x0=x0,
+                                            callback_func=record, max_time=max_time)
         else:  # chambolle_pock_ppd: fixed variables are eliminated first (reference :1244-1248)
             reduced = copy.deepcopy(self)
             free, shift = reduced.remove_fixed_variables()

@@ -1,0 +1,105 @@
+"""Block-splitting ADMM (reference ADMMBlocks.py): the oracle against iterates of the reference
+(tests/golden/make_blocks_golden.py), the host-side copies layout, and -- on the GPU -- the matrix-free
+device solver against the same iterates."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+from conftest import GOLDEN, Recorder, load_golden, solver_args
+from oracle import oracle
+
+CASES = ["sc50a", "sc105", "potts8", "potts50", "random0", "random1"]
+
+
+def _blocks(case):
+    d = np.load(os.path.join(GOLDEN, "admm_blocks.npz"))
+    return d, [tuple(r) for r in d[f"{case}_blocks_eq"]], [tuple(r) for r in d[f"{case}_blocks_ineq"]]
+
+
+def _with_blocks(a, blocks):
+    if a is None:
+        return None
+    a = scipy.sparse.csr_matrix(a.tocsr() if hasattr(a, "tocsr") else a)
+    a.__dict__["blocks"] = list(blocks)
+    return a
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_reproduces_reference_iterates(case):
+    d, beq, bineq = _blocks(case)
+    args = solver_args(load_golden("lp_" + case))
+    rec = Recorder(d[f"{case}_it"])
+    oracle.lp_admm_block_decomposition(*args, nb_iter=200, nb_iter_plot=1, callback_func=rec, blocks_eq=beq, blocks_ineq=bineq)
+    assert rec.it == list(d[f"{case}_it"])
+    # bit-identical in the build container (same SuperLU); 1e-12 leaves room for another scipy build on the GPU box
+    for got, ref in zip(rec.x, d[f"{case}_x"]):
+        assert np.max(np.abs(got - ref) / (1 + np.abs(ref))) < 1e-12
+    np.testing.assert_allclose(rec.e1, d[f"{case}_e1"], rtol=1e-10, atol=1e-10)
+    assert float(d[f"{case}_oracle_vs_reference"]) == 0.0
+
+
+def test_copies_layout():
+    from pysparselp_amd.ADMMBlocks import split_by_blocks
+    from pysparselp_amd.tools import CsrArrays
+
+    rng = np.random.RandomState(0)
+    a = scipy.sparse.random(12, 9, density=0.35, random_state=rng, format="csr")
+    a.sort_indices()
+    a.data[3] = 0.0  # an explicit zero stays an entry unless its whole column is zero inside the block
+    blocks = [(0, 3), (4, 8), (9, 11)]
+    a_split, owner, cptr, cidx = split_by_blocks(CsrArrays.from_any(a), blocks)
+    dense, off = a.toarray(), 0
+    big = a_split.tocsr().toarray()
+    for lo, hi in blocks:
+        sub = dense[lo:hi + 1]
+        ids = np.nonzero(np.abs(sub).sum(axis=0))[0]
+        assert np.array_equal(owner[off:off + ids.size], ids)
+        assert np.array_equal(big[lo:hi + 1, off:off + ids.size], sub[:, ids])
+        assert not big[lo:hi + 1, :off].any() and not big[lo:hi + 1, off + ids.size:].any()  # block diagonal
+        off += ids.size
+    assert a_split.shape == (12, off) and cptr[-1] == off
+    for j in range(9):
+        copies = cidx[cptr[j]:cptr[j + 1]]
+        assert np.all(owner[copies] == j) and np.all(np.diff(copies) > 0)
+    with pytest.raises(ValueError):
+        split_by_blocks(CsrArrays.from_any(a), [(0, 3), (3, 11)])
+    with pytest.raises(ValueError):
+        split_by_blocks(CsrArrays.from_any(a), [(0, 3)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_iterates_match_reference(case):
+    """Matrix-free per-block projections (conjugate gradients to 1e-13) against the reference's sparse-LU iterates."""
+    from pysparselp_amd.ADMMBlocks import lp_admm_block_decomposition
+
+    d, beq, bineq = _blocks(case)
+    c, a_eq, be, a_ineq, bl, bu, lb, ub = solver_args(load_golden("lp_" + case))
+    rec = Recorder(d[f"{case}_it"])
+    x = lp_admm_block_decomposition(c, _with_blocks(a_eq, beq), be, _with_blocks(a_ineq, bineq), bl, bu, lb, ub, nb_iter=200,
+                                    nb_iter_plot=1, callback_func=rec)
+    assert rec.it == list(d[f"{case}_it"])
+    for got, ref in zip(rec.x, d[f"{case}_x"]):
+        assert np.max(np.abs(got - ref) / (1 + np.abs(ref))) < 1e-8
+    assert np.array_equal(x, rec.x[-1])
+    np.testing.assert_allclose(rec.e1, d[f"{case}_e1"], rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_reporting_cadence_and_solve_method():
+    """nb_iter_plot = 7: reports after iterations 0, 7, 14, ...; SparseLP.solve(method="admm_blocks") end to end."""
+    from pysparselp_amd.ADMMBlocks import lp_admm_block_decomposition
+    from pysparselp_amd.problems import potts_lp
+
+    d, beq, bineq = _blocks("potts8")
+    c, a_eq, be, a_ineq, bl, bu, lb, ub = solver_args(load_golden("lp_potts8"))
+    rec = Recorder()
+    lp_admm_block_decomposition(c, None, None, _with_blocks(a_ineq, bineq), bl, bu, lb, ub, nb_iter=20, nb_iter_plot=7, callback_func=rec)
+    assert rec.it == [0, 7, 14]
+    ref = {int(i): v for i, v in zip(d["potts8_it"], d["potts8_x"])}
+    assert np.max(np.abs(rec.x[0] - ref[0])) < 1e-9
+    lp, gt, gt_idx, _ = potts_lp(8)
+    x = lp.solve(method="admm_blocks", nb_iter=200, nb_iter_plot=50, ground_truth=gt, ground_truth_indices=gt_idx, get_timing=False)
+    assert np.max(np.abs(x - ref[200])) < 1e-7 and lp.itrn_curve == [0, 50, 100, 150, 200]
