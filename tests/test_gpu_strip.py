@@ -188,3 +188,16 @@ def test_value_dictionary_size_limit(monkeypatch, ndistinct, want):
         got, ref = dm.matvec(x, 1), oracle.matvec(oracle.as_csr(b), x)
         assert _kernel(dm) == 1 and np.array_equal(np.isnan(got), np.isnan(ref))
         assert np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
+def test_randomised_shapes_all_kernel_families():
+    """tools/fuzz_spmv.py: 120 random shapes around the block / strip boundaries, empty rows, both orientations, every
+    kernel family (CSR, fp64 strips, dictionary pairs and quads, wide strips) -- bit for bit against the oracle."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_spmv
+
+    seen = fuzz_spmv.run(120, seed=1)
+    assert all(seen.get(code, 0) > 0 for code in (0, 1, 2, 3, 4, 5)), seen
