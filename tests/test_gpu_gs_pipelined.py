@@ -66,3 +66,16 @@ def test_potts_grid_takes_the_pipelined_sweep_by_default():
     x = lp_admm(*args, nb_iter=12, nb_iter_plot=5)
     xo = oracle.lp_admm(*args, nb_iter=12, nb_iter_plot=5)
     assert np.array_equal(x, xo)
+
+
+def test_randomised_systems_all_sweep_variants():
+    """tools/fuzz_gs.py: banded, grid, random and wide-first-level systems; per-level launches, single-workgroup and pipelined
+    sweeps (forced and chosen); w in {0.7, 1, 1.1}; 1-3 sweeps; +-inf bounds -- bit for bit against the oracle."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gs
+
+    tally = fuzz_gs.run(30, seed=3)
+    assert sum(tally.values()) == 30
