@@ -69,7 +69,7 @@ def run(cases, seed, verbose=False):
         g = boundedGaussSeidelClass(m)
         g.solve(rhs, lo, hi, xg, maxiter=sweeps, w=w)
         if verbose:
-            print("case", case, kind, n, m.nnz, "levels", g.num_levels(), "pipelined", force, flush=True)
+            print("case", case, kind, n, m.nnz, "levels", g.num_levels, "pipelined", force, flush=True)
         tally[(kind, force)] = tally.get((kind, force), 0) + 1
         if not np.array_equal(xg, xo):
             raise AssertionError(f"Gauss-Seidel mismatch: case {case} {kind} n={n} nnz={m.nnz} pipelined={force} "
