@@ -45,7 +45,7 @@ def parse():
     p.add_argument("--m", type=int, default=2_000_000, help="inequality constraints")
     p.add_argument("--density", type=float, default=1e-3)
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--method", default="admm", choices=["admm", "chambolle_pock_ppd"])
+    p.add_argument("--method", default="admm", choices=["admm", "chambolle_pock_ppd", "admm_blocks"])
     p.add_argument("--eq-frac", type=float, default=0.0,
                    help="fraction of the constraint rows turned into equalities a_i x = a_i x_feasible (randomLP.py:62-68); "
                         "the default all-inequality LP is the primary workload")
@@ -78,6 +78,10 @@ def cpu_baseline(args, method):
     t0 = time.perf_counter()
     if method == "chambolle_pock_ppd":
         oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9)
+    elif method == "admm_blocks":  # one block = all rows; includes the sparse LU of its KKT matrix, like the reference
+        iters = 3
+        oracle.lp_admm_block_decomposition(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9,
+                                           blocks_eq=[], blocks_ineq=[(0, m - 1)])
     else:
         oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
     dt = time.perf_counter() - t0
@@ -136,6 +140,7 @@ def main():
 
     # ---- timed region: W warm-up steps, then exactly K steps between two barriers
     solver.iterate(args.warmup)
+    cg0 = solver.cg_steps() if args.method == "admm_blocks" else 0
     _lib.check(lib.slp_comm_barrier())
     t0 = time.perf_counter()
     solver.iterate(args.steps)
@@ -161,6 +166,8 @@ def main():
         gbs_ax = b_ax / (ms_ax * 1e-3) / 1e9
         gbs_aty = b_aty / (ms_aty * 1e-3) / 1e9
         passes = solver.matrix_passes_per_iteration()
+        if args.method == "admm_blocks":  # 3 products + 2 per conjugate-gradient step (rank 0's count)
+            passes = 3 + 2 * (solver.cg_steps() - cg0) / args.steps
         which = lib.slp_matrix_spmv_kernel(a._h, 0)
         kernel = {4: "k_wstrip_spmv<true, 1> (wide strips: x gathered from L2, value-dictionary entries; rank 0's row block)",
                   5: "k_wstrip_spmv<false, 1> (wide strips: x gathered from L2, fp64 entries; rank 0's row block)",
@@ -181,7 +188,7 @@ def main():
                 if k:
                     traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/" + pmc_name[0]
         out = {
-            "metric": f"{'admm' if args.method == 'admm' else 'chambolle_pock'}_iterations_per_sec",
+            "metric": {"admm": "admm", "admm_blocks": "admm_blocks", "chambolle_pock_ppd": "chambolle_pock"}[args.method] + "_iterations_per_sec",
             "value": args.steps / dt,
             "unit": "it/s",
             "n_gpus": world,

@@ -228,6 +228,13 @@ slp_blocks *slp_blocks_create(int64_t P, int64_t m, int64_t N, const int64_t *in
                               const double *data, const double *b, const double *c, const double *lb, const double *ub,
                               const double *xp0, const int32_t *owner, const int64_t *copy_ptr, const int32_t *copy_idx,
                               double gamma);
+/* One block per rank over a device-resident row block (at scale / multi-GPU): the rows of `a` -- the first m_eq
+ * equalities a_i x = b_upper_i, the others b_lower_i <= a_i x <= b_upper_i (b_lower may be NULL = -inf) -- form ONE block
+ * of the standard form [A_eq 0; A_ineq -I] (slack column kept implicit).  With slp_comm_init active every rank holds
+ * its own block and the consensus sum is one all-reduce of n doubles per iteration; the per-block conjugate-gradient
+ * runs need no exchange.  x0 = 0.  `a` stays owned by the caller. */
+slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lower, const double *b_upper, const double *c,
+                                 const double *lb, const double *ub, double gamma);
 void slp_blocks_destroy(slp_blocks *s);
 int slp_blocks_set_cg(slp_blocks *s, double tol, int max_steps);
 int slp_blocks_iterate(slp_blocks *s, int64_t k);

@@ -136,6 +136,115 @@ __global__ __launch_bounds__(kBlock) void k_blk_energy(i64 P, const i32 *__restr
     if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
 
+// ---- one block per rank over a device-resident row block (at scale / multi-GPU) -------------------------
+// The rank's rows  [A_eq; A_ineq] x {=, <=}  are ONE block of the standard form [A_eq 0; A_ineq -I]: its copies are the n
+// original variables (those whose column is not empty in this row block) plus one slack per inequality row, which no
+// other block shares.  The slack column stays implicit:  A^ v = A v_x - v_s,  A^^T nu = [A^T nu; -nu],
+// S nu = A (A^T nu) + nu  on inequality rows.  The only exchange is the consensus sum over the ranks (n doubles).
+bool comm_active();
+void comm_allreduce_dev(double *buf, i64 count, int op);
+
+// v = xp - lambda / gamma  (original part)
+__global__ void k_rb_v(i64 n, const double *__restrict__ xp, const double *__restrict__ lam, double gamma, double *__restrict__ v) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) v[j] = xp[j] - lam[j] / gamma;
+}
+
+// rows: vs = xps - lams / gamma ; rhs = (A v)_i - [ineq] vs_i - b_i ; r = rhs - (q_i + [ineq] nu_i) ; dir = r
+__global__ void k_rb_resid0(i64 m, i64 m_eq, const double *__restrict__ w, const double *__restrict__ b, const double *__restrict__ q,
+                            const double *__restrict__ nu, const double *__restrict__ xps, const double *__restrict__ lams, double gamma,
+                            double *__restrict__ vs, double *__restrict__ r, double *__restrict__ dir, double *__restrict__ rhs) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        const bool ineq = i >= m_eq;
+        const double s = ineq ? xps[i] - lams[i] / gamma : 0.0;
+        vs[i] = s;
+        const double f = ineq ? (w[i] - s) - b[i] : w[i] - b[i];
+        rhs[i] = f;
+        const double ri = f - (ineq ? q[i] + nu[i] : q[i]);
+        r[i] = ri;
+        dir[i] = ri;
+    }
+}
+
+// q += dir on inequality rows (the slack column's share of S dir)
+__global__ void k_rb_add_identity(i64 m, i64 m_eq, const double *__restrict__ dir, double *__restrict__ q) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x + m_eq; i < m; i += (i64)gridDim.x * blockDim.x) q[i] = q[i] + dir[i];
+}
+
+// original part: x = alpha (v - u) + (1 - alpha) xp ; acc = used ? x + lambda / gamma : 0   (the consensus summand)
+__global__ void k_rb_x(i64 n, const unsigned char *__restrict__ used, const double *__restrict__ xp, const double *__restrict__ v,
+                       const double *__restrict__ u, const double *__restrict__ lam, double alpha, double one_minus_alpha, double gamma,
+                       double *__restrict__ x, double *__restrict__ acc) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        const double xj = alpha * (v[j] - u[j]) + one_minus_alpha * xp[j];
+        x[j] = xj;
+        acc[j] = used[j] ? (0.0 + (xj + lam[j] / gamma)) : 0.0;
+    }
+}
+
+// slack part, all local: xs = alpha (vs + nu) + (1 - alpha) xps ; xps = clamp(xs + lams / gamma) ; lams += gamma (xs - xps)
+__global__ void k_rb_slack(i64 m, i64 m_eq, const double *__restrict__ vs, const double *__restrict__ nu, const double *__restrict__ slo,
+                           const double *__restrict__ shi, double alpha, double one_minus_alpha, double gamma, double *__restrict__ xs,
+                           double *__restrict__ xps, double *__restrict__ lams) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x + m_eq; i < m; i += (i64)gridDim.x * blockDim.x) {
+        const double x = alpha * (vs[i] + nu[i]) + one_minus_alpha * xps[i];
+        double a = (0.0 + (x + lams[i] / gamma)) - 0.0 / gamma;  // cost 0, one copy
+        a = a / 1.0;
+        const double l = slo[i], h = shi[i];
+        a = (a > l) ? a : l;
+        a = (a < h) ? a : h;
+        xs[i] = x;
+        xps[i] = a;
+        lams[i] = lams[i] + gamma * (x - a);
+    }
+}
+
+// xp = clamp((acc - c / gamma) / max(copies, 1))  (acc = sum over the ranks; a column no rank uses keeps xp in the sum) ;
+// lambda += gamma (x - xp) where this rank holds a copy
+__global__ void k_rb_consensus(i64 n, const unsigned char *__restrict__ used, const double *__restrict__ copies, const double *__restrict__ acc,
+                               const double *__restrict__ c, const double *__restrict__ lb, const double *__restrict__ ub,
+                               const double *__restrict__ x, double gamma, double *__restrict__ xp, double *__restrict__ lam) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        const double cnt = copies[j];
+        double a = cnt > 0.0 ? acc[j] : xp[j];
+        a = a - c[j] / gamma;
+        a = a / (cnt > 1.0 ? cnt : 1.0);
+        const double l = lb[j], h = ub[j];
+        a = (a > l) ? a : l;
+        a = (a < h) ? a : h;
+        xp[j] = a;
+        if (used[j]) lam[j] = lam[j] + gamma * (x[j] - a);
+    }
+}
+
+__global__ void k_rb_used(i64 n, const i64 *__restrict__ tptr, unsigned char *__restrict__ used, double *__restrict__ copies) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        const unsigned char u = tptr[j + 1] > tptr[j] ? 1 : 0;
+        used[j] = u;
+        copies[j] = (double)u;
+    }
+}
+
+// energy terms of this rank's block: part = sum_{used j} 0.5 g d^2 + lambda d  +  the same over the slacks
+__global__ __launch_bounds__(kBlock) void k_rb_energy(i64 n, i64 m, i64 m_eq, const unsigned char *__restrict__ used,
+                                                      const double *__restrict__ x, const double *__restrict__ xp,
+                                                      const double *__restrict__ lam, const double *__restrict__ xs,
+                                                      const double *__restrict__ xps, const double *__restrict__ lams, double gamma,
+                                                      double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double s = 0.0;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x)
+        if (used[j]) {
+            const double d = x[j] - xp[j];
+            s += 0.5 * gamma * (d * d) + lam[j] * d;
+        }
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x + m_eq; i < m; i += (i64)gridDim.x * blockDim.x) {
+        const double d = xs[i] - xps[i];
+        s += 0.5 * gamma * (d * d) + lams[i] * d;
+    }
+    const double r = block_reduce<false>(s, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
 }  // namespace slp
 
 using namespace slp;
@@ -149,6 +258,11 @@ struct slp_blocks {
     DevBuf<i32> owner, cidx;
     DevBuf<i64> cptr;
     DevBuf<double> b, c, lb, ub, xp, x, lam, nu, v, u, w, q, r, dir, rhs, part, scal;
+    // one block per rank over a caller-owned row block (slp_blocks_create_on)
+    bool row_block = false, distributed = false;
+    i64 m_eq = 0;
+    DevBuf<unsigned char> used;
+    DevBuf<double> copies, acc, vs, xs, xps, lams, slo, shi;
 };
 
 namespace slp {
@@ -166,7 +280,61 @@ static void blk_apply(slp_blocks *s, const double *dir, double *q) {
     matrix_spmv(s->a, false, s->u.p, q, SLP_ORDER_AUTO);
 }
 
+// the conjugate-gradient loop shared by both layouts; `apply(dir, q)` computes q = S dir
+template <class Apply>
+static void blk_cg(slp_blocks *s, Apply apply) {
+    hipStream_t st = ctx().stream;
+    const i64 m = s->m;
+    const int gm = grid_for(m, kBlock);
+    blk_dot(s, m, s->rhs.p, s->rhs.p, B_RHS2, 0);
+    blk_dot(s, m, s->r.p, s->r.p, B_RS, 0);
+    double h[B_COUNT];
+    for (int it = 0; it < s->max_cg;) {
+        s->scal.download(h, B_COUNT);  // one 64-byte read every `check_every` steps
+        if (!(h[B_RS] > s->tol * s->tol * h[B_RHS2])) break;
+        for (int k = 0; k < s->check_every && it < s->max_cg; ++k, ++it) {
+            apply(s->dir.p, s->q.p);
+            blk_dot(s, m, s->dir.p, s->q.p, B_PQ, 1);
+            hipLaunchKernelGGL(k_blk_step, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->dir.p, s->q.p, s->nu.p, s->r.p);
+            blk_dot(s, m, s->r.p, s->r.p, B_RSNEW, 2);
+            hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->r.p, s->dir.p);
+            ++s->cg_steps;
+        }
+    }
+}
+
+static void rb_iteration(slp_blocks *s) {
+    hipStream_t st = ctx().stream;
+    const i64 n = s->N, m = s->m, me = s->m_eq;
+    const int gn = grid_for(n, kBlock), gm = grid_for(m, kBlock);
+    auto apply = [&](const double *dir, double *q) {
+        blk_apply(s, dir, q);
+        if (m > me) hipLaunchKernelGGL(k_rb_add_identity, dim3(grid_for(m - me, kBlock)), dim3(kBlock), 0, st, m, me, dir, q);
+    };
+    hipLaunchKernelGGL(k_rb_v, dim3(gn), dim3(kBlock), 0, st, n, s->xp.p, s->lam.p, s->gamma, s->v.p);
+    if (m > 0) {
+        matrix_spmv(s->a, false, s->v.p, s->w.p, SLP_ORDER_AUTO);
+        blk_apply(s, s->nu.p, s->q.p);
+        hipLaunchKernelGGL(k_rb_resid0, dim3(gm), dim3(kBlock), 0, st, m, me, s->w.p, s->b.p, s->q.p, s->nu.p, s->xps.p, s->lams.p, s->gamma,
+                           s->vs.p, s->r.p, s->dir.p, s->rhs.p);
+        blk_cg(s, apply);
+        matrix_spmv(s->a, true, s->nu.p, s->u.p, SLP_ORDER_AUTO);
+    } else {
+        s->u.zero();
+    }
+    hipLaunchKernelGGL(k_rb_x, dim3(gn), dim3(kBlock), 0, st, n, s->used.p, s->xp.p, s->v.p, s->u.p, s->lam.p, s->alpha, 1.0 - s->alpha,
+                       s->gamma, s->x.p, s->acc.p);
+    if (m > me)
+        hipLaunchKernelGGL(k_rb_slack, dim3(grid_for(m - me, kBlock)), dim3(kBlock), 0, st, m, me, s->vs.p, s->nu.p, s->slo.p, s->shi.p,
+                           s->alpha, 1.0 - s->alpha, s->gamma, s->xs.p, s->xps.p, s->lams.p);
+    if (s->distributed) comm_allreduce_dev(s->acc.p, n, 0);  // the consensus sum: the only exchange of an iteration
+    hipLaunchKernelGGL(k_rb_consensus, dim3(gn), dim3(kBlock), 0, st, n, s->used.p, s->copies.p, s->acc.p, s->c.p, s->lb.p, s->ub.p, s->x.p,
+                       s->gamma, s->xp.p, s->lam.p);
+    SLP_HIP(hipGetLastError());
+}
+
 static void blk_iteration(slp_blocks *s) {
+    if (s->row_block) { rb_iteration(s); return; }
     hipStream_t st = ctx().stream;
     const i64 P = s->P, m = s->m, N = s->N;
     const int gp = grid_for(P, kBlock), gm = grid_for(m, kBlock), gn = grid_for(N, kBlock);
@@ -176,21 +344,7 @@ static void blk_iteration(slp_blocks *s) {
         matrix_spmv(s->a, false, s->v.p, s->w.p, SLP_ORDER_AUTO);
         blk_apply(s, s->nu.p, s->q.p);
         hipLaunchKernelGGL(k_blk_resid0, dim3(gm), dim3(kBlock), 0, st, m, s->w.p, s->b.p, s->q.p, s->r.p, s->dir.p, s->rhs.p);
-        blk_dot(s, m, s->rhs.p, s->rhs.p, B_RHS2, 0);
-        blk_dot(s, m, s->r.p, s->r.p, B_RS, 0);
-        double h[B_COUNT];
-        for (int it = 0; it < s->max_cg;) {
-            s->scal.download(h, B_COUNT);  // one 64-byte read every `check_every` steps
-            if (!(h[B_RS] > s->tol * s->tol * h[B_RHS2])) break;
-            for (int k = 0; k < s->check_every && it < s->max_cg; ++k, ++it) {
-                blk_apply(s, s->dir.p, s->q.p);
-                blk_dot(s, m, s->dir.p, s->q.p, B_PQ, 1);
-                hipLaunchKernelGGL(k_blk_step, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->dir.p, s->q.p, s->nu.p, s->r.p);
-                blk_dot(s, m, s->r.p, s->r.p, B_RSNEW, 2);
-                hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->r.p, s->dir.p);
-                ++s->cg_steps;
-            }
-        }
+        blk_cg(s, [&](const double *dir, double *q) { blk_apply(s, dir, q); });
         matrix_spmv(s->a, true, s->nu.p, s->u.p, SLP_ORDER_AUTO);
     } else {
         s->u.zero();
@@ -238,9 +392,52 @@ slp_blocks *slp_blocks_create(int64_t P, int64_t m, int64_t N, const int64_t *in
     })
 }
 
+slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lower, const double *b_upper, const double *c,
+                                 const double *lb, const double *ub, double gamma) {
+    SLP_API_PTR({
+        SLP_REQUIRE(a && b_upper && c && lb && ub, "slp_blocks_create_on: NULL argument");
+        SLP_REQUIRE(m_eq >= 0 && m_eq <= a->a.nrow, "slp_blocks_create_on: m_eq out of range");
+        SLP_REQUIRE(gamma > 0.0, "slp_blocks_create_on: gamma must be positive");
+        auto *s = new slp_blocks();
+        try {
+            hipStream_t st = ctx().stream;
+            const i64 m = a->a.nrow, n = a->a.ncol;
+            s->a = a; s->row_block = true; s->m = m; s->N = n; s->P = n; s->m_eq = m_eq; s->gamma = gamma;
+            s->distributed = comm_active();
+            build_transpose(a);
+            const size_t sn = (size_t)n, sm = (size_t)m;
+            // standard form (tools.py:88-127): b = [b_eq; 0], slack bounds [b_lower, b_upper]; x0 = 0 so xp0 = clamp(0) (:84-86)
+            std::vector<double> hb(sm, 0.0), hlo(sm, 0.0), hhi(sm, 0.0), hx(sn), hs(sm, 0.0);
+            for (i64 i = 0; i < m; ++i) {
+                if (i < m_eq) { hb[(size_t)i] = b_upper[i]; continue; }
+                hlo[(size_t)i] = b_lower ? b_lower[i] : -INFINITY;
+                hhi[(size_t)i] = b_upper[i];
+                hs[(size_t)i] = std::min(std::max(0.0, hlo[(size_t)i]), hhi[(size_t)i]);
+            }
+            for (i64 j = 0; j < n; ++j) hx[(size_t)j] = std::min(std::max(0.0, lb[j]), ub[j]);
+            s->b.upload(hb.data(), sm); s->slo.upload(hlo.data(), sm); s->shi.upload(hhi.data(), sm); s->xps.upload(hs.data(), sm);
+            s->c.upload(c, sn); s->lb.upload(lb, sn); s->ub.upload(ub, sn); s->xp.upload(hx.data(), sn);
+            s->x.alloc(sn); s->lam.alloc(sn); s->lam.zero(); s->v.alloc(sn); s->u.alloc(sn); s->acc.alloc(sn);
+            s->used.alloc(sn); s->copies.alloc(sn);
+            s->nu.alloc(sm); s->nu.zero(); s->w.alloc(sm); s->q.alloc(sm); s->r.alloc(sm); s->dir.alloc(sm); s->rhs.alloc(sm);
+            s->vs.alloc(sm); s->xs.alloc(sm); s->xs.zero(); s->lams.alloc(sm); s->lams.zero();
+            s->part.alloc(kBlkPartials); s->scal.alloc(B_COUNT); s->scal.zero();
+            // which columns this row block uses (a copy exists only for those, :183-185) and in how many ranks' blocks
+            hipLaunchKernelGGL(k_rb_used, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, n, a->at.ptr.p, s->used.p, s->copies.p);
+            SLP_HIP(hipGetLastError());
+            if (s->distributed) comm_allreduce_dev(s->copies.p, n, 0);
+            SLP_HIP(hipStreamSynchronize(st));
+        } catch (...) {
+            delete s;
+            throw;
+        }
+        return s;
+    })
+}
+
 void slp_blocks_destroy(slp_blocks *s) {
     if (!s) return;
-    delete s->a;
+    if (!s->row_block) delete s->a;
     delete s;
 }
 
@@ -267,7 +464,17 @@ int slp_blocks_report(slp_blocks *s, double out[2]) {
         blk_dot(s, s->N, s->c.p, s->xp.p, B_PQ, 0);
         s->scal.download(h, B_COUNT);
         double e = h[B_PQ];
-        if (s->P > 0) {
+        if (s->row_block) {
+            int grid = std::min(grid_for(std::max(s->N, s->m), kBlock), kBlkPartials);
+            hipLaunchKernelGGL(k_rb_energy, dim3(grid), dim3(kBlock), 0, st, s->N, s->m, s->m_eq, s->used.p, s->x.p, s->xp.p, s->lam.p,
+                               s->xs.p, s->xps.p, s->lams.p, s->gamma, s->part.p);
+            hipLaunchKernelGGL(k_blk_finish, dim3(1), dim3(kBlock), 0, st, grid, s->part.p, s->scal.p, (int)B_PQ, 0);
+            SLP_HIP(hipGetLastError());
+            s->scal.download(h, B_COUNT);
+            double blocks = h[B_PQ];
+            if (s->distributed) SLP_REQUIRE(slp_comm_allreduce_host(&blocks, 1, 0) == 0, slp_last_error());
+            e += blocks;
+        } else if (s->P > 0) {
             int grid = std::min(grid_for(s->P, kBlock), kBlkPartials);
             hipLaunchKernelGGL(k_blk_energy, dim3(grid), dim3(kBlock), 0, st, s->P, s->owner.p, s->x.p, s->xp.p, s->lam.p, s->gamma,
                                s->part.p);

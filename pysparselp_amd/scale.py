@@ -60,4 +60,57 @@ def make_solver(method, a, b_upper, c, lb, ub, m_eq=0):
         from .admm_cg import DeviceADMM
 
         return DeviceADMM(a, b_upper, c, lb, ub, m_eq=m_eq)
+    if method == "admm_blocks":
+        return DeviceBlocks(a, b_upper, c, lb, ub, m_eq=m_eq)
     raise ValueError(method)
+
+
+class DeviceBlocks:
+    """Block-splitting ADMM (reference ADMMBlocks.py:45-352) with ONE block per rank: the rows of the DeviceMatrix ``a``
+    (this rank's row block when ``slp_comm_init`` is active).  The first ``m_eq`` rows are equalities, the others
+    ``b_lower <= a_i x <= b_upper``.  Per-block projections by conjugate gradients, no exchange inside them; one
+    all-reduce of n doubles per iteration for the consensus."""
+
+    def __init__(self, a, b_upper, c, lb, ub, gamma=0.7, m_eq=0, b_lower=None, cg_tol=1e-13, cg_max_steps=500):
+        self._l = _lib.lib()
+        self.a = a
+        self.n = a.shape[1]
+        self.c = _lib.f64(c)
+        b_upper, lb, ub = _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
+        b_lower = None if b_lower is None else _lib.f64(b_lower)
+        self._h = _lib.check_handle(self._l.slp_blocks_create_on(
+            a._h, int(m_eq), None if b_lower is None else _lib.ptr(b_lower), _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
+            _lib.ptr(ub), float(gamma)))
+        _lib.check(self._l.slp_blocks_set_cg(self._h, float(cg_tol), int(cg_max_steps)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.slp_blocks_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def iterate(self, k):
+        _lib.check(self._l.slp_blocks_iterate(self._h, int(k)))
+
+    def report(self):
+        out = np.zeros(2)
+        _lib.check(self._l.slp_blocks_report(self._h, _lib.ptr(out)))
+        return out
+
+    def x(self):
+        out = np.empty(self.n)
+        _lib.check(self._l.slp_blocks_get_xp(self._h, _lib.ptr(out), self.n))
+        return out
+
+    def objective(self):
+        return float(self.c.dot(self.x()))
+
+    def cg_steps(self):
+        return int(self.report()[1])
+
+    def matrix_passes_per_iteration(self):
+        return None  # 3 + 2 per conjugate-gradient step; see cg_steps()
+
+    def describe(self):
+        return "block-splitting ADMM (ADMMBlocks.py), one block per rank, matrix-free per-block projections (CG), gamma=0.7, alpha=1.95"

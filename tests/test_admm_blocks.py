@@ -103,3 +103,33 @@ def test_gpu_reporting_cadence_and_solve_method():
     lp, gt, gt_idx, _ = potts_lp(8)
     x = lp.solve(method="admm_blocks", nb_iter=200, nb_iter_plot=50, ground_truth=gt, ground_truth_indices=gt_idx, get_timing=False)
     assert np.max(np.abs(x - ref[200])) < 1e-7 and lp.itrn_curve == [0, 50, 100, 150, 200]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_nnz", ["1", "100000000000"])  # strip kernels / CSR kernels
+def test_gpu_row_block_solver_matches_oracle(monkeypatch, min_nnz):
+    """DeviceBlocks: the rows of a device-generated LP as ONE block (what a rank holds in the multi-GPU form), equality rows
+    and two-sided rows included, slack column implicit -- against the oracle's LU form with the single block [0, m - 1].
+    (The partitioned code path with the consensus all-reduce is exercised in tests/test_gpu_comm.py.)"""
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceBlocks
+
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", min_nnz)
+    n, m, p, m_eq = 3000, 4000, 0.004, 300
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=5)
+    s = a.download()
+    ax = a.matvec(xf)
+    rng = np.random.RandomState(8)
+    b = b.copy()
+    b[:m_eq] = ax[:m_eq]
+    bl = np.where(rng.rand(m) < 0.5, -np.inf, ax - rng.rand(m))
+    ae, ai = s[:m_eq], s[m_eq:]
+    xo = oracle.lp_admm_block_decomposition(c, ae, b[:m_eq], ai, bl[m_eq:], b[m_eq:], lb, ub, nb_iter=29, nb_iter_plot=10 ** 9,
+                                            blocks_eq=[(0, m - 1)], blocks_ineq=[])
+    sol = DeviceBlocks(a, b, c, lb, ub, m_eq=m_eq, b_lower=bl)
+    sol.iterate(30)
+    x = sol.x()
+    assert 30 < sol.cg_steps() < 30 * 500
+    sol.close()
+    assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-8
+    a.close()

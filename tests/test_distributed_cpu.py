@@ -148,6 +148,27 @@ def _rank_main(rank, world, port, out):
         lio, lis = lio + gi * (xo - xpo), lis + gi * (xs - xps)
         lam = lam + ge * (a_apply(xo, xs) - 0.0)
     out["admm_x"] = xo
+
+    # --- block-splitting ADMM, one block per rank (slp_blocks.hip, rb_iteration): the rank's rows with their slacks kept
+    #     implicit; per-block projection local (here: a direct solve of S nu = rhs), consensus sum = the only all-reduce
+    gam, alf = 0.7, 1.95
+    ad = a[r0:r0 + rows].toarray()
+    smat = ad @ ad.T + np.eye(rows)
+    used = (np.abs(ad).sum(axis=0) > 0).astype(np.float64)
+    copies = allreduce(used)
+    xp, xps = np.minimum(np.maximum(np.zeros(n), lb), ub), np.minimum(np.zeros(rows), bg)
+    lam_b, lams_b = np.zeros(n), np.zeros(rows)
+    for _ in range(40):
+        v, vs = xp - lam_b / gam, xps - lams_b / gam
+        nu = np.linalg.solve(smat, ad @ v - vs)
+        xb = alf * (v - ad.T @ nu) + (1 - alf) * xp
+        xsb = alf * (vs + nu) + (1 - alf) * xps
+        acc = allreduce(np.where(used > 0, xb + lam_b / gam, 0.0))
+        xp = np.minimum(np.maximum((np.where(copies > 0, acc, xp) - c / gam) / np.maximum(copies, 1), lb), ub)
+        xps = np.minimum(xsb + lams_b / gam, bg)
+        lam_b = np.where(used > 0, lam_b + gam * (xb - xp), lam_b)
+        lams_b = lams_b + gam * (xsb - xps)
+    out["blocks_x"] = xp
     dist.barrier()
     dist.destroy_process_group()
 
@@ -182,3 +203,11 @@ def test_row_partitioned_solvers_match_single_process_oracle():
     for r in range(world):
         assert np.max(np.abs(results[r]["admm_x"] - x_ref) / (1 + np.abs(x_ref))) < 1e-9
     assert np.array_equal(results[0]["admm_x"], results[1]["admm_x"])
+    # the reference's block-splitting ADMM with the two row halves as its blocks (sparse LU per block)
+    m = a.shape[0]
+    cuts = [row_block(m, world, r) for r in range(world)]
+    x_ref = oracle.lp_admm_block_decomposition(c, None, None, a, None, b, lb, ub, nb_iter=39, nb_iter_plot=10 ** 9,
+                                               blocks_eq=[], blocks_ineq=[(f, f + cnt - 1) for f, cnt in cuts])
+    for r in range(world):
+        assert np.max(np.abs(results[r]["blocks_x"] - x_ref) / (1 + np.abs(x_ref))) < 1e-9
+    assert np.array_equal(results[0]["blocks_x"], results[1]["blocks_x"])

@@ -22,7 +22,7 @@ os.environ["SLP_FORCE_DISTRIBUTED"] = "1"
 os.environ["SLP_STRIP_MIN_NNZ"] = %(min_nnz)r
 from pysparselp_amd import _lib
 from pysparselp_amd.problems import random_lp_on_device
-from pysparselp_amd.scale import DeviceCP
+from pysparselp_amd.scale import DeviceBlocks, DeviceCP
 from pysparselp_amd.admm_cg import DeviceADMM
 lib = _lib.lib(0)
 n, m, p = 30000, 40000, 0.001
@@ -30,9 +30,10 @@ n, m, p = 30000, 40000, 0.001
 def run():
     a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=3)
     cp = DeviceCP(a, b, c, lb, ub); cp.iterate(30); x_cp = cp.x(); cp.close()
+    blk = DeviceBlocks(a, b, c, lb, ub, cg_max_steps=40); blk.iterate(4); x_blk = blk.x(); e_blk = blk.report()[0]; blk.close()
     admm = DeviceADMM(a, b, c, lb, ub); admm.iterate(15); x_admm = admm.x(n); rep = admm.report(); admm.close()
     a.close()
-    return x_cp, x_admm, rep
+    return x_cp, x_admm, rep, x_blk, e_blk
 
 plain = run()                                   # no communicator yet: single-GPU code path
 uid = ctypes.create_string_buffer(128)
@@ -48,6 +49,8 @@ else:                                           # lane-parallel sums: the two pa
     assert np.max(np.abs(plain[0] - part[0]) / (1 + np.abs(plain[0]))) < 1e-12
 assert np.max(np.abs(plain[1] - part[1]) / (1 + np.abs(plain[1]))) < 1e-12
 assert np.allclose(plain[2], part[2], rtol=1e-10)
+assert np.max(np.abs(plain[3] - part[3]) / (1 + np.abs(plain[3]))) < 1e-12   # block-splitting ADMM, consensus all-reduce
+assert abs(plain[4] - part[4]) <= 1e-10 * (1 + abs(plain[4]))
 print("COMM-OK")
 """
 
