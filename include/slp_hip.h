@@ -73,6 +73,10 @@ int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, do
  * SLP_DICT_VARIANT=1), 4 / 5 = wide strips (k_wstrip_spmv: strips of 131072 columns, x gathered from L2; rows too sparse
  * for the LDS tile over a width far beyond an L2) with value-dictionary / fp64 entries,
  * 0 = row-per-lane-group CSR kernel (k_spmv), -1 = error. */
+/* New device-resident matrix whose row r is scale[r] * (row rows[r] of a): the one-sided stacking [A[up]; -A[lo]] of
+ * ChambollePockPPD.py:74-88 (and any row selection) without a round trip of the CSR through the host.
+ * scale 1 copies, -1 negates exactly. */
+slp_matrix *slp_matrix_gather_rows(slp_matrix *a, int64_t count, const int64_t *rows, const double *scale);
 int slp_matrix_spmv_kernel(slp_matrix *a, int transposed);
 /* Bytes of the matrix copy that kernel reads per product (entries + per-strip metadata; CSR: 12 nnz + 8 (rows + 1)),
  * i.e. the matrix part of the HBM traffic one launch must generate; -1 = error. */

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "slp_matrix_spmv_t": (c_int, [c_vp, c_vp, c_vp, c_int]),
     "slp_matrix_download": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
     "slp_matrix_bench_spmv": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),
+    "slp_matrix_gather_rows": (c_vp, [c_vp, c_i64, c_vp, c_vp]),
     "slp_matrix_spmv_kernel": (c_int, [c_vp, c_int]),
     "slp_matrix_format_bytes": (c_i64, [c_vp, c_int]),
     "slp_cp_create": (c_vp, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),

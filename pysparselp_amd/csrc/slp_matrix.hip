@@ -225,6 +225,71 @@ static slp_matrix *matrix_from_host(i64 nrow, i64 ncol, const i64 *indptr, const
     return m;
 }
 
+// ---- row gather: out row r = scale[r] * (row src[r] of a); used for the device-side one-sided stacking
+// [A[up]; -A[lo]] of ChambollePockPPD.py:74-88 (the CSR never returns to the host)
+__global__ void k_gather_len(i64 count, const i64 *__restrict__ src, const i64 *__restrict__ ptr, unsigned long long *__restrict__ len) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < count; r += (i64)gridDim.x * blockDim.x)
+        len[r] = (unsigned long long)(ptr[src[r] + 1] - ptr[src[r]]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_rows(i64 count, const i64 *__restrict__ src, const double *__restrict__ scale,
+                                                        const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
+                                                        const double *__restrict__ val, const i64 *__restrict__ optr,
+                                                        i32 *__restrict__ oidx, double *__restrict__ oval) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const i64 wave = ((i64)blockIdx.x * kBlock + threadIdx.x) / kWave, nwaves = (i64)gridDim.x * kBlock / kWave;
+    for (i64 r = wave; r < count; r += nwaves) {  // one wavefront per row: coalesced copies
+        const i64 s = ptr[src[r]], e = ptr[src[r] + 1], o = optr[r];
+        const double f = scale[r];
+        for (i64 k = s + lane; k < e; k += kWave) {
+            oidx[o + (k - s)] = idx[k];
+            oval[o + (k - s)] = (f == 1.0) ? val[k] : f * val[k];  // -1: an exact negation, like scipy's `-A`
+        }
+    }
+}
+
+static slp_matrix *matrix_gather_rows(slp_matrix *a, i64 count, const i64 *rows, const double *scale) {
+    SLP_REQUIRE(a && count >= 0 && (count == 0 || (rows && scale)), "slp_matrix_gather_rows: bad arguments");
+    for (i64 r = 0; r < count; ++r) SLP_REQUIRE(rows[r] >= 0 && rows[r] < a->a.nrow, "slp_matrix_gather_rows: row out of range");
+    hipStream_t st = ctx().stream;
+    auto *m = new slp_matrix();
+    try {
+        DevBuf<i64> src((size_t)count);
+        DevBuf<double> sc((size_t)count);
+        src.upload(rows, (size_t)count);
+        sc.upload(scale, (size_t)count);
+        DevBuf<unsigned long long> len((size_t)count + 1);
+        len.zero();
+        if (count) hipLaunchKernelGGL(k_gather_len, dim3(grid_for(count, kBlock)), dim3(kBlock), 0, st, count, src.p, a->a.ptr.p, len.p);
+        SLP_HIP(hipGetLastError());
+        m->a.nrow = count;
+        m->a.ncol = a->a.ncol;
+        m->a.ptr.alloc((size_t)count + 1);
+        size_t bytes = 0;
+        SLP_HIP(rocprim::exclusive_scan(nullptr, bytes, len.p, (unsigned long long *)m->a.ptr.p, 0ull, (size_t)count + 1,
+                                        rocprim::plus<unsigned long long>(), st));
+        DevBuf<char> tmp(bytes);
+        SLP_HIP(rocprim::exclusive_scan(tmp.p, bytes, len.p, (unsigned long long *)m->a.ptr.p, 0ull, (size_t)count + 1,
+                                        rocprim::plus<unsigned long long>(), st));
+        i64 nnz = 0;
+        SLP_HIP(hipMemcpyAsync(&nnz, m->a.ptr.p + count, sizeof(i64), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipStreamSynchronize(st));
+        m->a.nnz = nnz;
+        m->a.idx.alloc((size_t)nnz);
+        m->a.val.alloc((size_t)nnz);
+        if (count)
+            hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(count * kWave, kBlock)), dim3(kBlock), 0, st, count, src.p, sc.p, a->a.ptr.p,
+                               a->a.idx.p, a->a.val.p, m->a.ptr.p, m->a.idx.p, m->a.val.p);
+        SLP_HIP(hipGetLastError());
+        finish_stats(m->a);
+        SLP_HIP(hipStreamSynchronize(st));
+    } catch (...) {
+        delete m;
+        throw;
+    }
+    return m;
+}
+
 }  // namespace slp
 
 using namespace slp;
@@ -232,6 +297,10 @@ using namespace slp;
 extern "C" {
 
 int slp_version(void) { return 100; }
+
+slp_matrix *slp_matrix_gather_rows(slp_matrix *a, int64_t count, const int64_t *rows, const double *scale) {
+    SLP_API_PTR({ return matrix_gather_rows(a, count, rows, scale); })
+}
 
 const char *slp_last_error(void) { return g_err.c_str(); }
 

@@ -31,6 +31,13 @@ class DeviceMatrix:
         h = _lib.check_handle(l.slp_matrix_random(int(nrow), int(ncol), float(density), int(seed), int(row_offset)))
         return cls(h, (nrow, ncol))
 
+    def gather_rows(self, rows, scale=None):
+        """New DeviceMatrix whose row r is ``scale[r] *`` row ``rows[r]`` of this one, built on the device."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        scale = np.ones(rows.size) if scale is None else _lib.f64(np.broadcast_to(scale, rows.shape))
+        h = _lib.check_handle(self._l.slp_matrix_gather_rows(self._h, rows.size, _lib.ptr(rows), _lib.ptr(scale)))
+        return DeviceMatrix(h, (rows.size, self.shape[1]))
+
     def close(self):
         if getattr(self, "_h", None):
             self._l.slp_matrix_destroy(self._h)

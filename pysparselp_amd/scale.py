@@ -13,19 +13,50 @@ from ._lib import ORDER_AUTO
 class DeviceCP:
     """Chambolle-Pock (reference ChambollePockPPD.py:195-343) on a DeviceMatrix."""
 
-    def __init__(self, a, b_upper, c, lb, ub, alpha=1.0, theta=1.0, order=ORDER_AUTO, m_eq=0):
+    def __init__(self, a, b_upper, c, lb, ub, alpha=1.0, theta=1.0, order=ORDER_AUTO, m_eq=0, b_lower=None):
         self._l = _lib.lib()
-        self.a = a
         self.n = a.shape[1]
         self.c = _lib.f64(c)
         b_upper, lb, ub = _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
+        self._stacked = None
+        if b_lower is not None:
+            a, b_upper = self._one_sided(a, int(m_eq), _lib.f64(b_lower), b_upper)
+        self.a = a
         self._h = _lib.check_handle(self._l.slp_cp_create_on(a._h, int(m_eq), _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
                                                              _lib.ptr(ub), None, float(alpha), float(theta), int(order)))
+
+    def _one_sided(self, a, m_eq, b_lower, b_upper):
+        """b_lower <= A_ineq x <= b_upper  ->  K x <= b on the device (ChambollePockPPD.py:74-88): the rows with a finite upper
+        bound, then the negated rows with a finite lower bound; equality rows (the first m_eq) stay in front.  With no finite
+        lower bound the matrix is left as it is; with no finite upper bound every inequality row is negated (:80-86)."""
+        m = a.shape[0]
+        ineq = np.arange(m_eq, m)
+        up = ineq[b_upper[m_eq:] != np.inf]
+        lo = ineq[b_lower[m_eq:] != -np.inf]
+        if len(lo) == 0:
+            return a, b_upper
+        eq = np.arange(m_eq)
+        if len(up) > 0:
+            rows = np.concatenate((eq, up, lo))
+            scale = np.concatenate((np.ones(m_eq + len(up)), -np.ones(len(lo))))
+            b = np.concatenate((b_upper[:m_eq], b_upper[up], -b_lower[lo]))
+        else:
+            rows = np.arange(m)
+            scale = np.concatenate((np.ones(m_eq), -np.ones(m - m_eq)))
+            b = np.concatenate((b_upper[:m_eq], -b_lower[lo]))
+            if len(lo) != m - m_eq:
+                raise ValueError("rows without any finite bound next to lower-bounded rows: the reference's stacking is "
+                                 "inconsistent here (ChambollePockPPD.py:80-86); drop the unbounded rows first")
+        self._stacked = a.gather_rows(rows, scale)
+        return self._stacked, np.ascontiguousarray(b)
 
     def close(self):
         if getattr(self, "_h", None):
             self._l.slp_cp_destroy(self._h)
             self._h = None
+        if getattr(self, "_stacked", None) is not None:
+            self._stacked.close()
+            self._stacked = None
 
     __del__ = close
 

@@ -3,6 +3,7 @@ device-side standard form [A_eq 0; A_ineq -I] for the matrix-free ADMM, and Cham
 rows through the strip kernels.  Against the oracle on the downloaded matrix.  -m gpu."""
 import numpy as np
 import pytest
+import scipy.sparse
 
 from oracle import oracle
 
@@ -72,3 +73,51 @@ def test_two_sided_rows_admm_match_oracle(monkeypatch, min_nnz):
     assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-9
     assert abs(c.dot(x) - c.dot(xo)) <= 1e-6 * abs(c.dot(xo))
     assert np.sum(np.isfinite(bl[m_eq:])) > 20000 and np.all(np.isfinite(slack))
+
+
+@pytest.mark.parametrize("min_nnz", ["1", "100000000000"])
+def test_two_sided_rows_cp_match_oracle(monkeypatch, min_nnz):
+    """b_lower <= A x <= b_upper on the at-scale Chambolle-Pock: the one-sided stacking [A[up]; -A[lo]] of
+    ChambollePockPPD.py:74-88 is built on the device (slp_matrix_gather_rows); equality rows stay in front."""
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", min_nnz)
+    n, m, p, m_eq = 30000, 40000, 0.001, 3000
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=12)
+    s = a.download()
+    ax = a.matvec(xf)
+    rng = np.random.RandomState(6)
+    b = b.copy()
+    b[:m_eq] = ax[:m_eq]
+    bl = np.where(rng.rand(m) < 0.4, -np.inf, ax - rng.rand(m))
+    bu = np.where(rng.rand(m) < 0.2, np.inf, b)   # some rows only bounded from below
+    bu[:m_eq] = b[:m_eq]
+    bl[(bl == -np.inf) & (bu == np.inf)] = -5.0   # every inequality row keeps at least one finite side
+    ae, ai = s[:m_eq], s[m_eq:]
+    cp = DeviceCP(a, bu, c, lb, ub, m_eq=m_eq, b_lower=bl, order=1)
+    assert cp.a.shape[0] > m  # stacked
+    cp.iterate(40)
+    x = cp.x()
+    cp.close()
+    a.close()
+    xo, _ = oracle.chambolle_pock_ppd(c, ae, b[:m_eq], ai, bl[m_eq:], bu[m_eq:], lb, ub, nb_max_iter=40, nb_iter_plot=10 ** 9)
+    assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-10
+
+
+def test_gather_rows_on_device():
+    from pysparselp_amd.problems import random_lp_on_device
+
+    a = random_lp_on_device(500, 700, 0.02, seed=1)[0]
+    s = a.download()
+    rows = np.array([5, 5, 699, 0, 12], dtype=np.int64)
+    scale = np.array([1.0, -1.0, 2.5, 1.0, -1.0])
+    g = a.gather_rows(rows, scale)
+    got = g.download()
+    ref = (scipy.sparse.diags(scale) @ s[rows]).tocsr()
+    ref.sort_indices()  # scipy's product leaves the rows reversed
+    assert got.shape == ref.shape and np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    assert np.array_equal(got.data, ref.data)
+    assert a.gather_rows(np.zeros(0, dtype=np.int64)).shape == (0, 500)
+    g.close()
+    a.close()
