@@ -78,10 +78,6 @@ def cpu_baseline(args, method):
     t0 = time.perf_counter()
     if method == "chambolle_pock_ppd":
         oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9)
-    elif method == "admm_blocks":  # one block = all rows; includes the sparse LU of its KKT matrix, like the reference
-        iters = 3
-        oracle.lp_admm_block_decomposition(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9,
-                                           blocks_eq=[], blocks_ineq=[(0, m - 1)])
     else:
         oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
     dt = time.perf_counter() - t0
@@ -235,7 +231,9 @@ def main():
             "objective_after_run": obj,
             "setup_seconds": t_gen,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.method != "admm_blocks":
+            # (admm_blocks: the reference's per-block sparse LU of a KKT matrix with 5e5+ unknowns does not finish in
+            # bench time even on the 1/100 sample; tools/bench_blocks.py times the LU form on the Potts LP instead)
             out["cpu_baseline"] = cpu_baseline(args, args.method)
         print(json.dumps(out), flush=True)
     solver.close()

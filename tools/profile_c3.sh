@@ -15,3 +15,5 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 python3 tools/scaling_compute_only.py > gpurun_out/scaling.json 2> gpurun_out/scaling.err
 find gpurun_out -name "*.csv" -size +20M -delete
 cut -c1-400 gpurun_out/final_admm.json; cut -c1-300 gpurun_out/final_cp.json
+timeout 300 python3 bench.py --method admm_blocks --steps 3 --warmup 1 > gpurun_out/final_admm_blocks.json 2> gpurun_out/final_admm_blocks.err
+cut -c1-300 gpurun_out/final_admm_blocks.json
