@@ -137,6 +137,86 @@ __global__ __launch_bounds__(kBlock) void k_cp_dual(i64 m, const i64 *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// Short rows (Potts: 3 entries per row, <= 8 per column; netlib): ELL copies of K and K^T, column-major, padded to
+// W entries per row.  A thread reads its row's W (index, value) pairs with coalesced, unconditional loads (pads:
+// index 0, value 0, skipped in the sum) -- two dependent memory hops per half-iteration (entries -> gather)
+// instead of the three of CSR (row pointer -> entries -> gather); these LPs are latency-bound, not bandwidth-bound.
+// Sums run over e = 0 .. len-1 in storage order: the same sequential sums as k_cp_primal<1> / k_cp_dual<1>.
+__global__ void k_ell_fill(i64 nrow, int W, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, const double *__restrict__ val,
+                           i32 *__restrict__ oidx, double *__restrict__ oval, unsigned char *__restrict__ olen) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
+        const i64 s = ptr[r];
+        const int len = (int)(ptr[r + 1] - s);
+        olen[r] = (unsigned char)len;
+        for (int e = 0; e < W; ++e) {
+            oidx[(i64)e * nrow + r] = e < len ? idx[s + e] : 0;
+            oval[(i64)e * nrow + r] = e < len ? val[s + e] : 0.0;
+        }
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void k_cp_primal_ell(i64 n, const unsigned char *__restrict__ len, const i32 *__restrict__ eidx,
+                                                          const double *__restrict__ eval, const double *__restrict__ y,
+                                                          const double *__restrict__ c, const double *__restrict__ t,
+                                                          const double *__restrict__ lb, const double *__restrict__ ub,
+                                                          double *__restrict__ x, double *__restrict__ z, double *__restrict__ d_out,
+                                                          i32 m_eq, i64 m_ineq, double one_plus_theta, double theta) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        i32 ix[W];
+        double v[W], g[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) { ix[e] = eidx[(i64)e * n + j]; v[e] = eval[(i64)e * n + j]; }
+        const int L = len[j];
+        const double cj = c[j], tj = t[j], l = lb[j], u = ub[j], xo = x[j];
+#pragma unroll
+        for (int e = 0; e < W; ++e) g[e] = y[ix[e]];
+        double se = 0.0, si = 0.0;
+#pragma unroll
+        for (int e = 0; e < W; ++e)
+            if (e < L) {
+                if (ix[e] < m_eq) se += v[e] * g[e];
+                else si += v[e] * g[e];
+            }
+        double d;
+        if (m_eq > 0 && m_ineq > 0) d = (cj + se) + si;  // :206,216
+        else if (m_eq > 0) d = cj + se;
+        else d = cj + si;
+        double x2 = xo - tj * d;  // :220
+        x2 = (x2 < l) ? l : x2;
+        x2 = (x2 > u) ? u : x2;
+        z[j] = one_plus_theta * x2 - theta * xo;  // :226
+        x[j] = x2;
+        if (d_out) d_out[j] = d;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void k_cp_dual_ell(i64 m, const unsigned char *__restrict__ len, const i32 *__restrict__ eidx,
+                                                        const double *__restrict__ eval, const double *__restrict__ z,
+                                                        const double *__restrict__ b, const double *__restrict__ sigma,
+                                                        double *__restrict__ y, i64 m_eq) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        i32 ix[W];
+        double v[W], g[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) { ix[e] = eidx[(i64)e * m + i]; v[e] = eval[(i64)e * m + i]; }
+        const int L = len[i];
+        const double bi = b[i], sg = sigma[i], yo = y[i];
+#pragma unroll
+        for (int e = 0; e < W; ++e) g[e] = z[ix[e]];
+        double kz = 0.0;
+#pragma unroll
+        for (int e = 0; e < W; ++e)
+            if (e < L) kz += v[e] * g[e];
+        const double r = kz - bi;       // :235,240
+        double yn = yo + sg * r;        // :334,339
+        if (i >= m_eq) yn = (yn < 0.0) ? 0.0 : yn;  // :341
+        y[i] = yn;
+    }
+}
+
 // dual half-iteration from a precomputed K z (LDS-tiled SpMV path)
 __global__ void k_cp_dual_from(i64 m, const double *__restrict__ kz, const double *__restrict__ b,
                                const double *__restrict__ sigma, double *__restrict__ y, i64 m_eq) {
@@ -270,6 +350,11 @@ struct slp_cp {
     int order = SLP_ORDER_AUTO;
     int lanes_rows = 1, lanes_cols = 1;
     DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, kz, rowparts, colparts, out;
+    // ELL copies for short rows (0 = not used)
+    int ell_w_rows = 0, ell_w_cols = 0;
+    DevBuf<i32> ell_idx_rows, ell_idx_cols;
+    DevBuf<double> ell_val_rows, ell_val_cols;
+    DevBuf<unsigned char> ell_len_rows, ell_len_cols;
     bool distributed = false;
     IterGraph graph;
 };
@@ -288,6 +373,22 @@ static void cp_setup(slp_cp *s) {
     s->t.alloc((size_t)s->n);
     s->sigma.alloc((size_t)s->m);
     s->distributed = comm_active();
+    // short rows in both orientations, one lane per row, single GPU: ELL copies (SLP_CP_ELL=0 keeps the CSR walk)
+    {
+        const char *ee = getenv("SLP_CP_ELL");
+        auto width = [](i64 maxlen) { return maxlen <= 4 ? 4 : (maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : 0)); };
+        const bool small = a.nnz <= 50000000 && !(ee && ee[0] == '0') && !s->distributed && !fast_format(s->k, false) && !fast_format(s->k, true);
+        auto build = [&](const CsrDev &csr, int &W, DevBuf<i32> &ei, DevBuf<double> &ev, DevBuf<unsigned char> &el) {
+            W = width(csr.max_row_len);
+            if (!W || csr.nrow == 0) { W = 0; return; }
+            ei.alloc((size_t)W * (size_t)csr.nrow); ev.alloc((size_t)W * (size_t)csr.nrow); el.alloc((size_t)csr.nrow);
+            hipLaunchKernelGGL(k_ell_fill, dim3(grid_for(csr.nrow, kBlock)), dim3(kBlock), 0, st, csr.nrow, W, csr.ptr.p, csr.idx.p,
+                               csr.val.p, ei.p, ev.p, el.p);
+            SLP_HIP(hipGetLastError());
+        };
+        if (small && s->lanes_rows == 1) build(a, s->ell_w_rows, s->ell_idx_rows, s->ell_val_rows, s->ell_len_rows);
+        if (small && s->lanes_cols == 1) build(at, s->ell_w_cols, s->ell_idx_cols, s->ell_val_cols, s->ell_len_cols);
+    }
     if (s->n) {
         hipLaunchKernelGGL(k_cp_colsum, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p, at.val.p,
                            (i32)s->m_eq, s->m_ineq, 2.0 - s->alpha, s->t.p, s->distributed ? 0 : 1);
@@ -334,6 +435,16 @@ static void cp_primal(slp_cp *s, bool store_d) {
         hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
                            at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
                            s->m_ineq, opt, s->theta);
+    } else if (s->ell_w_cols) {
+        const int grid = grid_for(s->n, kBlock);
+#define SLP_ELL_PRIMAL(W)                                                                                                          \
+    hipLaunchKernelGGL((k_cp_primal_ell<W>), dim3(grid), dim3(kBlock), 0, st, s->n, s->ell_len_cols.p, s->ell_idx_cols.p,           \
+                       s->ell_val_cols.p, s->y.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq, s->m_ineq, opt, \
+                       s->theta)
+        if (s->ell_w_cols == 4) SLP_ELL_PRIMAL(4);
+        else if (s->ell_w_cols == 8) SLP_ELL_PRIMAL(8);
+        else SLP_ELL_PRIMAL(16);
+#undef SLP_ELL_PRIMAL
     } else {
         const int lanes = s->lanes_cols;
         const int grid = grid_for(s->n * lanes, kBlock);
@@ -352,6 +463,18 @@ static void cp_dual(slp_cp *s) {
         strip_spmv(*f, s->z.p, s->kz.p);
         hipLaunchKernelGGL(k_cp_dual_from, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->kz.p, s->b.p,
                            s->sigma.p, s->y.p, s->m_eq);
+        SLP_HIP(hipGetLastError());
+        return;
+    }
+    if (s->ell_w_rows) {
+        const int grid = grid_for(s->m, kBlock);
+#define SLP_ELL_DUAL(W)                                                                                                         \
+    hipLaunchKernelGGL((k_cp_dual_ell<W>), dim3(grid), dim3(kBlock), 0, ctx().stream, s->m, s->ell_len_rows.p, s->ell_idx_rows.p, \
+                       s->ell_val_rows.p, s->z.p, s->b.p, s->sigma.p, s->y.p, s->m_eq)
+        if (s->ell_w_rows == 4) SLP_ELL_DUAL(4);
+        else if (s->ell_w_rows == 8) SLP_ELL_DUAL(8);
+        else SLP_ELL_DUAL(16);
+#undef SLP_ELL_DUAL
         SLP_HIP(hipGetLastError());
         return;
     }
