@@ -259,6 +259,7 @@ struct slp_blocks {
     DevBuf<i64> cptr;
     DevBuf<double> b, c, lb, ub, xp, x, lam, nu, v, u, w, q, r, dir, rhs, part, scal;
     // one block per rank over a caller-owned row block (slp_blocks_create_on)
+    IterGraph cg_graph;       // `check_every` CG steps captured once (launch-bound problems)
     bool row_block = false, distributed = false;
     i64 m_eq = 0;
     DevBuf<unsigned char> used;
@@ -292,14 +293,18 @@ static void blk_cg(slp_blocks *s, Apply apply) {
     for (int it = 0; it < s->max_cg;) {
         s->scal.download(h, B_COUNT);  // one 64-byte read every `check_every` steps
         if (!(h[B_RS] > s->tol * s->tol * h[B_RHS2])) break;
-        for (int k = 0; k < s->check_every && it < s->max_cg; ++k, ++it) {
+        auto step = [&]() {
             apply(s->dir.p, s->q.p);
             blk_dot(s, m, s->dir.p, s->q.p, B_PQ, 1);
             hipLaunchKernelGGL(k_blk_step, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->dir.p, s->q.p, s->nu.p, s->r.p);
             blk_dot(s, m, s->r.p, s->r.p, B_RSNEW, 2);
             hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->r.p, s->dir.p);
-            ++s->cg_steps;
-        }
+        };
+        const int chunk = std::min(s->check_every, s->max_cg - it);
+        if (s->a->a.nnz <= 20000000) s->cg_graph.run(chunk, s->check_every, step);  // all kernel arguments are fixed pointers
+        else for (int k = 0; k < chunk; ++k) step();
+        it += chunk;
+        s->cg_steps += chunk;
     }
 }
 
@@ -372,6 +377,8 @@ slp_blocks *slp_blocks_create(int64_t P, int64_t m, int64_t N, const int64_t *in
             s->a = slp_matrix_create(m, P, indptr, indices, data);
             if (!s->a) throw Error(slp_last_error());
             build_transpose(s->a);
+            fast_format(s->a, false);  // derived formats are settled here, never inside a captured CG step
+            fast_format(s->a, true);
             s->P = P; s->m = m; s->N = N; s->gamma = gamma;
             s->owner.upload(owner, (size_t)P);
             s->cptr.upload(copy_ptr, (size_t)N + 1);
@@ -405,6 +412,8 @@ slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lo
             s->a = a; s->row_block = true; s->m = m; s->N = n; s->P = n; s->m_eq = m_eq; s->gamma = gamma;
             s->distributed = comm_active();
             build_transpose(a);
+            fast_format(a, false);
+            fast_format(a, true);
             const size_t sn = (size_t)n, sm = (size_t)m;
             // standard form (tools.py:88-127): b = [b_eq; 0], slack bounds [b_lower, b_upper]; x0 = 0 so xp0 = clamp(0) (:84-86)
             std::vector<double> hb(sm, 0.0), hlo(sm, 0.0), hhi(sm, 0.0), hx(sn), hs(sm, 0.0);
