@@ -350,6 +350,8 @@ struct slp_admm_cg {
     DevBuf<double> part, rowpart, colpart, scal, out;
     DevBuf<double> wx, wd, u2, v1;   // batched form: A x, A dir, g_eq A x + lambda (rows) and the two A^T products (2 n_o)
     bool have_w = false;
+    bool started = false;   // at least one full iteration done: the steady-state kernel sequence can be replayed
+    IterGraph graph;        // launch-bound problems: iterations replayed as a captured graph
 };
 
 namespace slp {
@@ -696,7 +698,14 @@ void slp_admm_cg_destroy(slp_admm_cg *s) {
 int slp_admm_cg_iterate(slp_admm_cg *s, int64_t k) {
     SLP_API_INT({
         SLP_REQUIRE(s && k >= 0, "slp_admm_cg_iterate: bad arguments");
-        for (i64 it = 0; it < k; ++it) { cg_xstep(s); cg_multipliers(s); }
+        auto one = [&]() { cg_xstep(s); cg_multipliers(s); s->started = true; };
+        if (k > 0 && !s->started) {  // the first iteration builds the derived formats and the shared products
+            one();
+            --k;
+        }
+        // ~30 small kernels per iteration: replay them as a graph when the matrix is cache-sized (no collectives inside)
+        if (!s->distributed && s->a->a.nnz <= 20000000) s->graph.run(k, 4, one);
+        else for (i64 it = 0; it < k; ++it) one();
     })
 }
 
@@ -706,12 +715,16 @@ int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse) {
         if (reuse && s->mx.n < (size_t)s->N) { s->mx.alloc((size_t)s->N); s->md.alloc((size_t)s->N); s->mx.zero(); s->md.zero(); }
         s->reuse = reuse < 0 ? 0 : (reuse > 2 ? 2 : reuse);
         s->have_w = false;
+        s->started = false;
+        s->graph.reset();
     })
 }
 
 int slp_admm_cg_xstep(slp_admm_cg *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cg_xstep(s); }) }
 
-int slp_admm_cg_multiplier_step(slp_admm_cg *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cg_multipliers(s); }) }
+int slp_admm_cg_multiplier_step(slp_admm_cg *s) {
+    SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cg_multipliers(s); s->started = true; })
+}
 
 int slp_admm_cg_report(slp_admm_cg *s, double out[3]) {
     SLP_API_INT({
