@@ -164,3 +164,16 @@ def test_matrix_entry_points_on_empty_matrices():
         assert dm.nnz == 0
         assert np.array_equal(dm.matvec(np.ones(shape[1])), np.zeros(shape[0]))
         assert np.array_equal(dm.rmatvec(np.ones(shape[0])), np.zeros(shape[1]))
+
+
+def test_randomised_lps_all_host_api_solvers():
+    """tools/fuzz_solvers.py: 40 random small LPs (empty rows / columns, one- and two-sided rows, infinite bounds, with and
+    without equalities, warm starts, odd reporting cadences) through lp_admm (both Gauss-Seidel forms), chambolle_pock_ppd --
+    bit for bit -- and the matrix-free and block-splitting ADMM within their tolerances."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_solvers
+
+    assert fuzz_solvers.run(40, seed=11) == 40
