@@ -216,6 +216,41 @@ __global__ void k_rb_consensus(i64 n, const unsigned char *__restrict__ used, co
     }
 }
 
+// ---- primal form of the projection, all rows inequalities and at least as many rows as columns:
+// min |x - v|^2 + |A x - vs|^2  <=>  (I + A^T A) x = v + A^T vs ,  s = A x.  Same projection as the dual form
+// (A A^T + I) nu = A v - vs, x = v - A^T nu, but the matrix has no unit eigenvalues from the rank deficit of A A^T:
+// condition (1 + smax^2) / (1 + smin^2) instead of 1 + smax^2 -- about a third of the CG steps on the C3 LP.
+__global__ void k_rb_vs(i64 m, const double *__restrict__ xps, const double *__restrict__ lams, double gamma, double *__restrict__ vs) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) vs[i] = xps[i] - lams[i] / gamma;
+}
+
+// rhs = v + u (u = A^T vs) ; r = rhs - (xsol + q) (q = A^T A xsol) ; dir = r
+__global__ void k_rb_resid0_primal(i64 n, const double *__restrict__ v, const double *__restrict__ u, const double *__restrict__ xsol,
+                                   const double *__restrict__ q, double *__restrict__ r, double *__restrict__ dir, double *__restrict__ rhs) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        const double f = v[j] + u[j];
+        rhs[j] = f;
+        const double rj = f - (xsol[j] + q[j]);
+        r[j] = rj;
+        dir[j] = rj;
+    }
+}
+
+__global__ void k_rb_add_vec(i64 n, const double *__restrict__ a, double *__restrict__ q) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) q[j] = q[j] + a[j];
+}
+
+// x = alpha xv + (1 - alpha) xp ; acc = used ? x + lambda / gamma : 0
+__global__ void k_rb_x_primal(i64 n, const unsigned char *__restrict__ used, const double *__restrict__ xp, const double *__restrict__ xv,
+                              const double *__restrict__ lam, double alpha, double one_minus_alpha, double gamma, double *__restrict__ x,
+                              double *__restrict__ acc) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        const double xj = alpha * xv[j] + one_minus_alpha * xp[j];
+        x[j] = xj;
+        acc[j] = used[j] ? (0.0 + (xj + lam[j] / gamma)) : 0.0;
+    }
+}
+
 __global__ void k_rb_used(i64 n, const i64 *__restrict__ tptr, unsigned char *__restrict__ used, double *__restrict__ copies) {
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
         const unsigned char u = tptr[j + 1] > tptr[j] ? 1 : 0;
@@ -264,6 +299,8 @@ struct slp_blocks {
     i64 m_eq = 0;
     DevBuf<unsigned char> used;
     DevBuf<double> copies, acc, vs, xs, xps, lams, slo, shi;
+    bool primal = false;      // projection solved in the primal form (I + A^T A), see k_rb_resid0_primal
+    DevBuf<double> xsol, zero_m;
 };
 
 namespace slp {
@@ -283,9 +320,10 @@ static void blk_apply(slp_blocks *s, const double *dir, double *q) {
 
 // the conjugate-gradient loop shared by both layouts; `apply(dir, q)` computes q = S dir
 template <class Apply>
-static void blk_cg(slp_blocks *s, Apply apply) {
+static void blk_cg(slp_blocks *s, Apply apply, i64 len = -1, double *sol = nullptr) {
     hipStream_t st = ctx().stream;
-    const i64 m = s->m;
+    const i64 m = len < 0 ? s->m : len;   // length of the system (rows: dual form; original variables: primal form)
+    if (!sol) sol = s->nu.p;
     const int gm = grid_for(m, kBlock);
     blk_dot(s, m, s->rhs.p, s->rhs.p, B_RHS2, 0);
     blk_dot(s, m, s->r.p, s->r.p, B_RS, 0);
@@ -296,7 +334,7 @@ static void blk_cg(slp_blocks *s, Apply apply) {
         auto step = [&]() {
             apply(s->dir.p, s->q.p);
             blk_dot(s, m, s->dir.p, s->q.p, B_PQ, 1);
-            hipLaunchKernelGGL(k_blk_step, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->dir.p, s->q.p, s->nu.p, s->r.p);
+            hipLaunchKernelGGL(k_blk_step, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->dir.p, s->q.p, sol, s->r.p);
             blk_dot(s, m, s->r.p, s->r.p, B_RSNEW, 2);
             hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->r.p, s->dir.p);
         };
@@ -317,6 +355,29 @@ static void rb_iteration(slp_blocks *s) {
         if (m > me) hipLaunchKernelGGL(k_rb_add_identity, dim3(grid_for(m - me, kBlock)), dim3(kBlock), 0, st, m, me, dir, q);
     };
     hipLaunchKernelGGL(k_rb_v, dim3(gn), dim3(kBlock), 0, st, n, s->xp.p, s->lam.p, s->gamma, s->v.p);
+    if (s->primal) {
+        auto apply_p = [&](const double *dir, double *q) {  // q = dir + A^T (A dir)
+            matrix_spmv(s->a, false, dir, s->w.p, SLP_ORDER_AUTO);
+            matrix_spmv(s->a, true, s->w.p, q, SLP_ORDER_AUTO);
+            hipLaunchKernelGGL(k_rb_add_vec, dim3(gn), dim3(kBlock), 0, st, n, dir, q);
+        };
+        hipLaunchKernelGGL(k_rb_vs, dim3(gm), dim3(kBlock), 0, st, m, s->xps.p, s->lams.p, s->gamma, s->vs.p);
+        matrix_spmv(s->a, true, s->vs.p, s->u.p, SLP_ORDER_AUTO);
+        matrix_spmv(s->a, false, s->xsol.p, s->w.p, SLP_ORDER_AUTO);
+        matrix_spmv(s->a, true, s->w.p, s->q.p, SLP_ORDER_AUTO);
+        hipLaunchKernelGGL(k_rb_resid0_primal, dim3(gn), dim3(kBlock), 0, st, n, s->v.p, s->u.p, s->xsol.p, s->q.p, s->r.p, s->dir.p, s->rhs.p);
+        blk_cg(s, apply_p, n, s->xsol.p);
+        matrix_spmv(s->a, false, s->xsol.p, s->w.p, SLP_ORDER_AUTO);  // the projected slacks s = A x
+        hipLaunchKernelGGL(k_rb_x_primal, dim3(gn), dim3(kBlock), 0, st, n, s->used.p, s->xp.p, s->xsol.p, s->lam.p, s->alpha, 1.0 - s->alpha,
+                           s->gamma, s->x.p, s->acc.p);
+        hipLaunchKernelGGL(k_rb_slack, dim3(gm), dim3(kBlock), 0, st, m, (i64)0, s->w.p, s->zero_m.p, s->slo.p, s->shi.p, s->alpha,
+                           1.0 - s->alpha, s->gamma, s->xs.p, s->xps.p, s->lams.p);
+        if (s->distributed) comm_allreduce_dev(s->acc.p, n, 0);
+        hipLaunchKernelGGL(k_rb_consensus, dim3(gn), dim3(kBlock), 0, st, n, s->used.p, s->copies.p, s->acc.p, s->c.p, s->lb.p, s->ub.p,
+                           s->x.p, s->gamma, s->xp.p, s->lam.p);
+        SLP_HIP(hipGetLastError());
+        return;
+    }
     if (m > 0) {
         matrix_spmv(s->a, false, s->v.p, s->w.p, SLP_ORDER_AUTO);
         blk_apply(s, s->nu.p, s->q.p);
@@ -428,7 +489,12 @@ slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lo
             s->c.upload(c, sn); s->lb.upload(lb, sn); s->ub.upload(ub, sn); s->xp.upload(hx.data(), sn);
             s->x.alloc(sn); s->lam.alloc(sn); s->lam.zero(); s->v.alloc(sn); s->u.alloc(sn); s->acc.alloc(sn);
             s->used.alloc(sn); s->copies.alloc(sn);
-            s->nu.alloc(sm); s->nu.zero(); s->w.alloc(sm); s->q.alloc(sm); s->r.alloc(sm); s->dir.alloc(sm); s->rhs.alloc(sm);
+            // all rows inequalities and m >= n: the better-conditioned primal form of the projection (SLP_BLOCKS_PRIMAL=0/1 forces)
+            const char *ep = getenv("SLP_BLOCKS_PRIMAL");
+            s->primal = m_eq == 0 && m > 0 && (ep ? ep[0] == '1' : m >= n);
+            const size_t sv = std::max(sn, sm);  // the CG vectors serve whichever form is used
+            s->nu.alloc(sm); s->nu.zero(); s->w.alloc(sm); s->q.alloc(sv); s->r.alloc(sv); s->dir.alloc(sv); s->rhs.alloc(sv);
+            if (s->primal) { s->xsol.alloc(sn); s->xsol.zero(); s->zero_m.alloc(sm); s->zero_m.zero(); }
             s->vs.alloc(sm); s->xs.alloc(sm); s->xs.zero(); s->lams.alloc(sm); s->lams.zero();
             s->part.alloc(kBlkPartials); s->scal.alloc(B_COUNT); s->scal.zero();
             // which columns this row block uses (a copy exists only for those, :183-185) and in how many ranks' blocks

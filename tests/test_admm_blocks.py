@@ -106,8 +106,9 @@ def test_gpu_reporting_cadence_and_solve_method():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m_eq", [300, 0])  # with equality rows: dual form (A A^T + I); all inequalities, m >= n: primal form (I + A^T A)
 @pytest.mark.parametrize("min_nnz", ["1", "100000000000"])  # strip kernels / CSR kernels
-def test_gpu_row_block_solver_matches_oracle(monkeypatch, min_nnz):
+def test_gpu_row_block_solver_matches_oracle(monkeypatch, min_nnz, m_eq):
     """DeviceBlocks: the rows of a device-generated LP as ONE block (what a rank holds in the multi-GPU form), equality rows
     and two-sided rows included, slack column implicit -- against the oracle's LU form with the single block [0, m - 1].
     (The partitioned code path with the consensus all-reduce is exercised in tests/test_gpu_comm.py.)"""
@@ -115,7 +116,7 @@ def test_gpu_row_block_solver_matches_oracle(monkeypatch, min_nnz):
     from pysparselp_amd.scale import DeviceBlocks
 
     monkeypatch.setenv("SLP_STRIP_MIN_NNZ", min_nnz)
-    n, m, p, m_eq = 3000, 4000, 0.004, 300
+    n, m, p = 3000, 4000, 0.004
     a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=5)
     s = a.download()
     ax = a.matvec(xf)
@@ -124,12 +125,18 @@ def test_gpu_row_block_solver_matches_oracle(monkeypatch, min_nnz):
     b[:m_eq] = ax[:m_eq]
     bl = np.where(rng.rand(m) < 0.5, -np.inf, ax - rng.rand(m))
     ae, ai = s[:m_eq], s[m_eq:]
-    xo = oracle.lp_admm_block_decomposition(c, ae, b[:m_eq], ai, bl[m_eq:], b[m_eq:], lb, ub, nb_iter=29, nb_iter_plot=10 ** 9,
-                                            blocks_eq=[(0, m - 1)], blocks_ineq=[])
+    xo = oracle.lp_admm_block_decomposition(c, ae if m_eq else None, b[:m_eq] if m_eq else None, ai, bl[m_eq:], b[m_eq:], lb, ub,
+                                            nb_iter=29, nb_iter_plot=10 ** 9, blocks_eq=[(0, m - 1)], blocks_ineq=[])
     sol = DeviceBlocks(a, b, c, lb, ub, m_eq=m_eq, b_lower=bl)
     sol.iterate(30)
     x = sol.x()
     assert 30 < sol.cg_steps() < 30 * 500
     sol.close()
     assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-8
+    if m_eq == 0:  # the two forms of the projection give the same iterates
+        monkeypatch.setenv("SLP_BLOCKS_PRIMAL", "0")
+        sol = DeviceBlocks(a, b, c, lb, ub, m_eq=0, b_lower=bl)
+        sol.iterate(30)
+        assert np.max(np.abs(sol.x() - x) / (1 + np.abs(x))) < 1e-9
+        sol.close()
     a.close()
