@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
                                                                          const unsigned char *__restrict__ slen,
                                                                          const unsigned int *__restrict__ soff,
                                                                          const unsigned short *__restrict__ ent,
-                                                                         const double *__restrict__ dict, int D, int cap,
+                                                                         const double *__restrict__ dict, int D,
                                                                          const double *__restrict__ x0, const double *__restrict__ x1,
                                                                          double *__restrict__ out0, double *__restrict__ out1) {
     __shared__ double xt[NV][kDictC];
@@ -453,8 +453,7 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
             }
         }
         const ushort2 r = r_next;
-        unsigned int n0 = nn_next.x, n1 = nn_next.y;  // n0 >= n1 (sorted)
-        if (n0 > (unsigned int)cap) n0 = cap;  // timing experiments only (SLP_DSTRIP_CAP): wrong sums
+        const unsigned int n0 = nn_next.x, n1 = nn_next.y;  // n0 >= n1 (sorted)
         const uint2 *__restrict__ e2 = reinterpret_cast<const uint2 *>(ent) + (base_next >> 1);
         __syncthreads();
         if (t + 1 < t_end) prefetch(t + 1);
@@ -844,11 +843,6 @@ bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int varian
     return variant == 2 ? strip_build_c<kQuadC, 4>(a, f, dict) : strip_build_c<kDictC, 2>(a, f, dict);
 }
 
-static int dstrip_cap() {
-    const char *e = getenv("SLP_DSTRIP_CAP");
-    return e ? atoi(e) : 255;
-}
-
 static void wide_launch(const StripJds &f, int nv, const double *x0, const double *x1, double *o0, double *o1) {
     const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
     hipStream_t st = ctx().stream;
@@ -877,15 +871,20 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
                                (double *)nullptr);
         else
         hipLaunchKernelGGL((k_dstrip_spmv<1>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T,
-                           f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, dstrip_cap(), x, x, f.S > 1 ? f.part.p : out,
+                           f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
                            (double *)nullptr);
         if (f.S > 1)
             hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
         SLP_HIP(hipGetLastError());
         return;
     }
-    const char *e = getenv("SLP_STRIP_ABLATE");
+    const char *e = getenv("SLP_STRIP_ABLATE");  // tools/ablate_strip.py only: the ablated kernels return WRONG sums
     const int ab = e ? atoi(e) : 0;
+    if (ab) {
+        static bool warned = false;
+        if (!warned) fprintf(stderr, "libslp_hip: SLP_STRIP_ABLATE=%d -- timing experiment, SpMV results are wrong\n", ab);
+        warned = true;
+    }
 #define SLP_STRIP_LAUNCH(A)                                                                                                        \
     hipLaunchKernelGGL((k_strip_spmv<A>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, \
                        f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out)
@@ -917,7 +916,7 @@ void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *
                            f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1);
     else if (f.D > 0)
         hipLaunchKernelGGL((k_dstrip_spmv<2>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
-                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, dstrip_cap(), x0, x1, o0, o1);
+                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1);
     else
         hipLaunchKernelGGL(k_strip_spmv2, dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
                            f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x0, x1, o0, o1);

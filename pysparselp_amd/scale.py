@@ -10,6 +10,31 @@ from . import _lib
 from ._lib import ORDER_AUTO
 
 
+def one_sided_rows(m, m_eq, b_lower, b_upper):
+    """Row plan of the one-sided stacking  b_lower <= A_ineq x <= b_upper  ->  K x <= b  (ChambollePockPPD.py:74-88):
+    ``(rows, scale, b)`` with K's row r = ``scale[r] *`` row ``rows[r]`` -- the equality rows (the first ``m_eq``), the rows
+    with a finite upper bound, then the negated rows with a finite lower bound -- or ``None`` when no lower bound is
+    finite (the matrix is used as it is).  With no finite upper bound every inequality row is negated (:82-83)."""
+    ineq = np.arange(m_eq, m)
+    up = ineq[b_upper[m_eq:] != np.inf]
+    lo = ineq[b_lower[m_eq:] != -np.inf]
+    if len(lo) == 0:
+        return None
+    eq = np.arange(m_eq)
+    if len(up) > 0:
+        rows = np.concatenate((eq, up, lo))
+        scale = np.concatenate((np.ones(m_eq + len(up)), -np.ones(len(lo))))
+        b = np.concatenate((b_upper[:m_eq], b_upper[up], -b_lower[lo]))
+    else:
+        if len(lo) != m - m_eq:
+            raise ValueError("rows without any finite bound next to lower-bounded rows: the reference's stacking is "
+                             "inconsistent here (ChambollePockPPD.py:80-86); drop the unbounded rows first")
+        rows = np.arange(m)
+        scale = np.concatenate((np.ones(m_eq), -np.ones(m - m_eq)))
+        b = np.concatenate((b_upper[:m_eq], -b_lower[lo]))
+    return rows.astype(np.int64), scale, np.ascontiguousarray(b)
+
+
 class DeviceCP:
     """Chambolle-Pock (reference ChambollePockPPD.py:195-343) on a DeviceMatrix."""
 
@@ -26,29 +51,12 @@ class DeviceCP:
                                                              _lib.ptr(ub), None, float(alpha), float(theta), int(order)))
 
     def _one_sided(self, a, m_eq, b_lower, b_upper):
-        """b_lower <= A_ineq x <= b_upper  ->  K x <= b on the device (ChambollePockPPD.py:74-88): the rows with a finite upper
-        bound, then the negated rows with a finite lower bound; equality rows (the first m_eq) stay in front.  With no finite
-        lower bound the matrix is left as it is; with no finite upper bound every inequality row is negated (:80-86)."""
-        m = a.shape[0]
-        ineq = np.arange(m_eq, m)
-        up = ineq[b_upper[m_eq:] != np.inf]
-        lo = ineq[b_lower[m_eq:] != -np.inf]
-        if len(lo) == 0:
+        plan = one_sided_rows(a.shape[0], m_eq, b_lower, b_upper)
+        if plan is None:
             return a, b_upper
-        eq = np.arange(m_eq)
-        if len(up) > 0:
-            rows = np.concatenate((eq, up, lo))
-            scale = np.concatenate((np.ones(m_eq + len(up)), -np.ones(len(lo))))
-            b = np.concatenate((b_upper[:m_eq], b_upper[up], -b_lower[lo]))
-        else:
-            rows = np.arange(m)
-            scale = np.concatenate((np.ones(m_eq), -np.ones(m - m_eq)))
-            b = np.concatenate((b_upper[:m_eq], -b_lower[lo]))
-            if len(lo) != m - m_eq:
-                raise ValueError("rows without any finite bound next to lower-bounded rows: the reference's stacking is "
-                                 "inconsistent here (ChambollePockPPD.py:80-86); drop the unbounded rows first")
+        rows, scale, b = plan
         self._stacked = a.gather_rows(rows, scale)
-        return self._stacked, np.ascontiguousarray(b)
+        return self._stacked, b
 
     def close(self):
         if getattr(self, "_h", None):

@@ -147,3 +147,43 @@ def test_modelling_equalities_and_fixed_variables():
     assert lp.b_lower is None and np.array_equal(lp.b_upper, [1.0]) and np.array_equal(lp.a_inequalities.data, [-1.0])
     with pytest.raises(ValueError):
         lp.solve(method="mehrotra")
+
+
+def test_one_sided_row_plan_matches_the_reference_stacking():
+    """scale.one_sided_rows (the plan slp_matrix_gather_rows executes on the device) against the oracle's restatement of
+    ChambollePockPPD.py:74-88 on the host."""
+    import scipy.sparse
+    from oracle import oracle
+    from pysparselp_amd.scale import one_sided_rows
+
+    rng = np.random.RandomState(3)
+    m, n = 40, 17
+    a = scipy.sparse.random(m, n, density=0.3, random_state=rng, format="csr")
+    a.sort_indices()
+    for case in ("mixed", "upper_only", "lower_only"):
+        bu = rng.rand(m)
+        bl = bu - 1 - rng.rand(m)
+        if case == "mixed":
+            bl[rng.rand(m) < 0.4] = -np.inf
+            bu[(rng.rand(m) < 0.3) & np.isfinite(bl)] = np.inf
+        elif case == "upper_only":
+            bl[:] = -np.inf
+        else:
+            bu[:] = np.inf
+        plan = one_sided_rows(m, 0, bl, bu)
+        k, b = oracle.one_sided(a, bl, bu)
+        if case == "upper_only":
+            assert plan is None
+            continue
+        rows, scale, bb = plan
+        got = (scipy.sparse.diags(scale) @ a[rows]).tocsr()
+        got.sort_indices()
+        ref = scipy.sparse.csr_matrix((k.data, k.indices, k.indptr), shape=k.shape)
+        assert got.shape == ref.shape and np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+        assert np.array_equal(got.data, ref.data) and np.array_equal(bb, b)
+    # equality rows stay in front and are never negated
+    rows, scale, bb = one_sided_rows(6, 2, np.array([0, 0, -1.0, -np.inf, -2.0, -np.inf]), np.array([5.0, 6.0, 1.0, 2.0, np.inf, 3.0]))
+    assert rows.tolist() == [0, 1, 2, 3, 5, 2, 4] and scale.tolist() == [1, 1, 1, 1, 1, -1, -1]
+    assert bb.tolist() == [5.0, 6.0, 1.0, 2.0, 3.0, 1.0, 2.0]
+    with pytest.raises(ValueError):
+        one_sided_rows(3, 0, np.array([-1.0, -np.inf, -1.0]), np.full(3, np.inf))
