@@ -168,6 +168,16 @@ __global__ __launch_bounds__(kBlock) void k_cg_finish(int nparts, const double *
     }
 }
 
+// reuse level 3: dir_new = step dir + a_cg r (E_LINE_STEP, E_UPDATE), so A dir_new = step (A dir) + a_cg (A r) without a product
+__global__ void k_cg_wd_update(i64 m, const double *__restrict__ scal, const double *__restrict__ w, double *__restrict__ wd) {
+    const double t = -(scal[S_T] + scal[S_T + 1]);
+    const bool on = fabs(t) > 0.0;
+    const double step = t / (scal[S_DMD] + scal[S_DMD + 1]);
+    const double acg = (scal[S_RS] + scal[S_RS + 1]) / (scal[S_PAP] + scal[S_PAP + 1]);
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x)
+        wd[i] = (on ? step * wd[i] : 0.0) + acg * w[i];
+}
+
 // lambda_eq_i += gamma_eq (w_i - b_i)  (:261-263), w = A x
 __global__ void k_cg_multiplier(i64 m, const double *__restrict__ w, const double *__restrict__ b, double gamma_eq,
                                 double *__restrict__ lam, double *__restrict__ v1) {
@@ -342,7 +352,9 @@ struct slp_admm_cg {
     double gamma_eq = 2, gamma_ineq = 3, alpha = 1.4;
     int order = SLP_ORDER_AUTO, lanes_rows = 1, lanes_cols = 1;
     bool distributed = false;
+    int since_refresh = 0; // level 3: iterations since A dir was last taken as a product
     int reuse = 0;        // 0: ten products as written; 1: CG residual from the line search's products (8);
+                          // 3: additionally A dir by recurrence from A dir_old and A r (5 products; exact refresh every 64 iterations)
                           // 2: additionally A^T (g_eq A x + lambda_eq) as one product (6 products, 4 passes with strips)
     DevBuf<double> sc, b, lam, w;                                         // rows
     DevBuf<double> rs, ws0, ws1;   // deferred row scaling (value-dictionary strips): A = diag(rs) A0; scratch rs o w
@@ -507,6 +519,10 @@ static void cg_xstep(slp_admm_cg *s) {
         cg_elem<E_RESID_FUSED>(s, S_RS);
         cg_rows(s, s->r.p); cg_cols(s, s->w.p); cg_elem<E_PAP>(s, S_PAP);
         cg_elem<E_UPDATE>(s, -1);
+        if (s->reuse >= 3) {  // w still holds A r
+            hipLaunchKernelGGL(k_cg_wd_update, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->scal.p, s->w.p, s->wd.p);
+            SLP_HIP(hipGetLastError());
+        }
         s->have_w = false;
         return;
     }
@@ -538,8 +554,13 @@ static void cg_xstep(slp_admm_cg *s) {
 static void cg_multipliers(slp_admm_cg *s) {
     cg_elem<E_PROJECT>(s, -1);
     const double *ax = s->w.p;
-    if (cg_batched(s)) {
+    if (s->reuse >= 3 && cg_batched(s) && s->wx.n >= (size_t)s->m && ++s->since_refresh < 64) {
+        cg_rows(s, s->x.p, s->wx.p);  // A dir came from the recurrence (k_cg_wd_update): one product, one vector
+        s->have_w = true;
+        ax = s->wx.p;
+    } else if (cg_batched(s)) {
         cg_refresh_products(s);   // A x for the multiplier AND, with A dir, for the next line search
+        s->since_refresh = 0;
         ax = s->wx.p;
     } else {
         cg_rows(s, s->x.p);
@@ -704,7 +725,7 @@ int slp_admm_cg_iterate(slp_admm_cg *s, int64_t k) {
             --k;
         }
         // ~30 small kernels per iteration: replay them as a graph when the matrix is cache-sized (no collectives inside)
-        if (!s->distributed && s->a->a.nnz <= 20000000) s->graph.run(k, 4, one);
+        if (!s->distributed && s->a->a.nnz <= 20000000 && s->reuse < 3) s->graph.run(k, 4, one);  // (level 3 alternates two sequences)
         else for (i64 it = 0; it < k; ++it) one();
     })
 }
@@ -713,7 +734,8 @@ int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse) {
     SLP_API_INT({
         SLP_REQUIRE(s, "NULL handle");
         if (reuse && s->mx.n < (size_t)s->N) { s->mx.alloc((size_t)s->N); s->md.alloc((size_t)s->N); s->mx.zero(); s->md.zero(); }
-        s->reuse = reuse < 0 ? 0 : (reuse > 2 ? 2 : reuse);
+        s->reuse = reuse < 0 ? 0 : (reuse > 3 ? 3 : reuse);
+        s->since_refresh = 0;
         s->have_w = false;
         s->started = false;
         s->graph.reset();
