@@ -210,6 +210,8 @@ void slp_admm_cg_destroy(slp_admm_cg *s);
  * 2  six: additionally A^T (g_eq A x + lambda_eq) is one product (y = ... - A^T lambda_eq is never formed);
  * 3  five: additionally A dir of the new direction dir = step dir_old + a_cg r is step (A dir_old) + a_cg (A r)
  *    (both at hand); taken as a product again every 64 iterations so that the recurrence cannot drift.
+ * 4  four: additionally M dir = step (M dir_old) + a_cg (M r) (M r is computed for the CG step anyway), so the A^T pass
+ *    of the line search carries one vector; refreshed together with A dir.
  * With the strip kernels, A [x, dir] and the two A^T products of the line search each share ONE sweep over the
  * matrix (two-vector pass): 5 sweeps at level 1, 4 at level 2. */
 int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse);

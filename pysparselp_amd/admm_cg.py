@@ -31,7 +31,9 @@ class _CGBase:
         1 -- eight: the CG residual ``y - M(x + t d)`` is formed from ``M x`` and ``M d`` of the line search;
         2 -- six: additionally ``A^T (g_eq A x + lambda_eq)`` is one product instead of two;
         3 -- five: additionally ``A d`` of the new direction ``d = t d_old + a r`` comes from ``A d_old`` and ``A r``
-             (taken as a product again every 64 iterations)."""
+             (taken as a product again every 64 iterations);
+        4 -- four: additionally ``M d = step M d_old + a M r`` (``M r`` is computed for the CG step anyway), so the
+             ``A^T`` pass of the line search carries one vector too (refreshed with ``A d``)."""
         reuse = int(reuse)
         _lib.check(self._l.slp_admm_cg_set_reuse(self._h, reuse))
         self.reuse = reuse
@@ -74,7 +76,7 @@ class DeviceADMM(_CGBase):
     ``a_i x <= b_i``.  Setup transforms run on the device and scale the matrix IN PLACE (the DeviceMatrix then
     holds the row-normalised values)."""
 
-    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO, reuse=3, m_eq=0, b_lower=None):
+    def __init__(self, a, b_upper, c, lb, ub, gamma_eq=2.0, gamma_ineq=3.0, order=ORDER_AUTO, reuse=4, m_eq=0, b_lower=None):
         self._l = _lib.lib()
         self.a = a
         self.n = a.shape[1]
@@ -98,12 +100,12 @@ class DeviceADMM(_CGBase):
         return bool(self.reuse and l.slp_matrix_spmv_kernel(self.a._h, 0) >= 1 and l.slp_matrix_spmv_kernel(self.a._h, 1) >= 1)
 
     def matrix_products_per_iteration(self):
-        return {0: 10, 1: 8, 2: 6, 3: 5}[self.reuse]
+        return {0: 10, 1: 8, 2: 6, 3: 5, 4: 4}[self.reuse]
 
     def matrix_passes_per_iteration(self):
         if not self.two_vector_passes():
             return self.matrix_products_per_iteration()
-        return {1: 5, 2: 4, 3: 4}[self.reuse]  # level 3: one of the four passes carries one vector instead of two
+        return {1: 5, 2: 4, 3: 4, 4: 4}[self.reuse]  # levels 3 / 4: one / both two-vector passes carry a single vector
 
     def describe(self):
         return ("ADMM, matrix-free conjugate-gradient x-step of the reference (ADMM.py:182-201), gamma_eq=2, gamma_ineq=3, "

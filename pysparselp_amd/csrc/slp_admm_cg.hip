@@ -67,12 +67,13 @@ __device__ __forceinline__ double at_elem(i64 j, i64 n_o, const double *__restri
 
 // Elementwise passes over the N unknowns.  Each also produces one dot product, split into the part over
 // the replicated original variables (slot) and the part over this rank's slack variables (slot + 1).
-enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7, E_RESID_REUSE = 8, E_GRAD = 9, E_RESID_FUSED = 10 };
+enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7, E_RESID_REUSE = 8, E_GRAD = 9, E_RESID_FUSED = 10, E_LINE_DMD_MD = 11 };
 
 struct CgVecs {
     const double *q, *c, *lb, *ub, *u, *sc, *w;
     double *x, *xp, *y, *dir, *xprev, *r, *lin, *mx, *md;
     int keep;  // store M x and M dir for E_RESID_REUSE
+    int carry_md;  // reuse level 4: E_PAP stores M r (in y), E_UPDATE advances M dir = step M dir + a_cg M r
     const double *scal;
     i64 n_o, N;
     double gamma_eq, gamma_ineq, alpha, one_minus_alpha;
@@ -90,6 +91,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
         f = t / (a.scal[S_DMD] + a.scal[S_DMD + 1]);             // :193
     }
     if (OP == E_UPDATE) f = (a.scal[S_RS] + a.scal[S_RS + 1]) / (a.scal[S_PAP] + a.scal[S_PAP + 1]);  // conjgrad :38
+    double step = 0.0;  // E_UPDATE with carry_md: the line-search step of this iteration (0 when it was skipped)
+    if (OP == E_UPDATE && a.carry_md) {
+        const double t = -(a.scal[S_T] + a.scal[S_T + 1]);
+        step = fabs(t) > 0.0 ? t / (a.scal[S_DMD] + a.scal[S_DMD + 1]) : 0.0;
+    }
     for (i64 j = (i64)blockIdx.x * kBlock + threadIdx.x; j < a.N; j += (i64)gridDim.x * kBlock) {
         double term = 0.0;
         if (OP == E_RHS) {  // y = -c + g_eq A^T b + g_ineq xp - A^T lambda_eq - lambda_ineq (:148) ; xprev = x (:184)
@@ -104,6 +110,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
             const double md = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.dir[j];
             if (a.keep) a.md[j] = md;
             term = a.dir[j] * md;
+        } else if (OP == E_LINE_DMD_MD) {  // the same with M dir carried by the recurrence (reuse level 4)
+            term = a.dir[j] * a.md[j];
         } else if (OP == E_LINE_STEP) {  // x = x + step * dir (:194)
             if (on) a.x[j] = a.x[j] + f * a.dir[j];
         } else if (OP == E_RESID) {  // r = y - M x ; p = r ; rsold = r.r (conjgrad :33-35)
@@ -127,9 +135,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
             term = r * r;
         } else if (OP == E_PAP) {  // p.(M p) (conjgrad :37-38)
             const double ap = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.r[j];
+            if (a.carry_md) a.y[j] = ap;  // y is free in the fused form
             term = a.r[j] * ap;
         } else if (OP == E_UPDATE) {  // x += alpha_cg p (:39) ; speed = x - xprev (:200) ; x = 1.4 x + (1-1.4) xp (:201)
             const double xn = a.x[j] + f * a.r[j];
+            if (a.carry_md) a.md[j] = step * a.md[j] + f * a.y[j];  // dir_new = step dir + a_cg r  =>  M dir_new likewise
             a.dir[j] = xn - a.xprev[j];
             a.x[j] = a.alpha * xn + a.one_minus_alpha * a.xp[j];
         } else if (OP == E_PROJECT) {  // xp = clip(x + lambda_ineq / g_ineq) ; lambda_ineq += g_ineq (x - xp) (:253-256)
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
         else acc_s += term;
     }
     if (OP == E_LINE_T || OP == E_LINE_DMD || OP == E_RESID || OP == E_RESID_REUSE || OP == E_PAP || OP == E_GRAD ||
-        OP == E_RESID_FUSED) {
+        OP == E_RESID_FUSED || OP == E_LINE_DMD_MD) {
         const double ro = block_reduce<false>(acc_o, lds), rs = block_reduce<false>(acc_s, lds);
         if (threadIdx.x == 0) {
             part[blockIdx.x * 2] = ro;
@@ -353,6 +363,7 @@ struct slp_admm_cg {
     int order = SLP_ORDER_AUTO, lanes_rows = 1, lanes_cols = 1;
     bool distributed = false;
     int since_refresh = 0; // level 3: iterations since A dir was last taken as a product
+    bool need_md = true;   // level 4: M dir must come from a product in the next x-step (start, and after every refresh)
     int reuse = 0;        // 0: ten products as written; 1: CG residual from the line search's products (8);
                           // 3: additionally A dir by recurrence from A dir_old and A r (5 products; exact refresh every 64 iterations)
                           // 2: additionally A^T (g_eq A x + lambda_eq) as one product (6 products, 4 passes with strips)
@@ -465,7 +476,7 @@ static CgVecs cg_vecs(slp_admm_cg *s, const double *u, const double *w) {
     v.u = u ? u : s->u.p;   // (A^T .) over the original variables ...
     v.w = w ? w : s->w.p;   // ... and the row vector whose slack column gives the rest: sc_i * w_i
     v.x = s->x.p; v.xp = s->xp.p; v.y = s->y.p; v.dir = s->dir.p; v.xprev = s->xprev.p; v.r = s->r.p; v.lin = s->lin.p;
-    v.mx = s->mx.p; v.md = s->md.p; v.keep = s->reuse ? 1 : 0;
+    v.mx = s->mx.p; v.md = s->md.p; v.keep = s->reuse ? 1 : 0; v.carry_md = s->reuse >= 4 ? 1 : 0;
     v.scal = s->scal.p; v.n_o = s->n_o; v.N = s->N;
     v.gamma_eq = s->gamma_eq; v.gamma_ineq = s->gamma_ineq; v.alpha = s->alpha; v.one_minus_alpha = 1.0 - s->alpha;
     return v;
@@ -512,9 +523,17 @@ static void cg_xstep(slp_admm_cg *s) {
                                s->gamma_eq, s->v1.p);
             SLP_HIP(hipGetLastError());
         }
-        cg_cols2(s, s->v1.p, s->wd.p, s->u2.p);
-        cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p);
-        cg_elem<E_LINE_DMD>(s, S_DMD, s->u2.p + s->n_o, s->wd.p);
+        if (s->reuse >= 4 && !s->need_md) {
+            // level 4: M dir = step M dir_old + a_cg M r was advanced in E_UPDATE: the A^T pass carries one vector
+            cg_cols(s, s->v1.p, s->u2.p);
+            cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p);
+            cg_elem<E_LINE_DMD_MD>(s, S_DMD);
+        } else {
+            cg_cols2(s, s->v1.p, s->wd.p, s->u2.p);
+            cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p);
+            cg_elem<E_LINE_DMD>(s, S_DMD, s->u2.p + s->n_o, s->wd.p);
+            s->need_md = false;
+        }
         cg_elem<E_LINE_STEP>(s, -1);
         cg_elem<E_RESID_FUSED>(s, S_RS);
         cg_rows(s, s->r.p); cg_cols(s, s->w.p); cg_elem<E_PAP>(s, S_PAP);
@@ -561,6 +580,7 @@ static void cg_multipliers(slp_admm_cg *s) {
     } else if (cg_batched(s)) {
         cg_refresh_products(s);   // A x for the multiplier AND, with A dir, for the next line search
         s->since_refresh = 0;
+        s->need_md = true;
         ax = s->wx.p;
     } else {
         cg_rows(s, s->x.p);
@@ -734,8 +754,9 @@ int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse) {
     SLP_API_INT({
         SLP_REQUIRE(s, "NULL handle");
         if (reuse && s->mx.n < (size_t)s->N) { s->mx.alloc((size_t)s->N); s->md.alloc((size_t)s->N); s->mx.zero(); s->md.zero(); }
-        s->reuse = reuse < 0 ? 0 : (reuse > 3 ? 3 : reuse);
+        s->reuse = reuse < 0 ? 0 : (reuse > 4 ? 4 : reuse);
         s->since_refresh = 0;
+        s->need_md = true;
         s->have_w = false;
         s->started = false;
         s->graph.reset();

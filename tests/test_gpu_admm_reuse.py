@@ -38,7 +38,7 @@ def test_admm_cg_fused_matches_reference_iterates(case):
 
 
 def test_reuse_levels_agree_on_device_generated_lp():
-    """Strip kernels + two-vector passes: levels 0, 1, 2, 3 give the same iterates to rounding."""
+    """Strip kernels + two-vector passes: levels 0 ... 4 give the same iterates to rounding."""
     import os
     from pysparselp_amd.admm_cg import DeviceADMM
     from pysparselp_amd.problems import random_lp_on_device
@@ -46,11 +46,11 @@ def test_reuse_levels_agree_on_device_generated_lp():
     os.environ["SLP_STRIP_MIN_NNZ"] = "1"
     try:
         xs = []
-        for level in (0, 1, 2, 3):
+        for level in (0, 1, 2, 3, 4):
             a, xf, c, lb, ub, b = random_lp_on_device(30000, 40000, 0.001, seed=3)
             s = DeviceADMM(a, b, c, lb, ub, reuse=level)
-            assert s.matrix_passes_per_iteration() == {0: 10, 1: 5, 2: 4, 3: 4}[level]
-            assert s.matrix_products_per_iteration() == {0: 10, 1: 8, 2: 6, 3: 5}[level]
+            assert s.matrix_passes_per_iteration() == {0: 10, 1: 5, 2: 4, 3: 4, 4: 4}[level]
+            assert s.matrix_products_per_iteration() == {0: 10, 1: 8, 2: 6, 3: 5, 4: 4}[level]
             s.iterate(25)
             xs.append(s.x(30000))
             s.close()
@@ -62,7 +62,7 @@ def test_reuse_levels_agree_on_device_generated_lp():
 
 
 def test_level3_recurrence_does_not_drift_over_a_refresh_period():
-    """Level 3 carries A dir by a recurrence and refreshes it every 64 iterations: 150 iterations stay with level 2."""
+    """Levels 3 / 4 carry A dir (and M dir) by recurrences and refresh them every 64 iterations: 150 iterations stay with level 2."""
     import os
     from pysparselp_amd.admm_cg import DeviceADMM
     from pysparselp_amd.problems import random_lp_on_device
@@ -70,14 +70,15 @@ def test_level3_recurrence_does_not_drift_over_a_refresh_period():
     os.environ["SLP_STRIP_MIN_NNZ"] = "1"
     try:
         xs = []
-        for level in (2, 3):
+        for level in (2, 3, 4):
             a, xf, c, lb, ub, b = random_lp_on_device(30000, 40000, 0.001, seed=4)
             s = DeviceADMM(a, b, c, lb, ub, reuse=level)
             s.iterate(150)
             xs.append(s.x(30000))
             s.close()
             a.close()
-        assert np.max(np.abs(xs[1] - xs[0]) / (1 + np.abs(xs[0]))) < 1e-9
-        assert abs(c.dot(xs[1]) - c.dot(xs[0])) <= 1e-9 * abs(c.dot(xs[0]))
+        for x in xs[1:]:
+            assert np.max(np.abs(x - xs[0]) / (1 + np.abs(xs[0]))) < 1e-9
+            assert abs(c.dot(x) - c.dot(xs[0])) <= 1e-9 * abs(c.dot(xs[0]))
     finally:
         del os.environ["SLP_STRIP_MIN_NNZ"]
