@@ -1,5 +1,5 @@
 """GPU vs CPU oracle over longer horizons on the benchmark distribution (mid size): objective and iterate
-agreement after 50 / 150 / 400 iterations of CP and of the matrix-free ADMM (reuse levels 0 and 2).
+agreement after 50 / 150 / 400 iterations of CP and of the matrix-free ADMM (reuse levels 0, 2 and 4).
 
     python tools/convergence_parity.py
 """
@@ -19,7 +19,7 @@ for iters in (50, 150, 400):
     xo, _ = oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10**9)
     res[f"cp_{iters}"] = dict(obj_gpu=float(c.dot(xg)), obj_cpu=float(c.dot(xo)), rel=float(abs(c.dot(xg)-c.dot(xo))/abs(c.dot(xo))), maxdx=float(np.max(np.abs(xg-xo))),
                              viol=float(np.max(s @ xg - b)))
-    for level in (0, 2):
+    for level in (0, 2, 4):
         a2 = random_lp_on_device(n, m, p, seed=1)[0]
         ad = DeviceADMM(a2, b, c, lb, ub, reuse=level); ad.iterate(iters); xg = ad.x(n); rep = ad.report(); ad.close(); a2.close()
         xo = oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters-1, nb_iter_plot=10**9)
