@@ -217,6 +217,7 @@ struct slp_matrix {
 };
 
 namespace slp {
+void finish_stats(CsrDev &a);          // max row length of a freshly built CSR
 void build_transpose(slp_matrix *m);   // stable: rows increasing inside every column
 int lanes_for(const CsrDev &a, int order);
 void launch_spmv(const CsrDev &a, const double *x, double *y, int order);

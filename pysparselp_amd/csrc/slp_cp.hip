@@ -144,10 +144,12 @@ __global__ __launch_bounds__(kBlock) void k_cp_dual(i64 m, const i64 *__restrict
 // instead of the three of CSR (row pointer -> entries -> gather); these LPs are latency-bound, not bandwidth-bound.
 // Sums run over e = 0 .. len-1 in storage order: the same sequential sums as k_cp_primal<1> / k_cp_dual<1>.
 __global__ void k_ell_fill(i64 nrow, int W, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, const double *__restrict__ val,
-                           i32 *__restrict__ oidx, double *__restrict__ oval, unsigned char *__restrict__ olen) {
+                           i32 *__restrict__ oidx, double *__restrict__ oval, unsigned char *__restrict__ olen, int *__restrict__ bad) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
         const i64 s = ptr[r];
-        const int len = (int)(ptr[r + 1] - s);
+        const i64 full = ptr[r + 1] - s;
+        if (full > W) atomicOr(bad, 1);  // a row longer than the width: the copy must not be used
+        const int len = (int)(full < W ? full : W);
         olen[r] = (unsigned char)len;
         for (int e = 0; e < W; ++e) {
             oidx[(i64)e * nrow + r] = e < len ? idx[s + e] : 0;
@@ -382,9 +384,17 @@ static void cp_setup(slp_cp *s) {
             W = width(csr.max_row_len);
             if (!W || csr.nrow == 0) { W = 0; return; }
             ei.alloc((size_t)W * (size_t)csr.nrow); ev.alloc((size_t)W * (size_t)csr.nrow); el.alloc((size_t)csr.nrow);
+            DevBuf<int> bad(1);
+            bad.zero();
             hipLaunchKernelGGL(k_ell_fill, dim3(grid_for(csr.nrow, kBlock)), dim3(kBlock), 0, st, csr.nrow, W, csr.ptr.p, csr.idx.p,
-                               csr.val.p, ei.p, ev.p, el.p);
+                               csr.val.p, ei.p, ev.p, el.p, bad.p);
             SLP_HIP(hipGetLastError());
+            int hbad = 0;
+            bad.download(&hbad, 1);
+            if (hbad) {  // (max_row_len out of date): keep the CSR walk
+                W = 0;
+                ei.release(); ev.release(); el.release();
+            }
         };
         if (small && s->lanes_rows == 1) build(a, s->ell_w_rows, s->ell_idx_rows, s->ell_val_rows, s->ell_len_rows);
         if (small && s->lanes_cols == 1) build(at, s->ell_w_cols, s->ell_idx_cols, s->ell_val_cols, s->ell_len_cols);

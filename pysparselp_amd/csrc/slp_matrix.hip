@@ -138,7 +138,7 @@ void invalidate_derived(slp_matrix *m) {
     m->vdict = ValueDict();
 }
 
-static void finish_stats(CsrDev &a) {
+void finish_stats(CsrDev &a) {  // fills a.max_row_len (kernel choices depend on it: every constructor must call this)
     DevBuf<unsigned long long> mx(1);
     mx.zero();
     if (a.nrow) {

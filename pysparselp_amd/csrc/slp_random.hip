@@ -135,7 +135,7 @@ slp_matrix *slp_matrix_random(int64_t nrow, int64_t ncol, double density, uint64
                 SLP_HIP(hipGetLastError());
             }
             SLP_HIP(hipStreamSynchronize(st));
-            a.max_row_len = 0;
+            finish_stats(a);
         } catch (...) {
             delete m;
             throw;

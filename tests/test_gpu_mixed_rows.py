@@ -121,3 +121,34 @@ def test_gather_rows_on_device():
     assert a.gather_rows(np.zeros(0, dtype=np.int64)).shape == (0, 500)
     g.close()
     a.close()
+
+
+def test_cp_on_generated_matrix_with_short_rows_regression():
+    """Regression: the generator left max_row_len unset, so the ELL copy of Chambolle-Pock's short-row path was built 4 wide
+    and truncated rows of ~7-20 entries.  Device-generated 25000 x 9000 LP, CSR kernels, one lane per row: bit-exact."""
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    a, xf, c, lb, ub, b = random_lp_on_device(9000, 25000, 0.0008, seed=684)
+    s = a.download()
+    assert np.diff(s.indptr).max() > 16  # longer than the widest ELL copy: the CSR walk must be used
+    for order in (0, 1):
+        cp = DeviceCP(a, b, c, lb, ub, order=order)
+        cp.iterate(10)
+        x = cp.x()
+        cp.close()
+        xo, _ = oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=10, nb_iter_plot=10 ** 9)
+        assert np.max(np.abs(x - xo)) < 1e-14
+    a.close()
+
+
+def test_randomised_at_scale_solvers():
+    """tools/fuzz_scale.py: DeviceCP and DeviceADMM (reuse levels 0 ... 4) on device-generated LPs of mixed shapes, every
+    strip variant and the CSR kernels, equality and two-sided rows -- against the oracle."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_scale
+
+    assert fuzz_scale.run(8, seed=2) == 8
