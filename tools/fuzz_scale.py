@@ -1,6 +1,7 @@
 """Randomised cross-check of the at-scale (device-resident) solvers against the oracle on mid-size device-generated LPs:
 DeviceCP and DeviceADMM (reuse levels 0 ... 4) over every strip variant, with equality rows and
-two-sided rows.  (DeviceBlocks has its own test: the oracle's sparse LU takes minutes beyond a few thousand rows.)
+two-sided rows.  DeviceBlocks is checked against the generic split-matrix block solver (the oracle's sparse LU takes minutes
+beyond a few thousand rows; both are checked against it in tests/test_admm_blocks.py on small LPs).
 python tools/fuzz_scale.py [--cases 16] [--seed 0]"""
 import argparse
 import os
@@ -53,6 +54,19 @@ def run(cases, seed, verbose=False):
         cbe = be if be is not None else np.zeros(0)
         xo, _ = oracle.chambolle_pock_ppd(c, cae, cbe, ai, bli, b[m_eq:], lb, ub, nb_max_iter=its, nb_iter_plot=10 ** 9)
         assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-10, f"cp case {case}: {np.max(np.abs(x - xo))}"
+        if m_eq == 0:  # two independent implementations of the block-splitting ADMM with ONE block: the row-block solver
+            # (implicit slack, primal or dual projection) against the generic split-matrix solver of the host API
+            from pysparselp_amd.ADMMBlocks import lp_admm_block_decomposition
+            from pysparselp_amd.scale import DeviceBlocks
+
+            blk = DeviceBlocks(a, b, c, lb, ub, b_lower=bl, cg_tol=1e-14)
+            blk.iterate(6)
+            x = blk.x()
+            blk.close()
+            ai_b = scipy.sparse.csr_matrix(ai)
+            ai_b.__dict__["blocks"] = [(0, m - 1)]
+            xh = lp_admm_block_decomposition(c, None, None, ai_b, bli, b, lb, ub, nb_iter=5, nb_iter_plot=10 ** 9, cg_tol=1e-14)
+            assert np.max(np.abs(x - xh) / (1 + np.abs(xh))) < 1e-8, f"blocks case {case}: {np.max(np.abs(x - xh))}"
         ad = DeviceADMM(a, b, c, lb, ub, m_eq=m_eq, b_lower=bl, reuse=level)   # last: may scale the matrix in place
         ad.iterate(its)
         x = ad.x(n)
