@@ -441,7 +441,7 @@ static void cg_rows2(slp_admm_cg *s, const double *v0, const double *v1, double 
 }
 
 // u_out = (A^T w) restricted to the original variables, summed over the ranks
-static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr) {
+static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr, bool reduce = true) {
     if (s->n_o == 0) return;
     double *u = u_out ? u_out : s->u.p;
     const CsrDev &at = s->a->at;
@@ -454,19 +454,20 @@ static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr) {
                                                      ctx().stream, s->n_o, at.ptr.p, at.idx.p, at.val.p, w, u));
         SLP_HIP(hipGetLastError());
     }
-    if (s->distributed) comm_allreduce_dev(u, s->n_o, 0);
+    if (s->distributed && reduce) comm_allreduce_dev(u, s->n_o, 0);
 }
 
 // [u2[0..n_o), u2[n_o..2 n_o)] = A^T [w0, w1]: one pass, one all-reduce of 2 n_o values
 static void cg_cols2(slp_admm_cg *s, const double *w0, const double *w1, double *u2) {
     if (s->n_o == 0) return;
-    const StripJds *f = fast_format(s->a, true);
-    if (!f) {
-        cg_cols(s, w0, u2);
-        cg_cols(s, w1, u2 + s->n_o);
-        return;
+    // the same ONE collective on every rank, whichever kernel a rank's block runs on (ranks must never disagree on the
+    // sequence of all-reduces)
+    if (const StripJds *f = fast_format(s->a, true)) {
+        strip_spmv2(*f, cg_scaled_rows(s, w0, s->ws0), cg_scaled_rows(s, w1, s->ws1), u2, u2 + s->n_o);
+    } else {
+        cg_cols(s, w0, u2, false);
+        cg_cols(s, w1, u2 + s->n_o, false);
     }
-    strip_spmv2(*f, cg_scaled_rows(s, w0, s->ws0), cg_scaled_rows(s, w1, s->ws1), u2, u2 + s->n_o);
     if (s->distributed) comm_allreduce_dev(u2, 2 * s->n_o, 0);
 }
 
@@ -502,6 +503,7 @@ static void cg_elem(slp_admm_cg *s, int slot, const double *u = nullptr, const d
 static bool cg_batched(slp_admm_cg *s) {
     if (!s->reuse || s->m <= 0 || s->n_o <= 0) return false;
     if (s->reuse >= 2) return true;  // the fused form is written on top of the shared products
+    if (s->distributed) return true; // never let the sequence of collectives depend on a rank's local kernel choice
     return fast_format(s->a, false) && fast_format(s->a, true);
 }
 
