@@ -248,6 +248,8 @@ int slp_blocks_set_cg(slp_blocks *s, double tol, int max_steps);
 int slp_blocks_iterate(slp_blocks *s, int64_t k);
 /* out[0] = the augmented-Lagrangian energy of ADMMBlocks.py:246-253, out[1] = CG steps taken so far. */
 int slp_blocks_report(slp_blocks *s, double out[2]);
+/* Conjugate-gradient steps this rank has taken so far (local: no exchange, unlike slp_blocks_report under slp_comm_init). */
+int64_t slp_blocks_cg_steps(const slp_blocks *s);
 int slp_blocks_get_xp(slp_blocks *s, double *xp, int64_t count);
 
 /* ---- synthetic random LP on the device (randomLP.py:14-75) -------------- *

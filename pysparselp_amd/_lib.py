@@ -76,6 +76,7 @@ _SIGNATURES = {
     "slp_blocks_set_cg": (c_int, [c_vp, c_dbl, c_int]),
     "slp_blocks_iterate": (c_int, [c_vp, c_i64]),
     "slp_blocks_report": (c_int, [c_vp, c_vp]),
+    "slp_blocks_cg_steps": (c_i64, [c_vp]),
     "slp_blocks_get_xp": (c_int, [c_vp, c_vp, c_i64]),
     "slp_admm_cg_create_on_two_sided": (c_vp, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_admm_cg_destroy": (None, [c_vp]),

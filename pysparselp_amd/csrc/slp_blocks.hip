@@ -563,6 +563,8 @@ int slp_blocks_report(slp_blocks *s, double out[2]) {
     })
 }
 
+int64_t slp_blocks_cg_steps(const slp_blocks *s) { return s ? (int64_t)s->cg_steps : -1; }  // local, no exchange
+
 int slp_blocks_get_xp(slp_blocks *s, double *xp, int64_t count) {
     SLP_API_INT({
         SLP_REQUIRE(s && xp && count >= 0 && count <= s->N, "slp_blocks_get_xp: bad arguments");

@@ -146,7 +146,8 @@ class DeviceBlocks:
         return float(self.c.dot(self.x()))
 
     def cg_steps(self):
-        return int(self.report()[1])
+        """CG steps taken by this rank so far (local: safe to call on one rank only)."""
+        return int(self._l.slp_blocks_cg_steps(self._h))
 
     def matrix_passes_per_iteration(self):
         return None  # 3 + 2 per conjugate-gradient step; see cg_steps()
