@@ -28,7 +28,10 @@ def test_sweep_random_against_oracle(pipelined, n, density):
     from pysparselp_amd.gaussSiedel import boundedGaussSeidelClass
 
     rng = np.random.RandomState(n)
-    b0 = scipy.sparse.random(n, n, density=density, random_state=rng, format="csr")
+    k = max(1, int(density * n * n))  # (scipy.sparse.random permutes all n * n cells: a minute for n = 40000)
+    b0 = scipy.sparse.coo_matrix((np.ones(k), (rng.randint(0, n, size=k), rng.randint(0, n, size=k))), shape=(n, n)).tocsr()
+    b0.sum_duplicates()
+    b0.sort_indices()
     b0.data = rng.randn(b0.nnz)
     m = (b0 + scipy.sparse.diags(np.abs(b0).sum(axis=1).A1 + 1.0)).tocsr()
     rhs = rng.randn(n)

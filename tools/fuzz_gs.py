@@ -34,7 +34,9 @@ def random_system(rng):
         n0, n1 = int(rng.randint(3000, 30000)), int(rng.randint(500, 20000))
         n = n0 + n1
         tail = scipy.sparse.diags([rng.randn(n1 - 1), rng.randn(n1 - 1)], [-1, 1], shape=(n1, n1))
-        link = scipy.sparse.random(n1, n0, density=2.0 / n0, random_state=rng)
+        k = 2 * n1  # about two links per tail row (scipy.sparse.random would permute all n1 * n0 cells)
+        link = scipy.sparse.coo_matrix((rng.rand(k), (rng.randint(0, n1, size=k), rng.randint(0, n0, size=k))), shape=(n1, n0)).tocsr()
+        link.sum_duplicates()
         m = scipy.sparse.bmat([[None, link.T], [link, tail]], format="csr")
     m = m.tocsr()
     m.sum_duplicates()
