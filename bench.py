@@ -13,9 +13,19 @@ partial column sums per SpMV^T); launched by the driver as
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
-``roofline`` (CSR SpMV kernel, algorithmic bytes / HIP-event time, against the
-8 TB/s HBM peak) and ``cpu_baseline`` (the oracle = CPU restatement of the
-reference algorithm, single thread, on a bounded sample of the same workload).
+
+``roofline``      the dominant kernel (the SpMV ``y = A x`` of the timed step): bytes that kernel HAS TO MOVE per launch
+                  (the matrix copy it streams + the vector it reads + the vector it writes) / its HIP-event time, against
+                  the 8 TB/s HBM peak -- a fraction <= 1 by construction.  The rate in CSR-equivalent algorithmic bytes
+                  (12 B per stored entry + vectors), which exceeds the physical rate when the kernel
+                  streams the lossless value-dictionary copy (3-4 B per entry), is reported under its own name
+                  (``csr_equivalent``), never as ``achieved``.
+``roofline.general_fp64``  the same matrix, same run, with the value dictionary ruled out (``slp_matrix_set_format(a, 1)``):
+                  fp64 strip entries (10 B per stored entry) -- the path a matrix with arbitrary coefficients takes --
+                  SpMV in both orientations, one Chambolle-Pock and one ADMM (reuse level 4) step rate.
+``cpu_baseline``  the oracle (CPU restatement of the reference algorithm, single thread like the reference) on a bounded
+                  sample of the same workload: the first rows of the same LP (all n columns, so the gathers hit a vector
+                  of the full size), ITERATIONS ONLY (setup excluded), scaled by the row ratio; ``extrapolated: true``.
 """
 import argparse
 import json
@@ -28,12 +38,28 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# the HIP library first: bench never needs torch on one GPU, and with N > 1 torch (gloo control
-# plane only) must find libamdhip64 already resolved to the system ROCm this library was built for
+# the HIP library first: bench never needs torch on one GPU
 from pysparselp_amd import _lib  # noqa: E402
 from pysparselp_amd.device import DeviceMatrix  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a plain copy achieves)
+
+KERNEL_NAMES = {
+    5: "k_wstrip_spmv<false> (wide strips: x gathered from L2, fp64 entries)",
+    4: "k_wstrip_spmv<true> (wide strips: x gathered from L2, value-dictionary entries)",
+    3: "k_qstrip_spmv<1> (LDS-tiled strip-JDS SpMV over the value-dictionary copy: 12-bit value id + 12-bit column per "
+       "stored entry, lossless)",
+    2: "k_dstrip_spmv<1> (LDS-tiled strip-JDS SpMV over the value-dictionary copy: uint16 value id + uint16 column per "
+       "stored entry, lossless)",
+    1: "k_strip_spmv<0> (LDS-tiled strip-JDS SpMV, fp64 value + uint16 column per stored entry)",
+    0: "k_spmv (row-per-lane-group CSR SpMV)",
+}
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this exact workload (tools/profile_c3.sh, tools/summarize_rocprof.py)
+PMC_FILES = {
+    3: (("r02_c3_pmc_hbm_admm.json", "r01_c3_pmc_hbm_quad.json"), "slp::k_qstrip_spmv<1>"),
+    2: (("r02_c3_pmc_hbm_admm.json", "r01_c3_pmc_hbm_dict.json"), "slp::k_dstrip_spmv<1>"),
+    1: (("r02_c3_pmc_hbm_fp64.json", "r01_cp_c3_pmc_hbm.json"), "slp::k_strip_spmv<0>"),
+}
 
 
 def parse():
@@ -50,7 +76,10 @@ def parse():
                    help="fraction of the constraint rows turned into equalities a_i x = a_i x_feasible (randomLP.py:62-68); "
                         "the default all-inequality LP is the primary workload")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-n", type=int, default=100_000)
+    p.add_argument("--no-general", action="store_true", help="skip the general (fp64 strip entries) block")
+    p.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU sample (default m / 10)")
+    p.add_argument("--format", type=int, default=0, choices=[0, 1, 2],
+                   help="slp_matrix_set_format policy of the timed run: 0 best available, 1 no value dictionary, 2 CSR kernels")
     return p.parse_args()
 
 
@@ -63,36 +92,133 @@ def cp_iter_bytes(nnz, m, n):
     return 24 * nnz + 8 * (m + 1) + 8 * (n + 1) + 8 * (8 * n + 5 * m)
 
 
+def pmc_traffic(kernel_id, shape):
+    """(HBM bytes per launch from the committed rocprofv3 PMC summary of this workload, its path) or (None, None)."""
+    if kernel_id not in PMC_FILES or shape != (1_000_000, 2_000_000, 1e-3):
+        return None, None
+    names, kern = PMC_FILES[kernel_id]
+    for name in names:
+        path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(path):
+            k = json.load(open(path))["kernels"].get(kern)
+            if k:
+                return k["hbm_bytes_per_launch_corrected"], "profiles/" + name
+    return None, None
+
+
+def spmv_block(lib, a, transposed, shape, reps=5):
+    """Roofline figures of one SpMV orientation of the resident matrix, timed with HIP events on the library's stream."""
+    rows, cols = (a.shape[1], a.shape[0]) if transposed else a.shape
+    ms = a.bench_spmv(transposed, reps=reps)
+    which = int(lib.slp_matrix_spmv_kernel(a._h, int(transposed)))
+    copy_bytes = int(lib.slp_matrix_format_bytes(a._h, int(transposed)))
+    moved = copy_bytes + 8 * cols + 8 * rows  # the matrix copy streamed once + x read once + y written once
+    alg = spmv_bytes(a.nnz, rows, cols)
+    traffic, src = pmc_traffic(which, shape) if not transposed else (None, None)
+    out = {
+        "kernel": KERNEL_NAMES.get(which, "?"),
+        "achieved": moved / (ms * 1e-3) / 1e9,
+        "frac": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "ms_per_launch": ms,
+        "bytes_per_launch": moved,
+        "matrix_copy_bytes_per_launch": copy_bytes,
+        "csr_equivalent": {"algorithmic_bytes_per_launch": alg, "gbps": alg / (ms * 1e-3) / 1e9,
+                           "x_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    if not transposed:
+        out["traffic"] = traffic
+        out["traffic_source"] = src
+    return out, which
+
+
 def cpu_baseline(args, method):
-    """Oracle (port of the reference algorithm, 1 thread) on a bounded sample of the same workload:
-    the same generator at n/10 x m/10 (1/100 of the stored entries), a few iterations."""
+    """Oracle (port of the reference algorithm, 1 thread) on a bounded sample: the first m/10 rows of the same LP with all n
+    columns (>= 1/10 of the stored entries; per-entry cost on a CPU depends on the size of the gathered vector, which is the
+    full one here).  Only iterations are timed (timestamps taken by the oracle's per-iteration hook); the rate is scaled by
+    the row ratio -- an extrapolation, validated once at full size by tools/cpu_full_c3.py (profiles/r02_cpu_full_c3.json)."""
     from oracle import oracle
 
-    scale = max(1, args.n // args.cpu_sample_n)
-    n, m = args.n // scale, args.m // scale
-    a = DeviceMatrix.random(m, n, args.density, args.seed)
+    rows = args.cpu_sample_rows or max(1, args.m // 10)
+    a = DeviceMatrix.random(rows, args.n, args.density, args.seed)
     xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed)
     s = a.download()
     a.close()
-    iters = 8
-    t0 = time.perf_counter()
+    stamps = []
+
+    def hook(i, *_):
+        stamps.append(time.perf_counter())
+
+    t_start = time.perf_counter()
     if method == "chambolle_pock_ppd":
-        oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9)
+        iters = 8
+        oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9, iterate_hook=hook)
     else:
-        oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
-    dt = time.perf_counter() - t0
-    its = iters / dt
-    full_nnz = args.n * args.m * args.density
-    return {
-        "value": its * (s.nnz / full_nnz),
+        iters = 5
+        oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9, iterate_hook=hook)
+    # stamp k is taken at the same point of iteration k: differences are whole iterations, setup is before stamp 0
+    per_iter = (stamps[-1] - stamps[1]) / (len(stamps) - 2)
+    its = 1.0 / per_iter
+    setup_s = stamps[0] - t_start - per_iter
+    out = {
+        "value": its * rows / args.m,
         "unit": "it/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"same generator at {n} x {m}, density {args.density} ({s.nnz} stored entries), {iters} iterations incl. setup: "
-                  f"{its:.3f} it/s measured; value = that rate scaled by the stored-entry ratio to the full problem",
+        "extrapolated": True,
+        "sample": f"first {rows} of the {args.m} rows of the same LP (all {args.n} columns, density {args.density}: {s.nnz} stored "
+                  f"entries), iterations {1}..{len(stamps) - 1} of {iters} timed without setup: {its:.4f} it/s measured; value = "
+                  f"that rate x {rows}/{args.m} (cost per iteration is linear in the rows)",
         "measured_it_per_s_on_sample": its,
+        "sample_setup_seconds": setup_s,
         "host_cores_present": os.cpu_count(),
     }
+    full = os.path.join(REPO, "profiles", "r02_cpu_full_c3.json")
+    if os.path.exists(full):
+        try:
+            out["full_size_validation"] = {"source": "profiles/r02_cpu_full_c3.json", **json.load(open(full)).get(method, {})}
+        except Exception:  # the validation record is optional evidence, never a reason to lose the bench line
+            pass
+    return out
+
+
+def timed_steps(lib, solver, warmup, steps):
+    solver.iterate(warmup)
+    _lib.check(lib.slp_comm_barrier())
+    t0 = time.perf_counter()
+    solver.iterate(steps)
+    _lib.check(lib.slp_comm_barrier())
+    return time.perf_counter() - t0
+
+
+def general_block(lib, args, a, b, c, lb, ub, shape):
+    """The same resident matrix with the value dictionary ruled out: fp64 strip entries, the path of a matrix with
+    arbitrary coefficients.  Runs AFTER the timed region of the headline number (it rebuilds the strip copies, and the
+    ADMM setup without a dictionary row-normalises the matrix in place)."""
+    from pysparselp_amd.scale import make_solver
+
+    _lib.check(lib.slp_matrix_set_format(a._h, 1))
+    t0 = time.perf_counter()
+    ax, which = spmv_block(lib, a, False, shape)
+    aty, _ = spmv_block(lib, a, True, shape)
+    t_build = time.perf_counter() - t0
+    out = {"what": "same matrix, value dictionary ruled out (slp_matrix_set_format(a, 1)): fp64 value + uint16 column per "
+                   "stored entry; the path a matrix with arbitrary coefficients takes",
+           "spmv": ax, "spmv_transposed": aty, "format_build_and_spmv_seconds": t_build}
+    if which != 1:
+        out["note"] = "the matrix does not qualify for the fp64 strip format at this size"
+    steps = max(5, min(args.steps, 20))
+    cp = make_solver("chambolle_pock_ppd", a, b, c, lb, ub)
+    dt = timed_steps(lib, cp, 2, steps)
+    out["chambolle_pock_it_per_s"] = steps / dt
+    out["chambolle_pock_ms_per_step"] = 1e3 * dt / steps
+    cp.close()
+    admm = make_solver("admm", a, b, c, lb, ub)  # no dictionary: row scaling in place (the matrix is not reused after this)
+    dt = timed_steps(lib, admm, 3, steps)
+    out["admm_it_per_s"] = steps / dt
+    out["admm_ms_per_step"] = 1e3 * dt / steps
+    out["admm"] = admm.describe()
+    admm.close()
+    return out
 
 
 def main():
@@ -103,25 +229,23 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     lib = _lib.lib(local)
-    dist = None
-    if world > 1 or os.environ.get("SLP_BENCH_FORCE_DIST") == "1":  # the latter: one-GPU test of the whole N > 1 plumbing
-        os.environ.setdefault("MASTER_PORT", "29511")
-        import torch.distributed as dist  # gloo, CPU: control plane only (RCCL id exchange)
+    distributed = world > 1 or os.environ.get("SLP_BENCH_FORCE_DIST") == "1"  # the latter: one-GPU test of the N > 1 plumbing
+    if distributed:
+        from pysparselp_amd.parallel import init_comm_from_env
 
-        from pysparselp_amd.parallel import init_comm
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        init_comm(dist, rank, world)
+        init_comm_from_env(rank, world)
 
     # ---- the workload: this rank's row block, generated in HBM
     from pysparselp_amd.parallel import row_block
 
+    shape = (args.n, args.m, args.density)
     r0, rows = row_block(args.m, world, rank)
     t_gen = time.perf_counter()
     a = DeviceMatrix.random(rows, args.n, args.density, args.seed, r0)
     xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed, r0)
     nnz_local = a.nnz
+    if args.format:
+        _lib.check(lib.slp_matrix_set_format(a._h, args.format))
     from pysparselp_amd.scale import make_solver
 
     m_eq_local = 0
@@ -137,11 +261,13 @@ def main():
     # ---- timed region: W warm-up steps, then exactly K steps between two barriers
     solver.iterate(args.warmup)
     cg0 = solver.cg_steps() if args.method == "admm_blocks" else 0
+    coll0 = int(lib.slp_comm_collectives())
     _lib.check(lib.slp_comm_barrier())
     t0 = time.perf_counter()
     solver.iterate(args.steps)
     _lib.check(lib.slp_comm_barrier())
     dt = time.perf_counter() - t0
+    coll = int(lib.slp_comm_collectives()) - coll0 - 1  # the closing barrier is one
     tmax = np.array([dt])
     _lib.check(lib.slp_comm_allreduce_host(_lib.ptr(tmax), 1, 1))
     dt = float(tmax[0])
@@ -153,36 +279,34 @@ def main():
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
-        # dominant kernel: the CSR SpMV (both orientations stream 12 B per stored entry)
-        reps = 5
-        ms_ax = a.bench_spmv(False, reps=reps)
-        ms_aty = a.bench_spmv(True, reps=reps)
-        b_ax = spmv_bytes(nnz_local, rows, args.n)
-        b_aty = spmv_bytes(nnz_local, args.n, rows)
-        gbs_ax = b_ax / (ms_ax * 1e-3) / 1e9
-        gbs_aty = b_aty / (ms_aty * 1e-3) / 1e9
+        ax, which = spmv_block(lib, a, False, shape)
+        aty, _ = spmv_block(lib, a, True, shape)
         passes = solver.matrix_passes_per_iteration()
         if args.method == "admm_blocks":  # 3 products + 2 per conjugate-gradient step (rank 0's count)
             passes = 3 + 2 * (solver.cg_steps() - cg0) / args.steps
-        which = lib.slp_matrix_spmv_kernel(a._h, 0)
-        kernel = {4: "k_wstrip_spmv<true, 1> (wide strips: x gathered from L2, value-dictionary entries; rank 0's row block)",
-                  5: "k_wstrip_spmv<false, 1> (wide strips: x gathered from L2, fp64 entries; rank 0's row block)",
-                  3: "k_qstrip_spmv<1> (LDS-tiled strip-JDS SpMV y = A x over the value-dictionary copy: 12-bit value id + "
-                     "12-bit column per stored entry, lossless; rank 0's row block)",
-                  2: "k_dstrip_spmv<1> (LDS-tiled strip-JDS SpMV y = A x over the value-dictionary copy: uint16 value id + "
-                     "uint16 column per stored entry, lossless; rank 0's row block)",
-                  1: "k_strip_spmv (LDS-tiled strip-JDS SpMV y = A x, rank 0's row block)"}.get(
-                      which, "k_spmv (CSR SpMV y = A x, rank 0's row block)")
-        traffic, traffic_src = None, None
-        pmc_name = {3: ("r01_c3_pmc_hbm_quad.json", "slp::k_qstrip_spmv<1>"), 2: ("r01_c3_pmc_hbm_dict.json", "slp::k_dstrip_spmv<1>"), 1: ("r01_cp_c3_pmc_hbm.json", "slp::k_strip_spmv<0>")}.get(which)
-        if pmc_name and world == 1 and (args.n, args.m, args.density) == (1_000_000, 2_000_000, 1e-3):
-            # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 correction),
-            # collected on this exact workload and kernel; see tools/summarize_rocprof.py and DESIGN.md
-            pmc_file = os.path.join(REPO, "profiles", pmc_name[0])
-            if os.path.exists(pmc_file):
-                k = json.load(open(pmc_file))["kernels"].get(pmc_name[1])
-                if k:
-                    traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/" + pmc_name[0]
+        # one iteration = `passes` single-vector sweeps, alternating orientations: bytes the iteration has to move
+        iter_bytes = passes / 2.0 * (ax["bytes_per_launch"] + aty["bytes_per_launch"])
+        roofline = {
+            "bound": "hbm",
+            "kernel": ax["kernel"] + " -- rank 0's row block",
+            "achieved": ax["achieved"],
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": ax["frac"],
+            "traffic": ax["traffic"],
+            "traffic_source": ax["traffic_source"],
+            "definition": "achieved = bytes the kernel has to move per launch (the matrix copy it streams + x read once + y "
+                          "written once) / HIP-event time per launch on the library's stream; traffic = rocprofv3 PMC "
+                          "(FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of the same kernel on the same workload",
+            "bytes_per_launch": ax["bytes_per_launch"],
+            "matrix_copy_bytes_per_launch": ax["matrix_copy_bytes_per_launch"],
+            "ms_per_launch": ax["ms_per_launch"],
+            "csr_equivalent": ax["csr_equivalent"],
+            "spmv_transposed": aty,
+            "iteration": {"bytes": iter_bytes, "achieved": iter_bytes / (ms_step * 1e-3) / 1e9,
+                          "frac_of_all_gpus": iter_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                          "csr_equivalent_gbps": passes * 12 * nnz_total / (ms_step * 1e-3) / 1e9},
+        }
         out = {
             "metric": {"admm": "admm", "admm_blocks": "admm_blocks", "chambolle_pock_ppd": "chambolle_pock"}[args.method] + "_iterations_per_sec",
             "value": args.steps / dt,
@@ -202,46 +326,30 @@ def main():
                             f"rows partitioned over {world} GPU(s)",
                 "n": args.n, "m": args.m, "density": args.density, "seed": args.seed, "nnz": nnz_total, "eq_frac": args.eq_frac,
                 "method": args.method, "matrix_passes_per_iteration": passes,
+                "collectives_per_iteration": (coll / args.steps) if distributed else 0,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel,
-                "achieved": gbs_ax,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": gbs_ax / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                # what actually crosses the HBM interface (PMC), as a rate: the physical utilisation of the 8 TB/s
-                "hbm_achieved": (traffic / (ms_ax * 1e-3) / 1e9) if traffic else None,
-                "hbm_frac": (traffic / (ms_ax * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "note": ("achieved/frac follow the contract: ALGORITHMIC CSR bytes (12 B per stored entry + vectors) / kernel time. "
-                         "The kernel streams a lossless value-dictionary copy (3-4 B per entry + 3 B per (row, strip)), so the "
-                         "algorithmic rate can exceed the HBM peak; hbm_achieved/hbm_frac = PMC traffic / kernel time."
-                         if which >= 2 else None),
-                "algorithmic_bytes_per_launch": b_ax,
-                "matrix_copy_bytes_per_launch": int(lib.slp_matrix_format_bytes(a._h, 0)),
-                "ms_per_launch": ms_ax,
-                "spmv_transposed": {"achieved": gbs_aty, "frac": gbs_aty / HBM_PEAK_GBS, "ms_per_launch": ms_aty,
-                                    "algorithmic_bytes_per_launch": b_aty},
-                "iteration": {"algorithmic_bytes": passes * 12 * nnz_total,
-                              "achieved": passes * 12 * nnz_total / dt * args.steps / 1e9,
-                              "frac_of_all_gpus": passes * 12 * nnz_total / dt * args.steps / 1e9 / (HBM_PEAK_GBS * world)},
-            },
+            "roofline": roofline,
             "objective_after_run": obj,
             "setup_seconds": t_gen,
         }
+        solver.close()
+        solver = None
+        if world == 1 and not args.no_general and args.format == 0 and which >= 2 and args.method != "admm_blocks":
+            roofline["general_fp64"] = general_block(lib, args, a, b, c, lb, ub, shape)
         if world == 1 and not args.no_cpu_baseline and args.method != "admm_blocks":
             # (admm_blocks: the reference's per-block sparse LU of a KKT matrix with 5e5+ unknowns does not finish in
-            # bench time even on the 1/100 sample; tools/bench_blocks.py times the LU form on the Potts LP instead)
+            # bench time even on the sample; tools/bench_blocks.py times the LU form on the Potts LP instead)
+            a.close()
+            a = None
             out["cpu_baseline"] = cpu_baseline(args, args.method)
         print(json.dumps(out), flush=True)
-    solver.close()
-    a.close()
-    if dist is not None:
+    if solver is not None:
+        solver.close()
+    if a is not None:
+        a.close()
+    if distributed:
         _lib.check(lib.slp_comm_barrier())
         _lib.check(lib.slp_comm_finalize())
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

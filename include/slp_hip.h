@@ -64,6 +64,11 @@ int slp_matrix_spmv_t(slp_matrix *a, const double *y, double *out, int order);
  * transposed CSR, i.e. CSC of A (transposed = 1).  Any pointer may be NULL. */
 int slp_matrix_download(slp_matrix *a, int transposed, int64_t *indptr,
                         int32_t *indices, double *data);
+/* The same for rows row0 .. row0 + count of that orientation (a slice of a matrix too large to copy whole): indptr[count + 1]
+ * keeps the ABSOLUTE offsets of the device array (entries of the slice: indptr[count] - indptr[0], starting at indptr[0]);
+ * call once for indptr, then with buffers of that size for indices / data. */
+int slp_matrix_download_rows(slp_matrix *a, int transposed, int64_t row0, int64_t count, int64_t *indptr,
+                             int32_t *indices, double *data);
 /* Device-resident benchmark kernels: `reps` back-to-back launches on resident
  * vectors, no host traffic; *ms = average GPU time per launch (HIP events). */
 int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, double *ms);
@@ -78,6 +83,10 @@ int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, do
  * scale 1 copies, -1 negates exactly. */
 slp_matrix *slp_matrix_gather_rows(slp_matrix *a, int64_t count, const int64_t *rows, const double *scale);
 int slp_matrix_spmv_kernel(slp_matrix *a, int transposed);
+/* Which derived copies the products may use: 0 (default) = the best the matrix qualifies for; 1 = no value dictionary
+ * (fp64 entries in the strips: the general, any-values path); 2 = CSR kernels only.  Frees the strip copies built so
+ * far; fails while a solver created on the matrix is alive. */
+int slp_matrix_set_format(slp_matrix *a, int policy);
 /* Bytes of the matrix copy that kernel reads per product (entries + per-strip metadata; CSR: 12 nnz + 8 (rows + 1)),
  * i.e. the matrix part of the HBM traffic one launch must generate; -1 = error. */
 int64_t slp_matrix_format_bytes(slp_matrix *a, int transposed);
@@ -287,6 +296,9 @@ int slp_comm_finalize(void);
  * device, for bench timing and report scalars. */
 int slp_comm_allreduce_host(double *v, int64_t count, int op);
 int slp_comm_barrier(void);
+/* All-reduces this process has issued since slp_comm_init (0 without a communicator): the data-path exchange steps
+ * can be counted per iteration (Chambolle-Pock 1, matrix-free ADMM at reuse level 4: 2, block-splitting ADMM 1). */
+long long slp_comm_collectives(void);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslp_hip.so")
+# SLP_LIB_VARIANT=ablation: the -DSLP_ABLATION build of `make -C pysparselp_amd/csrc ablation` (tools/ablate_strip.py only)
+LIB_PATH = os.path.join(_HERE, "libslp_hip_ablation.so" if os.environ.get("SLP_LIB_VARIANT") == "ablation" else "libslp_hip.so")
 
 ORDER_AUTO, ORDER_SEQUENTIAL, ORDER_TREE = 0, 1, 2
 
@@ -37,9 +38,11 @@ _SIGNATURES = {
     "slp_matrix_spmv": (c_int, [c_vp, c_vp, c_vp, c_int]),
     "slp_matrix_spmv_t": (c_int, [c_vp, c_vp, c_vp, c_int]),
     "slp_matrix_download": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
+    "slp_matrix_download_rows": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "slp_matrix_bench_spmv": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),
     "slp_matrix_gather_rows": (c_vp, [c_vp, c_i64, c_vp, c_vp]),
     "slp_matrix_spmv_kernel": (c_int, [c_vp, c_int]),
+    "slp_matrix_set_format": (c_int, [c_vp, c_int]),
     "slp_matrix_format_bytes": (c_i64, [c_vp, c_int]),
     "slp_cp_create": (c_vp, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_cp_create_on": (c_vp, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
@@ -93,6 +96,7 @@ _SIGNATURES = {
     "slp_comm_finalize": (c_int, []),
     "slp_comm_allreduce_host": (c_int, [c_vp, c_i64, c_int]),
     "slp_comm_barrier": (c_int, []),
+    "slp_comm_collectives": (ctypes.c_longlong, []),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -150,8 +154,8 @@ def lib(device=None):
         if dev is None:
             dev = int(os.environ.get("SLP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
             n = l.slp_device_count()
-            if n > 0:
-                dev %= n
+            if n > 0 and dev >= n:  # never wrap: that would silently put two ranks on one GPU
+                raise SlpError(f"device index {dev} (SLP_DEVICE / LOCAL_RANK) but only {n} HIP device(s) are visible")
         check(l.slp_init(int(dev)))
         _device = int(dev)
     elif device is not None and int(device) != _device:

@@ -669,6 +669,7 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
     SLP_API_PTR({
         SLP_REQUIRE(a_ineq && b_upper && c && lb && ub, "slp_admm_cg_create_on: NULL argument");
         SLP_REQUIRE(m_eq >= 0 && m_eq <= a_ineq->a.nrow, "slp_admm_cg_create_on_mixed: m_eq out of range");
+        Phase ph("slp_admm_cg_create_on");
         auto *s = new slp_admm_cg();
         try {
             hipStream_t st = ctx().stream;
@@ -686,8 +687,11 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
             // Few distinct stored values and long rows: keep the matrix as it is (value-dictionary strips) and carry
             // the two row scalings as a vector.  Otherwise: rows scaled in place, twice; the transposed copy is
             // (re)built from the scaled values.
+            // the in-place normalisation below is not idempotent (pass 2 adds the slack entry's 1)
+            SLP_REQUIRE(!a_ineq->scaled, "slp_admm_cg_create_on: this matrix was already row-normalised in place by an earlier ADMM "
+                                         "setup; scaling it again would solve a different problem -- build the solver on a fresh matrix");
             bool deferred = false;
-            if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1) || strip_wanted(a, 3)) && value_dictionary(a, a_ineq->vdict)) {
+            if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1) || strip_wanted(a, 3)) && matrix_dictionary(a_ineq)) {
                 build_transpose(a_ineq);
                 const StripJds *f0 = fast_format(a_ineq, false), *f1 = fast_format(a_ineq, true);
                 deferred = f0 && f1 && f0->D > 0 && f1->D > 0;
@@ -699,7 +703,12 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
                                                              m, (i64)m_eq, a.ptr.p, a.val.p, bu.p, s->sc.p, s->rs.p, bl.p));
                 SLP_HIP(hipGetLastError());
             } else if (m) {
+                // in place: the matrix then holds the row-normalised values and every derived copy is rebuilt -- refuse when
+                // that would pull the data from under another solver
+                SLP_REQUIRE(a_ineq->borrowers == 0, "slp_admm_cg_create_on: another solver created on this matrix is still alive; the "
+                                                    "in-place row normalisation would change the values it iterates on");
                 invalidate_derived(a_ineq);
+                a_ineq->scaled = true;
                 const int lanes = lanes_for(a, SLP_ORDER_TREE);
                 for (int pass = 1; pass <= 2; ++pass) {
                     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_scale_rows<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0,
@@ -728,6 +737,7 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
             delete s;
             throw;
         }
+        ++a_ineq->borrowers;
         return s;
     })
 }
@@ -735,6 +745,7 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
 void slp_admm_cg_destroy(slp_admm_cg *s) {
     if (!s) return;
     if (s->owns_a) delete s->a;
+    else --s->a->borrowers;
     delete s;
 }
 

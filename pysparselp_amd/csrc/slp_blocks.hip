@@ -506,6 +506,7 @@ slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lo
             delete s;
             throw;
         }
+        ++a->borrowers;
         return s;
     })
 }
@@ -513,6 +514,7 @@ slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lo
 void slp_blocks_destroy(slp_blocks *s) {
     if (!s) return;
     if (!s->row_block) delete s->a;
+    else --s->a->borrowers;
     delete s;
 }
 

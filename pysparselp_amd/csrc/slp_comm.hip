@@ -33,6 +33,7 @@ static struct {
     fn_error_string error_string = nullptr;
     NcclComm comm = nullptr;
     int nranks = 1, rank = 0;
+    long long collectives = 0;  // all-reduces issued since slp_comm_init (slp_comm_collectives)
     DevBuf<double> scratch;
 } g;
 
@@ -43,7 +44,10 @@ static void load_rccl() {
         g.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
         if (g.lib) break;
     }
-    SLP_REQUIRE(g.lib, std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?"));
+    if (!g.lib) {
+        const char *e = dlerror();  // reading it clears it: once
+        throw Error(std::string("cannot load RCCL: ") + (e ? e : "?"));
+    }
     g.get_unique_id = (fn_get_unique_id)dlsym(g.lib, "ncclGetUniqueId");
     g.comm_init_rank = (fn_comm_init_rank)dlsym(g.lib, "ncclCommInitRank");
     g.all_reduce = (fn_all_reduce)dlsym(g.lib, "ncclAllReduce");
@@ -68,6 +72,7 @@ bool comm_active() {
 void comm_allreduce_dev(double *buf, i64 count, int op) {
     SLP_REQUIRE(g.comm, "slp_comm_init has not been called");
     if (count <= 0) return;
+    ++g.collectives;
     check(g.all_reduce(buf, buf, (size_t)count, /*ncclFloat64*/ 8, op == 1 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, g.comm, ctx().stream),
           "ncclAllReduce");
 }
@@ -124,6 +129,8 @@ int slp_comm_allreduce_host(double *v, int64_t count, int op) {
         g.scratch.download(v, (size_t)count);
     })
 }
+
+long long slp_comm_collectives(void) { return g.collectives; }
 
 int slp_comm_barrier(void) {
     SLP_API_INT({

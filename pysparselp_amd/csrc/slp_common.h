@@ -151,6 +151,25 @@ struct IterGraph {
     }
 };
 
+// Setup phases on stderr (SLP_TRACE=1): host wall-clock per phase with the stream drained on both sides, so that
+// allocation / free / host work show up next to kernel time.  Off: no synchronisation, no output.
+struct Phase {
+    const char *name;
+    double t0 = 0.0;
+    bool on;
+    static bool enabled() {
+        static const int e = [] { const char *v = getenv("SLP_TRACE"); return (v && v[0] == '1') ? 1 : 0; }();
+        return e != 0;
+    }
+    static double now();
+    explicit Phase(const char *n) : name(n), on(enabled()) {
+        if (on) { (void)hipStreamSynchronize(ctx().stream); t0 = now(); }
+    }
+    ~Phase() {
+        if (on) { (void)hipStreamSynchronize(ctx().stream); fprintf(stderr, "[slp trace] %-34s %9.3f ms\n", name, (now() - t0) * 1e3); }
+    }
+};
+
 inline int grid_for(i64 work_items, int block, int max_blocks_per_cu = 8) {
     i64 g = (work_items + block - 1) / block;
     i64 cap = (i64)ctx().num_cu * max_blocks_per_cu;
@@ -214,6 +233,9 @@ struct slp_matrix {
     bool tried_fa = false, tried_fat = false;
     slp::ValueDict vdict;             // shared by both orientations
     slp::DevBuf<double> vx, vy;  // scratch vectors for the host-vector entry points
+    int format_policy = 0;       // slp_matrix_set_format: 0 auto, 1 no value dictionary (fp64 entries), 2 CSR kernels only
+    bool scaled = false;         // the stored values were row-normalised in place by an ADMM setup (not idempotent)
+    int borrowers = 0;           // live solvers created *_on this matrix (they hold raw pointers into its copies)
 };
 
 namespace slp {
@@ -226,5 +248,6 @@ const StripJds *fast_format(slp_matrix *m, bool transposed);
 // y = A x (transposed: y = A^T x) with the best kernel for the matrix.
 void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int order);
 void invalidate_derived(slp_matrix *m);  // after the CSR values were modified in place
+bool matrix_dictionary(slp_matrix *m);   // value_dictionary() of the matrix unless its format policy rules the dictionary out
 // two-stage deterministic reductions; result lands in out[0..k) (device), see slp_reduce.hip
 }  // namespace slp

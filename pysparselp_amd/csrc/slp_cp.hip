@@ -554,13 +554,16 @@ slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const dou
                          const double *ub, const double *x0, double alpha, double theta, int order) {
     SLP_API_PTR({
         SLP_REQUIRE(a && b && c && lb && ub, "slp_cp_create_on: NULL argument");
-        return cp_make(a, false, m_eq, b, c, lb, ub, x0, alpha, theta, order);
+        slp_cp *s = cp_make(a, false, m_eq, b, c, lb, ub, x0, alpha, theta, order);
+        ++a->borrowers;
+        return s;
     })
 }
 
 void slp_cp_destroy(slp_cp *s) {
     if (!s) return;
     if (s->owns_k) delete s->k;
+    else --s->k->borrowers;
     delete s;
 }
 

@@ -2,6 +2,8 @@
 // CSR SpMV / SpMV^T.  Replaces the scipy.sparse operands and
 // _sparsetools.csr_matvec / csc_matvec calls of the reference's solver loops
 // (ChambollePockPPD.py:206,216,235,240 ; ADMM.py:95,148,220,262).
+#include <chrono>
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 
@@ -14,6 +16,8 @@ namespace slp {
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
+
+double Phase::now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static Context g_ctx;
 Context &ctx_unchecked() { return g_ctx; }
@@ -105,20 +109,23 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
     bool &tried = transposed ? m->tried_fat : m->tried_fa;
     if (!tried) {
         tried = true;
+        if (m->format_policy == 2) return nullptr;  // CSR kernels only
         // few distinct stored values (rounded coefficients, +-1 patterns): 4-byte entries, values looked up in LDS
         // quads (4096-row blocks, 3-byte entries) when that still leaves enough row blocks to fill the chip without
         // splitting strips (a split changes the association of the row sums); else pairs.  SLP_DICT_VARIANT=1|2 forces.
         const char *ev = getenv("SLP_DICT_VARIANT");
         int variant = (a.nrow + 4095) / 4096 >= 384 ? 2 : 1;
         if (ev && (ev[0] == '1' || ev[0] == '2')) variant = ev[0] - '0';
-        const bool dict = strip_wanted(a, variant) && value_dictionary(m->a, m->vdict);
+        const bool dict = strip_wanted(a, variant) && matrix_dictionary(m);
         if (dict) strip_build(a, f, &m->vdict, variant);
         else if (strip_wanted(a, 0)) strip_build(a, f, nullptr, 0);
         else if (strip_wanted(a, 3))  // long rows over a width far beyond an L2: wide strips, x gathered from L2
-            strip_build(a, f, value_dictionary(m->a, m->vdict) ? &m->vdict : nullptr, 3);
+            strip_build(a, f, matrix_dictionary(m) ? &m->vdict : nullptr, 3);
     }
     return f.ok ? &f : nullptr;
 }
+
+bool matrix_dictionary(slp_matrix *m) { return m->format_policy == 0 && value_dictionary(m->a, m->vdict); }
 
 void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int order) {
     // the strip kernel sums every row with one accumulator in storage order: valid for every `order`
@@ -156,6 +163,7 @@ void finish_stats(CsrDev &a) {  // fills a.max_row_len (kernel choices depend on
 // scipy's csc_matvec accumulates `y * A`.
 void build_transpose(slp_matrix *m) {
     if (m->have_at) return;
+    Phase ph("build_transpose");
     const CsrDev &a = m->a;
     CsrDev &t = m->at;
     hipStream_t st = ctx().stream;
@@ -203,11 +211,24 @@ void build_transpose(slp_matrix *m) {
     m->have_at = true;
 }
 
+// One pass over the uploaded arrays: indptr non-decreasing, 0 <= index < ncol.  Every entry point that takes host CSR
+// arrays goes through matrix_from_host, so a bad index is an slp_last_error instead of an out-of-bounds device access.
+__global__ void k_validate_csr(i64 nrow, i64 ncol, i64 nnz, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, int *__restrict__ bad) {
+    const i64 t0 = (i64)blockIdx.x * blockDim.x + threadIdx.x, stride = (i64)gridDim.x * blockDim.x;
+    int b = 0;
+    for (i64 r = t0; r < nrow; r += stride)
+        if (ptr[r + 1] < ptr[r]) b |= 1;
+    for (i64 k = t0; k < nnz; k += stride)
+        if (idx[k] < 0 || (i64)idx[k] >= ncol) b |= 2;
+    if (b) atomicOr(bad, b);
+}
+
 static slp_matrix *matrix_from_host(i64 nrow, i64 ncol, const i64 *indptr, const i32 *indices, const double *data) {
     SLP_REQUIRE(nrow >= 0 && ncol >= 0 && indptr != nullptr, "slp_matrix_create: bad arguments");
     SLP_REQUIRE(ncol < (i64)1 << 31, "column count must fit int32");
     const i64 nnz = indptr[nrow];
     SLP_REQUIRE(indptr[0] == 0 && nnz >= 0, "slp_matrix_create: indptr must start at 0");
+    SLP_REQUIRE(nnz == 0 || (indices != nullptr && data != nullptr), "slp_matrix_create: NULL indices / data");
     ctx();
     auto *m = new slp_matrix();
     try {
@@ -217,6 +238,15 @@ static slp_matrix *matrix_from_host(i64 nrow, i64 ncol, const i64 *indptr, const
         m->a.ptr.upload(indptr, (size_t)nrow + 1);
         m->a.idx.upload(indices, (size_t)nnz);
         m->a.val.upload(data, (size_t)nnz);
+        DevBuf<int> bad(1);
+        bad.zero();
+        hipLaunchKernelGGL(k_validate_csr, dim3(grid_for(std::max(nrow, nnz), kBlock)), dim3(kBlock), 0, ctx().stream, nrow, ncol, nnz,
+                           m->a.ptr.p, m->a.idx.p, bad.p);
+        SLP_HIP(hipGetLastError());
+        int hbad = 0;
+        bad.download(&hbad, 1);
+        SLP_REQUIRE(!(hbad & 1), "slp_matrix_create: indptr must be non-decreasing");
+        SLP_REQUIRE(!(hbad & 2), "slp_matrix_create: column index out of range [0, ncol)");
         finish_stats(m->a);
     } catch (...) {
         delete m;
@@ -387,6 +417,40 @@ int slp_matrix_download(slp_matrix *m, int transposed, int64_t *indptr, int32_t 
         if (indptr) a.ptr.download(indptr, (size_t)a.nrow + 1);
         if (indices) a.idx.download(indices, (size_t)a.nnz);
         if (data) a.val.download(data, (size_t)a.nnz);
+    })
+}
+
+int slp_matrix_download_rows(slp_matrix *m, int transposed, int64_t row0, int64_t count, int64_t *indptr, int32_t *indices,
+                             double *data) {
+    SLP_API_INT({
+        SLP_REQUIRE(m, "slp_matrix_download_rows: NULL matrix");
+        if (transposed) build_transpose(m);
+        const CsrDev &a = transposed ? m->at : m->a;
+        SLP_REQUIRE(row0 >= 0 && count >= 0 && row0 + count <= a.nrow, "slp_matrix_download_rows: rows out of range");
+        hipStream_t st = ctx().stream;
+        i64 ends[2] = {0, 0};
+        SLP_HIP(hipMemcpyAsync(&ends[0], a.ptr.p + row0, sizeof(i64), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipMemcpyAsync(&ends[1], a.ptr.p + row0 + count, sizeof(i64), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipStreamSynchronize(st));
+        const size_t k0 = (size_t)ends[0], k = (size_t)(ends[1] - ends[0]);
+        if (indptr) SLP_HIP(hipMemcpyAsync(indptr, a.ptr.p + row0, (size_t)(count + 1) * sizeof(i64), hipMemcpyDeviceToHost, st));
+        if (indices && k) SLP_HIP(hipMemcpyAsync(indices, a.idx.p + k0, k * sizeof(i32), hipMemcpyDeviceToHost, st));
+        if (data && k) SLP_HIP(hipMemcpyAsync(data, a.val.p + k0, k * sizeof(double), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipStreamSynchronize(st));
+    })
+}
+
+int slp_matrix_set_format(slp_matrix *m, int policy) {
+    SLP_API_INT({
+        SLP_REQUIRE(m && policy >= 0 && policy <= 2, "slp_matrix_set_format: bad arguments");
+        SLP_REQUIRE(m->borrowers == 0, "slp_matrix_set_format: a solver created on this matrix is still alive (it holds pointers "
+                                       "into the copies this call would free)");
+        if (policy == m->format_policy) return 0;
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+        m->fa = StripJds();
+        m->fat = StripJds();
+        m->tried_fa = m->tried_fat = false;
+        m->format_policy = policy;
     })
 }
 

@@ -103,6 +103,7 @@ slp_matrix *slp_matrix_random(int64_t nrow, int64_t ncol, double density, uint64
     SLP_API_PTR({
         SLP_REQUIRE(nrow >= 0 && ncol > 0 && ncol < ((i64)1 << 31) && density > 0.0 && density < 1.0,
                     "slp_matrix_random: bad arguments");
+        Phase ph("slp_matrix_random");
         hipStream_t st = ctx().stream;
         auto *m = new slp_matrix();
         try {
@@ -148,6 +149,7 @@ int slp_random_lp_vectors(slp_matrix *m, double density, uint64_t seed, int64_t 
                           double *lb, double *ub, double *b_upper) {
     SLP_API_INT({
         SLP_REQUIRE(m, "slp_random_lp_vectors: NULL matrix");
+        Phase ph("slp_random_lp_vectors");
         hipStream_t st = ctx().stream;
         const i64 n = m->a.ncol, rows = m->a.nrow;
         DevBuf<double> xf((size_t)n), dc((size_t)n), dl((size_t)n), du((size_t)n), ax((size_t)rows), db((size_t)rows);

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
 // ---- the product ---------------------------------------------------------------
 // One workgroup per row block; 60 KB x-tile + 16 KB running sums + 1 KB slot offsets of LDS
 // (two workgroups per CU).  out[row] = sum over the row (single accumulator, storage order).
-// ABLATE (timing experiments only, wrong results): 1 = no x-tile staging, 2 = no entry streaming
+// ABLATE != 0 is instantiated only in the -DSLP_ABLATION build (timing experiments, wrong results): 1 = no x-tile
+// staging, 2 = no entry streaming
 template <int ABLATE>
 __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                            const unsigned short *__restrict__ perm,
@@ -737,6 +738,7 @@ bool value_dictionary(const CsrDev &a, ValueDict &d) {
     d.state = 0;
     const char *e = getenv("SLP_VALUE_DICT");
     if ((e && e[0] == '0') || a.nnz == 0) return false;
+    Phase ph("value_dictionary");
     hipStream_t st = ctx().stream;
     DevBuf<unsigned long long> table((size_t)kDictHash);
     DevBuf<unsigned int> count(1);
@@ -772,6 +774,7 @@ bool value_dictionary(const CsrDev &a, ValueDict &d) {
 template <int C, int RPL, bool WIDE = false>
 static bool strip_build_c(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     constexpr int kStripR = RPL * kStripT;  // rows per block of this variant
+    Phase ph(WIDE ? "strip_build (wide)" : (RPL == 4 ? "strip_build (quads)" : (dict ? "strip_build (pairs)" : "strip_build (fp64)")));
     hipStream_t st = ctx().stream;
     f = StripJds();
     if (a.nrow == 0 || a.nnz == 0) return false;
@@ -878,19 +881,17 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
         SLP_HIP(hipGetLastError());
         return;
     }
-    const char *e = getenv("SLP_STRIP_ABLATE");  // tools/ablate_strip.py only: the ablated kernels return WRONG sums
-    const int ab = e ? atoi(e) : 0;
-    if (ab) {
-        static bool warned = false;
-        if (!warned) fprintf(stderr, "libslp_hip: SLP_STRIP_ABLATE=%d -- timing experiment, SpMV results are wrong\n", ab);
-        warned = true;
-    }
 #define SLP_STRIP_LAUNCH(A)                                                                                                        \
     hipLaunchKernelGGL((k_strip_spmv<A>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, \
                        f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out)
+#ifdef SLP_ABLATION  // `make ablation` (tools/ablate_strip.py) only: the ablated kernels return WRONG sums; not in libslp_hip.so
+    const char *e = getenv("SLP_STRIP_ABLATE");
+    const int ab = e ? atoi(e) : 0;
     if (ab == 1) SLP_STRIP_LAUNCH(1);
     else if (ab == 2) SLP_STRIP_LAUNCH(2);
-    else SLP_STRIP_LAUNCH(0);
+    else
+#endif
+    SLP_STRIP_LAUNCH(0);
 #undef SLP_STRIP_LAUNCH
     if (f.S > 1)
         hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);

@@ -74,6 +74,24 @@ class DeviceMatrix:
         _lib.check(self._l.slp_matrix_download(self._h, int(transposed), None, _lib.ptr(indices), _lib.ptr(data)))
         return scipy.sparse.csr_matrix((data, indices, indptr), shape=(nrow, ncol))
 
+    def download_rows(self, row0, count, transposed=False):
+        """scipy CSR copy of rows ``row0 .. row0 + count`` (of the device-built A^T when ``transposed``)."""
+        ncol = self.shape[0] if transposed else self.shape[1]
+        indptr = np.empty(count + 1, dtype=np.int64)
+        _lib.check(self._l.slp_matrix_download_rows(self._h, int(transposed), int(row0), int(count), _lib.ptr(indptr), None, None))
+        nnz = int(indptr[-1] - indptr[0])
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz)
+        _lib.check(self._l.slp_matrix_download_rows(self._h, int(transposed), int(row0), int(count), None, _lib.ptr(indices), _lib.ptr(data)))
+        return scipy.sparse.csr_matrix((data, indices, indptr - indptr[0]), shape=(count, ncol))
+
+    def set_format(self, policy):
+        """0: best available copy; 1: no value dictionary (fp64 strip entries); 2: CSR kernels only."""
+        _lib.check(self._l.slp_matrix_set_format(self._h, int(policy)))
+
+    def spmv_kernel(self, transposed=False):
+        return int(self._l.slp_matrix_spmv_kernel(self._h, int(transposed)))
+
     def bench_spmv(self, transposed=False, order=ORDER_AUTO, reps=20):
         """Average GPU milliseconds of one SpMV launch on resident vectors (HIP events)."""
         ms = np.zeros(1)

@@ -11,7 +11,7 @@ import pytest
 import scipy.sparse
 
 from oracle import oracle
-from pysparselp_amd.parallel import exchange_unique_id, row_block, row_block_by_nnz
+from pysparselp_amd.parallel import rendezvous_unique_id, row_block, row_block_by_nnz
 
 
 def test_row_block_covers_all_rows():
@@ -66,8 +66,8 @@ def _rank_main(rank, world, port, out):
         dist.all_reduce(t, op=op)
         return t.numpy()
 
-    # --- id exchange helper
-    uid = exchange_unique_id(dist, rank, lambda: bytes(range(128)))
+    # --- id exchange (the product's control plane: plain TCP on MASTER_ADDR : MASTER_PORT + 1, no torch)
+    uid = rendezvous_unique_id(rank, world, lambda: bytes(range(128)))
     assert uid == bytes(range(128))
 
     a, b, c, lb, ub = _small_lp()

@@ -1,0 +1,156 @@
+"""BASELINE config 3 at FULL size (1e6 variables x 2e6 inequality rows, density 1e-3, ~2e9 stored entries) and one
+matrix with more than 2^31 stored entries, inside ``pytest -m gpu``.
+
+No CPU run is affordable at this size, so parity is established through
+  (i)   bit-for-bit agreement of the three kernel families on the full products: value-dictionary strips, fp64 strips
+        and the thread-per-row CSR kernel ``k_spmv<1>`` (every one of them sums a row with a single accumulator in
+        storage order; ``k_spmv<1>`` is pinned bit-exactly to the oracle at small sizes in test_gpu_parity.py),
+  (ii)  the oracle itself on downloaded slices: 2048 rows of A and 2048 rows of the device-built A^T,
+  (iii) the adjoint identity <A x, y> = <x, A^T y>,
+  (iv)  solver runs: two runs bit-identical, objective after 50 iterations equal to the recorded convergence run
+        (profiles/r01_c3_convergence.json).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, M, P, SEED = 1_000_000, 2_000_000, 1e-3, 0
+
+
+@pytest.fixture(scope="module")
+def c3():
+    from pysparselp_amd.problems import random_lp_on_device
+
+    a, xf, c, lb, ub, b = random_lp_on_device(N, M, P, seed=SEED)
+    yield a, xf, c, lb, ub, b
+    a.close()
+
+
+def _vectors():
+    rng = np.random.RandomState(5)
+    return rng.randn(N), rng.randn(M)
+
+
+def test_c3_products_agree_bit_for_bit_across_kernel_families(c3):
+    a = c3[0]
+    assert 1.98e9 < a.nnz < 2.0e9
+    x, y = _vectors()
+    got = {}
+    for policy, kernels in ((0, (2, 3)), (1, (1,)), (2, (0,))):
+        a.set_format(policy)
+        assert a.spmv_kernel(False) in kernels and a.spmv_kernel(True) in kernels, (policy, a.spmv_kernel(False), a.spmv_kernel(True))
+        got[policy] = (a.matvec(x, order=1), a.rmatvec(y, order=1))  # order 1 = SEQUENTIAL: k_spmv<1> under policy 2
+    a.set_format(0)
+    for policy in (1, 2):
+        assert np.array_equal(got[0][0], got[policy][0]), f"A x: dictionary strips vs policy {policy}"
+        assert np.array_equal(got[0][1], got[policy][1]), f"A^T y: dictionary strips vs policy {policy}"
+    ax, aty = got[0]
+    # (iii) adjoint identity; both sides are sums of 2e9 products of O(1) numbers
+    lhs, rhs = float(ax.dot(y)), float(x.dot(aty))
+    assert abs(lhs - rhs) <= 1e-10 * (abs(lhs) + np.linalg.norm(ax) * np.linalg.norm(y))
+    # (ii) oracle on slices.  Rows: the slice of A itself.
+    for r0 in (0, 1_234_567, M - 2048):
+        rows = a.download_rows(r0, 2048)
+        assert np.array_equal(oracle.matvec(oracle.as_csr(rows), x), ax[r0:r0 + 2048])
+    # Columns: rows of the device-built transpose; inside a row of A^T the entries are ordered by increasing row of A,
+    # which is the order in which scipy's csc_matvec accumulates `y * A` (oracle: orc_csr_rmatvec).
+    for c0 in (0, 543_210, N - 2048):
+        cols = a.download_rows(c0, 2048, transposed=True)
+        assert np.all(np.diff(cols.indptr) > 0)
+        for j in (0, 1000, 2047):
+            seg = cols.indices[cols.indptr[j]:cols.indptr[j + 1]]
+            assert np.all(np.diff(seg) > 0)  # strictly increasing rows: stable transposition, no duplicates
+        assert np.array_equal(oracle.matvec(oracle.as_csr(cols), y), aty[c0:c0 + 2048])
+    # the transposed slice holds exactly the entries of A in those columns: compare with regenerated rows of A
+    from pysparselp_amd.device import DeviceMatrix
+
+    blk = DeviceMatrix.random(4096, N, P, SEED, 777_000)
+    sub = blk.download().tocsc()[:, 543_210:543_210 + 2048].tocoo()
+    blk.close()
+    cols = a.download_rows(543_210, 2048, transposed=True).tocoo()
+    keep = (cols.col >= 777_000) & (cols.col < 777_000 + 4096)
+    got_set = set(zip(cols.row[keep].tolist(), (cols.col[keep] - 777_000).tolist(), cols.data[keep].tolist()))
+    ref_set = set(zip(sub.col.tolist(), sub.row.tolist(), sub.data.tolist()))
+    assert got_set == ref_set and len(ref_set) > 5000
+
+
+def test_c3_solver_runs_are_deterministic_and_match_the_recorded_convergence(c3):
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.scale import DeviceCP
+
+    a, xf, c, lb, ub, b = c3
+    rec = json.load(open(os.path.join(REPO, "profiles", "r01_c3_convergence.json")))
+    assert (rec["n"], rec["m"], rec["nnz"]) == (N, M, a.nnz)
+    ax = a.matvec(xf)
+    assert abs(float(c.dot(xf)) - rec["feasible_point"]["objective"]) < 1e-9
+    assert float(np.max(ax - b)) <= 1e-9  # the generator's point is feasible (randomLP.py:43-46)
+
+    def at50(entry):
+        e = [r for r in entry if r["iteration"] == 50][0]
+        return e["objective"], e["max_row_violation"]
+
+    runs = []
+    for _ in range(2):
+        s = DeviceCP(a, b, c, lb, ub)
+        s.iterate(30)
+        x30 = s.x()
+        s.iterate(20)
+        runs.append((x30, s.x()))
+        s.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    obj, viol = at50(rec["chambolle_pock_ppd"])
+    x = runs[0][1]
+    assert abs(float(c.dot(x)) - obj) <= 1e-9 * abs(obj)
+    assert abs(float(np.max(a.matvec(x) - b)) - viol) <= 1e-8 * (1 + viol)
+
+    runs = []
+    for _ in range(2):
+        s = DeviceADMM(a, b, c, lb, ub)  # value-dictionary strips: the matrix itself is left untouched (deferred row scaling)
+        assert s.reuse == 4
+        s.iterate(30)
+        x30 = s.x(N)
+        s.iterate(20)
+        runs.append((x30, s.x(N)))
+        s.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    obj, viol = at50(rec["admm"])
+    x = runs[0][1]
+    scale = abs(rec["feasible_point"]["objective"])  # the objective passes through 0 around iteration 50
+    assert abs(float(c.dot(x)) - obj) <= 1e-6 * scale
+    assert abs(float(np.max(a.matvec(x) - b)) - viol) <= 1e-6 * (1 + viol)
+
+
+def test_more_than_2_31_stored_entries():
+    """The 1/8 row slice of a 1e7-variable, density-1e-4 LP: 2.5e6 x 1e7, ~2.5e9 stored entries (> 2^31): every entry
+    offset is 64-bit.  Wide strips vs the thread-per-row CSR kernel bit for bit, the oracle on row slices of both
+    orientations, the adjoint identity."""
+    from pysparselp_amd.device import DeviceMatrix
+
+    n, rows = 10_000_000, 2_500_000
+    a = DeviceMatrix.random(rows, n, 1e-4, 1, 0)
+    try:
+        assert a.nnz > 2 ** 31
+        rng = np.random.RandomState(6)
+        x, y = rng.randn(n), rng.randn(rows)
+        assert a.spmv_kernel(False) in (4, 5) and a.spmv_kernel(True) in (2, 3, 4, 5)
+        ax, aty = a.matvec(x, order=1), a.rmatvec(y, order=1)
+        a.set_format(2)
+        assert np.array_equal(a.matvec(x, order=1), ax)
+        assert np.array_equal(a.rmatvec(y, order=1), aty)
+        lhs, rhs = float(ax.dot(y)), float(x.dot(aty))
+        assert abs(lhs - rhs) <= 1e-10 * (abs(lhs) + np.linalg.norm(ax) * np.linalg.norm(y))
+        for r0 in (0, rows - 1024):  # the last rows sit behind offset 2^31
+            sl = a.download_rows(r0, 1024)
+            assert np.array_equal(oracle.matvec(oracle.as_csr(sl), x), ax[r0:r0 + 1024])
+        for c0 in (0, n - 4096):
+            sl = a.download_rows(c0, 4096, transposed=True)
+            assert np.array_equal(oracle.matvec(oracle.as_csr(sl), y), aty[c0:c0 + 4096])
+    finally:
+        a.close()

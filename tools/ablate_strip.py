@@ -1,6 +1,8 @@
 """Timing experiments on the strip SpMV at BASELINE config 3 (wrong results in ablated modes):
-which part of k_strip_spmv costs what.  python tools/ablate_strip.py"""
+which part of k_strip_spmv costs what.  make -C pysparselp_amd/csrc ablation && python tools/ablate_strip.py"""
 import os, sys, json
+os.environ["SLP_LIB_VARIANT"] = "ablation"  # make -C pysparselp_amd/csrc ablation ; the shipped library has no ablation switch
+os.environ.setdefault("SLP_VALUE_DICT", "0")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from pysparselp_amd.device import DeviceMatrix

@@ -79,5 +79,27 @@ def db_pmc(fetch_path, write_path):
     print(json.dumps({"correction": "FETCH_SIZE x2 (gfx950, coalesced streaming reads), KiB -> bytes x1024", "kernels": keep}, indent=1))
 
 
+def db_sq(path):
+    """Per-kernel launch means of whatever SQ_* counters one --pmc pass collected, plus the ratios quoted in DESIGN.md."""
+    import sqlite3
+
+    cur = sqlite3.connect(path).cursor()
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for name, counter, value in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+        agg[short(name)][counter].append(float(value))
+    out = {}
+    for k, d in agg.items():
+        if not k.startswith("slp::k_") or "strip_spmv" not in k:
+            continue
+        r = {c: sum(v) / len(v) for c, v in d.items()}
+        r["launches"] = len(next(iter(d.values())))
+        for a, b in (("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"), ("SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_ANY"),
+                     ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY")):
+            if a in r and b in r and r[b]:
+                r[a + "/" + b] = r[a] / r[b]
+        out[k] = r
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "db-stats": db_stats, "db-pmc": db_pmc}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "db-stats": db_stats, "db-pmc": db_pmc, "db-sq": db_sq}[sys.argv[1]](*sys.argv[2:])
