@@ -56,9 +56,9 @@ KERNEL_NAMES = {
 }
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this exact workload (tools/profile_c3.sh, tools/summarize_rocprof.py)
 PMC_FILES = {
-    3: (("r02_c3_pmc_hbm_admm.json", "r01_c3_pmc_hbm_quad.json"), "slp::k_qstrip_spmv<1>"),
-    2: (("r02_c3_pmc_hbm_admm.json", "r01_c3_pmc_hbm_dict.json"), "slp::k_dstrip_spmv<1>"),
-    1: (("r02_c3_pmc_hbm_fp64.json", "r01_cp_c3_pmc_hbm.json"), "slp::k_strip_spmv<0>"),
+    3: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_quad.json"), "slp::k_qstrip_spmv<1>"),
+    2: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_dict.json"), "slp::k_dstrip_spmv<1>"),
+    1: (("r02_c3_pmc_hbm.json", "r01_cp_c3_pmc_hbm.json"), "slp::k_strip_spmv<0>"),
 }
 
 

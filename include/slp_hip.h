@@ -291,6 +291,12 @@ slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const dou
  * first use, so single-GPU use does not depend on it. */
 int slp_comm_unique_id(char id[128]);
 int slp_comm_init(int nranks, int rank, const char id[128]);
+/* Test transport: instead of RCCL, every all-reduce copies its buffer to the host, calls
+ * fn(buf, count, op, user) -- which must reduce buf[0..count) in place over the ranks (op 0 sum, 1 max) and return 0 -- and
+ * copies the result back.  Lets several ranks of the real partitioned device code share one GPU (RCCL refuses two ranks on
+ * one device) and lets tests record the sequence of collectives. */
+typedef int (*slp_host_allreduce_fn)(double *buf, int64_t count, int op, void *user);
+int slp_comm_init_host(int nranks, int rank, slp_host_allreduce_fn fn, void *user);
 int slp_comm_finalize(void);
 /* In-place all-reduce of a small host vector (op: 0 sum, 1 max) through the
  * device, for bench timing and report scalars. */

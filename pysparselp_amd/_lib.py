@@ -93,6 +93,7 @@ _SIGNATURES = {
     "slp_random_lp_vectors": (c_int, [c_vp, c_dbl, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "slp_comm_unique_id": (c_int, [c_vp]),
     "slp_comm_init": (c_int, [c_int, c_int, c_vp]),
+    "slp_comm_init_host": (c_int, [c_int, c_int, c_vp, c_vp]),
     "slp_comm_finalize": (c_int, []),
     "slp_comm_allreduce_host": (c_int, [c_vp, c_i64, c_int]),
     "slp_comm_barrier": (c_int, []),
@@ -100,6 +101,9 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+# int fn(double *buf, int64_t count, int op, void *user): the host all-reduce of slp_comm_init_host
+HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, ctypes.POINTER(c_dbl), c_i64, c_int, c_vp)
 
 
 class SlpError(RuntimeError):

@@ -26,6 +26,7 @@ bool comm_active();
 void comm_allreduce_dev(double *buf, i64 count, int op);
 
 constexpr int kCgPartials = 2048;
+constexpr int kCgTail = 8;       // doubles reserved behind u / u2 for the packed exchange
 enum { S_T = 0, S_DMD = 2, S_RS = 4, S_PAP = 6, S_TMP = 8, S_COUNT = 32 };
 
 // w_i = At_i . v_o + sc_i v_s,i          (A v)
@@ -79,10 +80,13 @@ struct CgVecs {
     double gamma_eq, gamma_ineq, alpha, one_minus_alpha;
 };
 
+// Blocks [0, go) walk the n_o replicated original variables, blocks [go, gridDim.x) this rank's slack variables: `go`
+// depends on n_o only, so the original-variable part of every dot product is summed in the same order on every rank
+// whatever the size of its row block (replicas must stay bit-identical), and a block's partial sum belongs to one part.
 template <int OP>
-__global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict__ part) {
+__global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict__ part, int go) {
     __shared__ double lds[kBlock / kWave];
-    double acc_o = 0.0, acc_s = 0.0;
+    double acc = 0.0;
     double f = 0.0;
     bool on = true;
     if (OP == E_LINE_STEP || OP == E_RESID_REUSE || OP == E_RESID_FUSED) {
@@ -96,7 +100,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
         const double t = -(a.scal[S_T] + a.scal[S_T + 1]);
         step = fabs(t) > 0.0 ? t / (a.scal[S_DMD] + a.scal[S_DMD + 1]) : 0.0;
     }
-    for (i64 j = (i64)blockIdx.x * kBlock + threadIdx.x; j < a.N; j += (i64)gridDim.x * kBlock) {
+    const bool slack = (int)blockIdx.x >= go;
+    const i64 j_begin = slack ? a.n_o + ((i64)blockIdx.x - go) * kBlock + threadIdx.x : (i64)blockIdx.x * kBlock + threadIdx.x;
+    const i64 j_end = slack ? a.N : a.n_o;
+    const i64 j_stride = (slack ? (i64)gridDim.x - go : (i64)go) * kBlock;
+    for (i64 j = j_begin; j < j_end; j += j_stride) {
         double term = 0.0;
         if (OP == E_RHS) {  // y = -c + g_eq A^T b + g_ineq xp - A^T lambda_eq - lambda_ineq (:148) ; xprev = x (:184)
             const double atl = at_elem(j, a.n_o, a.u, a.sc, a.w);
@@ -151,30 +159,89 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
             a.xp[j] = p;
             a.lin[j] = a.lin[j] + a.gamma_ineq * (xj - p);
         }
-        if (j < a.n_o) acc_o += term;
-        else acc_s += term;
+        acc += term;
     }
     if (OP == E_LINE_T || OP == E_LINE_DMD || OP == E_RESID || OP == E_RESID_REUSE || OP == E_PAP || OP == E_GRAD ||
         OP == E_RESID_FUSED || OP == E_LINE_DMD_MD) {
-        const double ro = block_reduce<false>(acc_o, lds), rs = block_reduce<false>(acc_s, lds);
-        if (threadIdx.x == 0) {
-            part[blockIdx.x * 2] = ro;
-            part[blockIdx.x * 2 + 1] = rs;
-        }
+        const double r = block_reduce<false>(acc, lds);
+        if (threadIdx.x == 0) part[blockIdx.x] = r;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cg_finish(int nparts, const double *__restrict__ part, double *__restrict__ scal, int slot) {
+// scal[slot] = sum of the original-variable partials (blocks [0, go)), scal[slot + 1] = this rank's slack partials.
+// Packed exchange (row-partitioned level-4 iteration): the slack part was summed over the ranks in the tail of the
+// preceding vector all-reduce and replaces the local one --
+//   tail_mode 1: scal[slot + 1] = tail[0]
+//   tail_mode 2: r = -(g + step M dir), so r.r over the slack unknowns = g.g + 2 step g.Md + step^2 Md.Md from the three
+//                reduced coefficients tail[0..3) (step is known only after the exchange that carried them)
+__global__ __launch_bounds__(kBlock) void k_cg_finish(int go, int nparts, const double *__restrict__ part, double *__restrict__ scal,
+                                                      int slot, const double *__restrict__ tail, int tail_mode) {
     __shared__ double lds[kBlock / kWave];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += kBlock) {
-        a += part[i * 2];
-        b += part[i * 2 + 1];
-    }
+    for (int i = threadIdx.x; i < go; i += kBlock) a += part[i];
+    for (int i = go + threadIdx.x; i < nparts; i += kBlock) b += part[i];
     const double ra = block_reduce<false>(a, lds), rb = block_reduce<false>(b, lds);
     if (threadIdx.x == 0) {
         scal[slot] = ra;
-        scal[slot + 1] = rb;
+        double sl = rb;
+        if (tail_mode == 1) sl = tail[0];
+        if (tail_mode == 2) {
+            const double t = -(scal[S_T] + scal[S_T + 1]);
+            const double f = t / (scal[S_DMD] + scal[S_DMD + 1]);
+            sl = fabs(t) > 0.0 ? (tail[0] + 2.0 * f * tail[1]) + (f * f) * tail[2] : tail[0];
+        }
+        scal[slot + 1] = sl;
+    }
+}
+
+// Packed exchange, rank-local pre-pass over this rank's slack unknowns j = n_o + i, BEFORE the all-reduce of the A^T
+// product of the line search: everything the iteration needs from the slack part of its first three dot products only
+// depends on rank-local data (the slack column of A^T w is sc_i w_i), so it rides behind the vector.
+//   g_j  = (sc_i v1_i + g_ineq x_j) - ((q_j + g_ineq xp_j) - lin_j)          = what E_GRAD computes for j
+//   Md_j = refresh ? g_eq sc_i wd_i + g_ineq dir_j (E_LINE_DMD) : carried md_j (E_LINE_DMD_MD)
+// partial sums per block: [0] dir.g  [1] dir.Md  [2] g.g  [3] g.Md  [4] Md.Md
+__global__ __launch_bounds__(kBlock) void k_cg_slack_pre(CgVecs a, const double *__restrict__ v1, const double *__restrict__ wd,
+                                                         int refresh, double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double v[5] = {0, 0, 0, 0, 0};
+    for (i64 j = a.n_o + (i64)blockIdx.x * kBlock + threadIdx.x; j < a.N; j += (i64)gridDim.x * kBlock) {
+        const i64 i = j - a.n_o;
+        const double g = (a.sc[i] * v1[i] + a.gamma_ineq * a.x[j]) - ((a.q[j] + a.gamma_ineq * a.xp[j]) - a.lin[j]);
+        const double d = a.dir[j];
+        const double md = refresh ? a.gamma_eq * (a.sc[i] * wd[i]) + a.gamma_ineq * d : a.md[j];
+        v[0] += d * g;
+        v[1] += d * md;
+        v[2] += g * g;
+        v[3] += g * md;
+        v[4] += md * md;
+    }
+    for (int k = 0; k < 5; ++k) {
+        const double r = block_reduce<false>(v[k], lds);
+        if (threadIdx.x == 0) part[blockIdx.x * 5 + k] = r;
+    }
+}
+
+// ... and before the all-reduce of A^T (A r): the slack part of r.(M r), M r over slack j = g_eq sc_i w_i + g_ineq r_j, w = A r
+__global__ __launch_bounds__(kBlock) void k_cg_slack_pap(CgVecs a, const double *__restrict__ w, double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double v = 0.0;
+    for (i64 j = a.n_o + (i64)blockIdx.x * kBlock + threadIdx.x; j < a.N; j += (i64)gridDim.x * kBlock) {
+        const i64 i = j - a.n_o;
+        const double ap = a.gamma_eq * (a.sc[i] * w[i]) + a.gamma_ineq * a.r[j];
+        v += a.r[j] * ap;
+    }
+    const double r = block_reduce<false>(v, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+// tail[k] = sum over blocks of part[block * K + k]  (fixed order)
+__global__ __launch_bounds__(kBlock) void k_cg_tail(int nparts, int K, const double *__restrict__ part, double *__restrict__ tail) {
+    __shared__ double lds[kBlock / kWave];
+    for (int k = 0; k < K; ++k) {
+        double a = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += kBlock) a += part[i * K + k];
+        const double r = block_reduce<false>(a, lds);
+        if (threadIdx.x == 0) tail[k] = r;
     }
 }
 
@@ -440,8 +507,9 @@ static void cg_rows2(slp_admm_cg *s, const double *v0, const double *v1, double 
     cg_rows(s, v1, w1);
 }
 
-// u_out = (A^T w) restricted to the original variables, summed over the ranks
-static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr, bool reduce = true) {
+// u_out = (A^T w) restricted to the original variables, summed over the ranks; `tail` more doubles stored right behind the
+// n_o sums (packed exchange: rank-local slack parts of dot products) are summed in the same all-reduce
+static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr, bool reduce = true, i64 tail = 0) {
     if (s->n_o == 0) return;
     double *u = u_out ? u_out : s->u.p;
     const CsrDev &at = s->a->at;
@@ -454,11 +522,11 @@ static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr, bo
                                                      ctx().stream, s->n_o, at.ptr.p, at.idx.p, at.val.p, w, u));
         SLP_HIP(hipGetLastError());
     }
-    if (s->distributed && reduce) comm_allreduce_dev(u, s->n_o, 0);
+    if (s->distributed && reduce) comm_allreduce_dev(u, s->n_o + tail, 0);
 }
 
 // [u2[0..n_o), u2[n_o..2 n_o)] = A^T [w0, w1]: one pass, one all-reduce of 2 n_o values
-static void cg_cols2(slp_admm_cg *s, const double *w0, const double *w1, double *u2) {
+static void cg_cols2(slp_admm_cg *s, const double *w0, const double *w1, double *u2, i64 tail = 0) {
     if (s->n_o == 0) return;
     // the same ONE collective on every rank, whichever kernel a rank's block runs on (ranks must never disagree on the
     // sequence of all-reduces)
@@ -468,7 +536,7 @@ static void cg_cols2(slp_admm_cg *s, const double *w0, const double *w1, double 
         cg_cols(s, w0, u2, false);
         cg_cols(s, w1, u2 + s->n_o, false);
     }
-    if (s->distributed) comm_allreduce_dev(u2, 2 * s->n_o, 0);
+    if (s->distributed) comm_allreduce_dev(u2, 2 * s->n_o + tail, 0);
 }
 
 static CgVecs cg_vecs(slp_admm_cg *s, const double *u, const double *w) {
@@ -483,17 +551,43 @@ static CgVecs cg_vecs(slp_admm_cg *s, const double *u, const double *w) {
     return v;
 }
 
+// grid of the elementwise passes: `go` blocks for the replicated original variables (a function of n_o alone: the same on
+// every rank), the rest for this rank's slack variables
+static void cg_grids(const slp_admm_cg *s, int *go, int *gs) {
+    *go = std::min(grid_for(s->n_o, kBlock), kCgPartials / 2);
+    *gs = std::min(grid_for(s->N - s->n_o, kBlock), kCgPartials / 2);
+}
+
+// tail / tail_mode: packed exchange -- the slack part of the dot product was reduced over the ranks behind a vector
+// all-reduce (k_cg_finish); otherwise, when the rows are partitioned, one scalar all-reduce of the slack part.
 template <int OP>
-static void cg_elem(slp_admm_cg *s, int slot, const double *u = nullptr, const double *w = nullptr) {
-    int grid = grid_for(s->N, kBlock);
-    if (grid > kCgPartials) grid = kCgPartials;
-    hipLaunchKernelGGL((k_cg_elem<OP>), dim3(grid), dim3(kBlock), 0, ctx().stream, cg_vecs(s, u, w), s->part.p);
+static void cg_elem(slp_admm_cg *s, int slot, const double *u = nullptr, const double *w = nullptr, const double *tail = nullptr,
+                    int tail_mode = 0) {
+    int go, gs;
+    cg_grids(s, &go, &gs);
+    hipLaunchKernelGGL((k_cg_elem<OP>), dim3(go + gs), dim3(kBlock), 0, ctx().stream, cg_vecs(s, u, w), s->part.p, go);
     SLP_HIP(hipGetLastError());
     if (slot >= 0) {
-        hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(kBlock), 0, ctx().stream, grid, s->part.p, s->scal.p, slot);
+        hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(kBlock), 0, ctx().stream, go, go + gs, s->part.p, s->scal.p, slot, tail, tail_mode);
         SLP_HIP(hipGetLastError());
-        if (s->distributed) comm_allreduce_dev(s->scal.p + slot + 1, 1, 0);  // slack part lives on its rank
+        if (s->distributed && !tail_mode) comm_allreduce_dev(s->scal.p + slot + 1, 1, 0);  // slack part lives on its rank
     }
+}
+
+// Packed exchange: the rank-local slack sums land in `tail` (device, right behind the vector the next all-reduce sends)
+static void cg_slack_pre(slp_admm_cg *s, bool refresh, double *tail) {
+    const int g = std::min(grid_for(s->N - s->n_o, kBlock), kCgPartials / 8);
+    hipLaunchKernelGGL(k_cg_slack_pre, dim3(g), dim3(kBlock), 0, ctx().stream, cg_vecs(s, nullptr, nullptr), s->v1.p, s->wd.p, refresh ? 1 : 0,
+                       s->part.p);
+    hipLaunchKernelGGL(k_cg_tail, dim3(1), dim3(kBlock), 0, ctx().stream, g, 5, s->part.p, tail);
+    SLP_HIP(hipGetLastError());
+}
+
+static void cg_slack_pap(slp_admm_cg *s, const double *w, double *tail) {
+    const int g = std::min(grid_for(s->N - s->n_o, kBlock), kCgPartials / 8);
+    hipLaunchKernelGGL(k_cg_slack_pap, dim3(g), dim3(kBlock), 0, ctx().stream, cg_vecs(s, nullptr, nullptr), w, s->part.p);
+    hipLaunchKernelGGL(k_cg_tail, dim3(1), dim3(kBlock), 0, ctx().stream, g, 1, s->part.p, tail);
+    SLP_HIP(hipGetLastError());
 }
 
 // Batched form (reuse mode + strip kernels): the products A x and A dir that the NEXT line search needs are
@@ -501,15 +595,18 @@ static void cg_elem(slp_admm_cg *s, int slot, const double *u = nullptr, const d
 // A^T (A x), A^T (A dir) in one two-vector pass: 5 passes over the matrix per iteration instead of 8.
 // Every product is the same arithmetic as in the unbatched form; only the passes are shared.
 static bool cg_batched(slp_admm_cg *s) {
-    if (!s->reuse || s->m <= 0 || s->n_o <= 0) return false;
+    if (!s->reuse) return false;
+    // rows partitioned: never let the sequence (or the size) of the collectives depend on rank-local data -- a rank whose
+    // row block is empty (m == 0: fewer rows than ranks) runs the same batched sequence over zero-sized products
+    if (s->distributed) return true;
+    if (s->m <= 0 || s->n_o <= 0) return false;
     if (s->reuse >= 2) return true;  // the fused form is written on top of the shared products
-    if (s->distributed) return true; // never let the sequence of collectives depend on a rank's local kernel choice
     return fast_format(s->a, false) && fast_format(s->a, true);
 }
 
 static void cg_refresh_products(slp_admm_cg *s) {  // wx = A x, wd = A dir
-    if (s->wx.n < (size_t)s->m) {
-        s->wx.alloc((size_t)s->m); s->wd.alloc((size_t)s->m); s->v1.alloc((size_t)s->m); s->u2.alloc(2 * (size_t)s->n_o);
+    if (!s->u2.p) {  // (+ kCgTail: the packed exchange appends rank-local scalars to the vectors it sends)
+        s->wx.alloc((size_t)s->m); s->wd.alloc((size_t)s->m); s->v1.alloc((size_t)s->m); s->u2.alloc(2 * (size_t)s->n_o + kCgTail);
     }
     cg_rows2(s, s->x.p, s->dir.p, s->wx.p, s->wd.p);
     s->have_w = true;
@@ -525,20 +622,32 @@ static void cg_xstep(slp_admm_cg *s) {
                                s->gamma_eq, s->v1.p);
             SLP_HIP(hipGetLastError());
         }
+        // Rows partitioned, level 4: the slack parts of ALL dot products of the iteration ride behind the two vector
+        // all-reduces (5 doubles behind A^T v1, 1 behind A^T (A r)): two collectives per iteration, no scalar ones.
+        const bool packed = s->distributed && s->reuse >= 4;
         if (s->reuse >= 4 && !s->need_md) {
             // level 4: M dir = step M dir_old + a_cg M r was advanced in E_UPDATE: the A^T pass carries one vector
-            cg_cols(s, s->v1.p, s->u2.p);
-            cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p);
-            cg_elem<E_LINE_DMD_MD>(s, S_DMD);
+            double *tail = s->u2.p + s->n_o;
+            if (packed) cg_slack_pre(s, false, tail);
+            cg_cols(s, s->v1.p, s->u2.p, true, packed ? 5 : 0);
+            cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p, tail, packed ? 1 : 0);
+            cg_elem<E_LINE_DMD_MD>(s, S_DMD, nullptr, nullptr, tail + 1, packed ? 1 : 0);
+            cg_elem<E_LINE_STEP>(s, -1);
+            cg_elem<E_RESID_FUSED>(s, S_RS, nullptr, nullptr, tail + 2, packed ? 2 : 0);
         } else {
-            cg_cols2(s, s->v1.p, s->wd.p, s->u2.p);
-            cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p);
-            cg_elem<E_LINE_DMD>(s, S_DMD, s->u2.p + s->n_o, s->wd.p);
+            double *tail = s->u2.p + 2 * s->n_o;
+            if (packed) cg_slack_pre(s, true, tail);
+            cg_cols2(s, s->v1.p, s->wd.p, s->u2.p, packed ? 5 : 0);
+            cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p, tail, packed ? 1 : 0);
+            cg_elem<E_LINE_DMD>(s, S_DMD, s->u2.p + s->n_o, s->wd.p, tail + 1, packed ? 1 : 0);
             s->need_md = false;
+            cg_elem<E_LINE_STEP>(s, -1);
+            cg_elem<E_RESID_FUSED>(s, S_RS, nullptr, nullptr, tail + 2, packed ? 2 : 0);
         }
-        cg_elem<E_LINE_STEP>(s, -1);
-        cg_elem<E_RESID_FUSED>(s, S_RS);
-        cg_rows(s, s->r.p); cg_cols(s, s->w.p); cg_elem<E_PAP>(s, S_PAP);
+        cg_rows(s, s->r.p);
+        if (packed) cg_slack_pap(s, s->w.p, s->u.p + s->n_o);
+        cg_cols(s, s->w.p, nullptr, true, packed ? 1 : 0);
+        cg_elem<E_PAP>(s, S_PAP, nullptr, nullptr, s->u.p + s->n_o, packed ? 1 : 0);
         cg_elem<E_UPDATE>(s, -1);
         if (s->reuse >= 3) {  // w still holds A r
             hipLaunchKernelGGL(k_cg_wd_update, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->scal.p, s->w.p, s->wd.p);
@@ -575,7 +684,7 @@ static void cg_xstep(slp_admm_cg *s) {
 static void cg_multipliers(slp_admm_cg *s) {
     cg_elem<E_PROJECT>(s, -1);
     const double *ax = s->w.p;
-    if (s->reuse >= 3 && cg_batched(s) && s->wx.n >= (size_t)s->m && ++s->since_refresh < 64) {
+    if (s->reuse >= 3 && cg_batched(s) && s->u2.p && ++s->since_refresh < 64) {
         cg_rows(s, s->x.p, s->wx.p);  // A dir came from the recurrence (k_cg_wd_update): one product, one vector
         s->have_w = true;
         ax = s->wx.p;
@@ -600,7 +709,7 @@ static void cg_alloc_state(slp_admm_cg *s) {
     s->w.alloc(m);
     s->xp.alloc(N); s->y.alloc(N); s->q.alloc(N); s->dir.alloc(N); s->dir.zero(); s->xprev.alloc(N); s->r.alloc(N);
     s->lin.alloc(N); s->lin.zero();
-    s->u.alloc((size_t)s->n_o);
+    s->u.alloc((size_t)s->n_o + kCgTail);
     s->part.alloc((size_t)kCgPartials * 2); s->rowpart.alloc((size_t)kCgPartials * 3); s->colpart.alloc((size_t)kCgPartials * 8);
     s->scal.alloc(S_COUNT); s->scal.zero(); s->out.alloc(16);
     s->distributed = comm_active();

@@ -1,39 +1,49 @@
-// slp_comm.hip -- multi-GPU exchange: one RCCL sum-all-reduce of the n partial
-// column sums K_g^T y_g per Chambolle-Pock iteration (plus one at setup and a
-// few scalars per report).  The reference is single-process; this is new.
+// slp_comm.hip -- multi-GPU exchange: sum-all-reduces of the n partial column
+// sums K_g^T y_g (one per Chambolle-Pock iteration, two per matrix-free ADMM
+// iteration, one per block-splitting iteration), plus one at setup and a few
+// scalars per report.  The reference is single-process; this is new.
 //
-// RCCL is bound with dlopen on first use: a single-GPU process never loads it,
-// and a process that also imports torch does not get a link-time dependency on
-// one particular librccl.  xGMI is point-to-point (7 links per GPU): the
-// message is n doubles (8 MB at n = 1e6), large enough that RCCL's direct
-// reduce-scatter/all-gather schedule over the fully connected node applies; it
-// is issued on the library's own stream, in order with the kernels around it.
+// Transport 1 (product): RCCL over xGMI.  The prototypes, the unique-id struct
+// and the enum values come from <rccl/rccl.h> (compile-time checked); the
+// library itself is bound with dlopen on first use, so a single-GPU process
+// never loads it and the .so carries no link-time dependency on one librccl.
+// xGMI is point-to-point (7 links per GPU): the message is n doubles (8 MB at
+// n = 1e6), large enough for RCCL's direct reduce-scatter / all-gather schedule
+// over the fully connected node; it is issued on the library's compute stream,
+// in order with the kernels around it -- every all-reduce's result is consumed
+// by the very next kernel of the iteration, so there is no rank-local pass to
+// overlap it with.
+//
+// Transport 2 (tests): a host callback (slp_comm_init_host).  The device buffer
+// is copied to the host, the callback reduces it in place across the ranks --
+// over gloo, a pipe, or not at all for a recording stub -- and the result is
+// copied back.  Lets world_size > 1 runs of the REAL partitioned device code
+// share one GPU (RCCL refuses two ranks on one device), and lets tests count
+// and inspect the sequence of collectives.
 #include <dlfcn.h>
 
 #include <cstdlib>
+
+#include <rccl/rccl.h>
 
 #include "slp_common.h"
 
 namespace slp {
 
-struct NcclId { char internal[128]; };
-typedef void *NcclComm;
-typedef int (*fn_get_unique_id)(NcclId *);
-typedef int (*fn_comm_init_rank)(NcclComm *, int, NcclId, int);
-typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
-typedef int (*fn_comm_destroy)(NcclComm);
-typedef const char *(*fn_error_string)(int);
-
 static struct {
     void *lib = nullptr;
-    fn_get_unique_id get_unique_id = nullptr;
-    fn_comm_init_rank comm_init_rank = nullptr;
-    fn_all_reduce all_reduce = nullptr;
-    fn_comm_destroy comm_destroy = nullptr;
-    fn_error_string error_string = nullptr;
-    NcclComm comm = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    ncclComm_t comm = nullptr;
+    slp_host_allreduce_fn host_fn = nullptr;  // transport 2
+    void *host_user = nullptr;
+    std::vector<double> host_buf;
+    bool active = false;
     int nranks = 1, rank = 0;
-    long long collectives = 0;  // all-reduces issued since slp_comm_init (slp_comm_collectives)
+    long long collectives = 0;  // all-reduces issued since slp_comm_init* (slp_comm_collectives)
     DevBuf<double> scratch;
 } g;
 
@@ -48,33 +58,45 @@ static void load_rccl() {
         const char *e = dlerror();  // reading it clears it: once
         throw Error(std::string("cannot load RCCL: ") + (e ? e : "?"));
     }
-    g.get_unique_id = (fn_get_unique_id)dlsym(g.lib, "ncclGetUniqueId");
-    g.comm_init_rank = (fn_comm_init_rank)dlsym(g.lib, "ncclCommInitRank");
-    g.all_reduce = (fn_all_reduce)dlsym(g.lib, "ncclAllReduce");
-    g.comm_destroy = (fn_comm_destroy)dlsym(g.lib, "ncclCommDestroy");
-    g.error_string = (fn_error_string)dlsym(g.lib, "ncclGetErrorString");
+    g.get_unique_id = (decltype(g.get_unique_id))dlsym(g.lib, "ncclGetUniqueId");
+    g.comm_init_rank = (decltype(g.comm_init_rank))dlsym(g.lib, "ncclCommInitRank");
+    g.all_reduce = (decltype(g.all_reduce))dlsym(g.lib, "ncclAllReduce");
+    g.comm_destroy = (decltype(g.comm_destroy))dlsym(g.lib, "ncclCommDestroy");
+    g.error_string = (decltype(g.error_string))dlsym(g.lib, "ncclGetErrorString");
     SLP_REQUIRE(g.get_unique_id && g.comm_init_rank && g.all_reduce && g.comm_destroy, "RCCL symbols missing");
 }
 
-static void check(int rc, const char *what) {
-    if (rc != 0) throw Error(std::string(what) + ": " + (g.error_string ? g.error_string(rc) : "RCCL error"));
+static void check(ncclResult_t rc, const char *what) {
+    if (rc != ncclSuccess) throw Error(std::string(what) + ": " + (g.error_string ? g.error_string(rc) : "RCCL error"));
 }
 
 // SLP_FORCE_DISTRIBUTED=1 runs the partitioned code path (partial sums -> all-reduce -> update) on a single
 // rank too, so that it can be exercised on a one-GPU box; the all-reduce is then the identity.
 bool comm_active() {
-    if (g.comm == nullptr) return false;
+    if (!g.active) return false;
     if (g.nranks > 1) return true;
     const char *e = getenv("SLP_FORCE_DISTRIBUTED");
     return e && e[0] == '1';
 }
 
+// In-place all-reduce of `count` doubles at `buf` (device), ordered with the kernels on the compute stream.
+// `count` must be the same on every rank (callers derive it from global sizes only).
 void comm_allreduce_dev(double *buf, i64 count, int op) {
-    SLP_REQUIRE(g.comm, "slp_comm_init has not been called");
+    SLP_REQUIRE(g.active, "slp_comm_init has not been called");
     if (count <= 0) return;
     ++g.collectives;
-    check(g.all_reduce(buf, buf, (size_t)count, /*ncclFloat64*/ 8, op == 1 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, g.comm, ctx().stream),
-          "ncclAllReduce");
+    hipStream_t st = ctx().stream;
+    if (g.host_fn) {
+        if (g.host_buf.size() < (size_t)count) g.host_buf.resize((size_t)count);
+        SLP_HIP(hipMemcpyAsync(g.host_buf.data(), buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipStreamSynchronize(st));
+        const int rc = g.host_fn(g.host_buf.data(), count, op, g.host_user);
+        SLP_REQUIRE(rc == 0, "host all-reduce callback failed");
+        SLP_HIP(hipMemcpyAsync(buf, g.host_buf.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
+        SLP_HIP(hipStreamSynchronize(st));  // host_buf is reused by the next call
+        return;
+    }
+    check(g.all_reduce(buf, buf, (size_t)count, ncclFloat64, op == 1 ? ncclMax : ncclSum, g.comm, st), "ncclAllReduce");
 }
 
 }  // namespace slp
@@ -85,8 +107,9 @@ extern "C" {
 
 int slp_comm_unique_id(char id[128]) {
     SLP_API_INT({
+        static_assert(sizeof(ncclUniqueId) == 128, "slp_comm_unique_id hands out NCCL_UNIQUE_ID_BYTES = 128 bytes");
         load_rccl();
-        NcclId nid;
+        ncclUniqueId nid;
         check(g.get_unique_id(&nid), "ncclGetUniqueId");
         memcpy(id, nid.internal, 128);
     })
@@ -96,24 +119,44 @@ int slp_comm_init(int nranks, int rank, const char id[128]) {
     SLP_API_INT({
         SLP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks && id, "slp_comm_init: bad arguments");
         ctx();
-        SLP_REQUIRE(!g.comm, "slp_comm_init: already initialised");
+        SLP_REQUIRE(!g.active, "slp_comm_init: already initialised");
         load_rccl();
-        NcclId nid;
+        ncclUniqueId nid;
         memcpy(nid.internal, id, 128);
         check(g.comm_init_rank(&g.comm, nranks, nid, rank), "ncclCommInitRank");
         g.nranks = nranks;
         g.rank = rank;
+        g.collectives = 0;
+        g.active = true;
+        g.scratch.alloc(64);
+    })
+}
+
+int slp_comm_init_host(int nranks, int rank, slp_host_allreduce_fn fn, void *user) {
+    SLP_API_INT({
+        SLP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks && fn, "slp_comm_init_host: bad arguments");
+        ctx();
+        SLP_REQUIRE(!g.active, "slp_comm_init_host: already initialised");
+        g.host_fn = fn;
+        g.host_user = user;
+        g.nranks = nranks;
+        g.rank = rank;
+        g.collectives = 0;
+        g.active = true;
         g.scratch.alloc(64);
     })
 }
 
 int slp_comm_finalize(void) {
     SLP_API_INT({
-        if (g.comm) {
+        if (g.active) {
             SLP_HIP(hipStreamSynchronize(ctx().stream));
             g.scratch.release();
-            check(g.comm_destroy(g.comm), "ncclCommDestroy");
+            if (g.comm) check(g.comm_destroy(g.comm), "ncclCommDestroy");
             g.comm = nullptr;
+            g.host_fn = nullptr;
+            g.host_user = nullptr;
+            g.active = false;
             g.nranks = 1;
             g.rank = 0;
         }

@@ -66,6 +66,11 @@ struct Context {
 Context &ctx();          // throws if slp_init has not succeeded
 Context &ctx_unchecked();
 
+// SLP_TRACE=1: driver calls that take longer than 2 ms are reported (setup timeline; see Phase below)
+bool trace_enabled();
+double trace_now();
+void trace_slow(const char *what, size_t bytes, double t0);
+
 // ---- device buffer
 template <class T>
 struct DevBuf {
@@ -82,7 +87,11 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            const double t0 = trace_enabled() ? trace_now() : 0.0;
+            (void)hipFree(p);
+            if (t0 != 0.0) trace_slow("hipFree", n * sizeof(T), t0);
+        }
         p = nullptr;
         n = 0;
     }
@@ -90,7 +99,9 @@ struct DevBuf {
         release();
         n = count;
         // never hand out a NULL device pointer for an empty vector
+        const double t0 = trace_enabled() ? trace_now() : 0.0;
         SLP_HIP(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
+        if (t0 != 0.0) trace_slow("hipMalloc", count * sizeof(T), t0);
     }
     void upload(const T *host, size_t count) {
         if (count > n || !p) alloc(count);
@@ -157,11 +168,8 @@ struct Phase {
     const char *name;
     double t0 = 0.0;
     bool on;
-    static bool enabled() {
-        static const int e = [] { const char *v = getenv("SLP_TRACE"); return (v && v[0] == '1') ? 1 : 0; }();
-        return e != 0;
-    }
-    static double now();
+    static bool enabled() { return trace_enabled(); }
+    static double now() { return trace_now(); }
     explicit Phase(const char *n) : name(n), on(enabled()) {
         if (on) { (void)hipStreamSynchronize(ctx().stream); t0 = now(); }
     }

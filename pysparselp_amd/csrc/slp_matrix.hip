@@ -17,7 +17,15 @@ namespace slp {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
-double Phase::now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool trace_enabled() {
+    static const int e = [] { const char *v = getenv("SLP_TRACE"); return (v && v[0] == '1') ? 1 : 0; }();
+    return e != 0;
+}
+double trace_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void trace_slow(const char *what, size_t bytes, double t0) {
+    const double ms = (trace_now() - t0) * 1e3;
+    if (ms > 2.0) fprintf(stderr, "[slp trace]     %-10s %8.1f MB %9.3f ms\n", what, (double)bytes / 1e6, ms);
+}
 
 static Context g_ctx;
 Context &ctx_unchecked() { return g_ctx; }

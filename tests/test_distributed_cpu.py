@@ -149,6 +149,55 @@ def _rank_main(rank, world, port, out):
         lam = lam + ge * (a_apply(xo, xs) - 0.0)
     out["admm_x"] = xo
 
+    # --- the same ADMM in the form the device runs at scale (slp_admm_cg.hip, reuse level 4, rows partitioned): fused
+    #     gradient g = M x - y, M dir and A dir carried by recurrences, and the PACKED exchange -- the rank-local slack parts
+    #     of all dot products ride behind the two vector all-reduces (5 doubles behind A^T v1, 1 behind A^T (A r)); r.r over
+    #     the slack unknowns is rebuilt from three reduced coefficients once the step is known.  Exactly two collectives
+    #     per iteration, counted here.
+    counter = {"n": 0}
+
+    def allreduce_counted(v):
+        counter["n"] += 1
+        return allreduce(v)
+
+    xo, xs = np.zeros(n), np.zeros(rows)
+    xpo, xps = np.maximum(xo, 0), np.maximum(xs, 0)
+    lam, lio, lis = np.zeros(rows), np.zeros(n), np.zeros(rows)
+    diro, dirs, mdo, mds = np.zeros(n), np.zeros(rows), np.zeros(n), np.zeros(rows)
+    qo, qs = -co, np.zeros(rows)                       # q = -c + g_eq A^T b, b = 0
+    v1 = ge * a_apply(xo, xs) + lam
+    for _ in range(30):
+        gs = (sc * v1 + gi * xs) - ((qs + gi * xps) - lis)         # rank-local pre-pass over the slack unknowns
+        tail = np.array([dirs.dot(gs), dirs.dot(mds), gs.dot(gs), gs.dot(mds), mds.dot(mds)])
+        red = allreduce_counted(np.concatenate((oracle.rmatvec(a2, v1), tail)))     # collective 1: n + 5
+        go = (red[:n] + gi * xo) - ((qo + gi * xpo) - lio)
+        tl = red[n:]
+        xprev_o, xprev_s = xo.copy(), xs.copy()
+        t = -(diro.dot(go) + tl[0])
+        step = 0.0
+        if abs(t) > 0:
+            step = t / (diro.dot(mdo) + tl[1])
+            xo, xs = xo + step * diro, xs + step * dirs
+        ro, rs_ = -(go + step * mdo), -(gs + step * mds)
+        rsold = ro.dot(ro) + ((tl[2] + 2.0 * step * tl[3]) + (step * step) * tl[4])
+        w = a_apply(ro, rs_)
+        aps = ge * (sc * w) + gi * rs_
+        red = allreduce_counted(np.concatenate((oracle.rmatvec(a2, w), [rs_.dot(aps)])))  # collective 2: n + 1
+        apo = ge * red[:n] + gi * ro
+        a_cg = rsold / (ro.dot(apo) + red[n])
+        xo, xs = xo + a_cg * ro, xs + a_cg * rs_
+        mdo, mds = step * mdo + a_cg * apo, step * mds + a_cg * aps
+        diro, dirs = xo - xprev_o, xs - xprev_s
+        xo, xs = alpha * xo + (1 - alpha) * xpo, alpha * xs + (1 - alpha) * xps
+        xpo = np.minimum(np.maximum(xo + lio / gi, lbo), ubo)
+        xps = np.minimum(np.maximum(xs + lis / gi, lbs), ubs)
+        lio, lis = lio + gi * (xo - xpo), lis + gi * (xs - xps)
+        wx = a_apply(xo, xs)
+        lam = lam + ge * wx
+        v1 = ge * wx + lam
+    assert counter["n"] == 2 * 30
+    out["admm_packed_x"] = xo
+
     # --- block-splitting ADMM, one block per rank (slp_blocks.hip, rb_iteration): the rank's rows with their slacks kept
     #     implicit; per-block projection local (here: a direct solve of S nu = rhs), consensus sum = the only all-reduce
     gam, alf = 0.7, 1.95
@@ -203,6 +252,9 @@ def test_row_partitioned_solvers_match_single_process_oracle():
     for r in range(world):
         assert np.max(np.abs(results[r]["admm_x"] - x_ref) / (1 + np.abs(x_ref))) < 1e-9
     assert np.array_equal(results[0]["admm_x"], results[1]["admm_x"])
+    for r in range(world):  # the packed two-collective form the device runs at scale
+        assert np.max(np.abs(results[r]["admm_packed_x"] - x_ref) / (1 + np.abs(x_ref))) < 1e-9
+    assert np.array_equal(results[0]["admm_packed_x"], results[1]["admm_packed_x"])
     # the reference's block-splitting ADMM with the two row halves as its blocks (sparse LU per block)
     m = a.shape[0]
     cuts = [row_block(m, world, r) for r in range(world)]

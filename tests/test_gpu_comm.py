@@ -60,3 +60,61 @@ def test_partitioned_path_single_rank(min_nnz):
     code = SCRIPT % {"repo": REPO, "min_nnz": min_nnz}
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "COMM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The exchange steps themselves, recorded: slp_comm_init_host routes every all-reduce of the partitioned device
+# code through a host callback (here: one rank, the callback records (count, op) and leaves the buffer alone).
+RECORD_SCRIPT = r"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r)
+os.environ["SLP_FORCE_DISTRIBUTED"] = "1"
+os.environ["SLP_STRIP_MIN_NNZ"] = "1"
+from pysparselp_amd import _lib
+from pysparselp_amd.problems import random_lp_on_device
+from pysparselp_amd.scale import DeviceBlocks, DeviceCP
+from pysparselp_amd.admm_cg import DeviceADMM
+lib = _lib.lib(0)
+calls = []
+@_lib.HOST_ALLREDUCE_FN
+def record(buf, count, op, user):
+    calls.append((int(count), int(op)))
+    return 0
+_lib.check(lib.slp_comm_init_host(1, 0, record, None))
+n, m, p = 30000, 40000, 0.001
+a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=3)
+
+def per_iteration(solver, warm, k):
+    solver.iterate(warm)
+    del calls[:]
+    c0 = lib.slp_comm_collectives()
+    solver.iterate(k)
+    assert lib.slp_comm_collectives() - c0 == len(calls)
+    return list(calls)
+
+cp = DeviceCP(a, b, c, lb, ub)
+got = per_iteration(cp, 2, 10)
+assert got == [(n, 0)] * 10, got[:4]                      # Chambolle-Pock: ONE all-reduce of the n partial column sums
+cp.close()
+
+admm = DeviceADMM(a, b, c, lb, ub)                        # reuse level 4 (the default at scale)
+got = per_iteration(admm, 3, 10)                          # iterations 4..13: no refresh inside
+assert got == [(n + 5, 0), (n + 1, 0)] * 10, got[:6]      # TWO: A^T v1 (+5 packed scalars), A^T (A r) (+1); no scalar all-reduces
+got = per_iteration(admm, 40, 20)                         # iterations 54..73: the refresh of iteration 64 falls inside
+assert len(got) == 40 and got.count((2 * n + 5, 0)) == 1 and got.count((n + 5, 0)) == 19 and got.count((n + 1, 0)) == 20, got
+admm.close()
+
+blk = DeviceBlocks(a, b, c, lb, ub, cg_max_steps=30)
+got = per_iteration(blk, 1, 3)
+assert got == [(n, 0)] * 3, got                           # block splitting: ONE consensus all-reduce, none inside the block CG
+blk.close()
+a.close()
+_lib.check(lib.slp_comm_finalize())
+print("RECORD-OK")
+"""
+
+
+def test_collectives_per_iteration_are_counted_and_minimal():
+    r = subprocess.run([sys.executable, "-c", RECORD_SCRIPT % {"repo": REPO}], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RECORD-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

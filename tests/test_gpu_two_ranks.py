@@ -1,0 +1,107 @@
+"""world_size = 2 runs of the REAL row-partitioned device code on ONE GPU: two processes bind the same device and
+exchange through the host-callback transport (slp_comm_init_host; here a pipe between the two processes) -- RCCL
+itself refuses two ranks on one device, everything above it (partial sums, packed scalars, sequence and sizes of the
+collectives, unequal and EMPTY row blocks) is the product's code.  The two replicas must stay bit-identical and match
+the single-process run of the whole problem to summation-order tolerance.  -m gpu."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rank(rank, world, conn, n, m, p, seed, iters, q):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ["SLP_STRIP_MIN_NNZ"] = "1"  # strip kernels, value dictionary, deferred row scaling: the at-scale configuration
+        from pysparselp_amd import _lib
+        from pysparselp_amd.admm_cg import DeviceADMM
+        from pysparselp_amd.parallel import row_block
+        from pysparselp_amd.problems import random_lp_on_device
+        from pysparselp_amd.scale import DeviceCP
+
+        lib = _lib.lib(0)
+        sizes = []
+
+        @_lib.HOST_ALLREDUCE_FN
+        def allreduce(buf, count, op, user):
+            mine = np.ctypeslib.as_array(buf, shape=(count,))
+            sizes.append(int(count))
+            if rank == 0:  # one side sends first, the other receives first: no deadlock on large buffers
+                conn.send_bytes(mine.tobytes())
+                other = np.frombuffer(conn.recv_bytes(), dtype=np.float64)
+                res = np.maximum(mine, other) if op == 1 else mine + other
+            else:
+                other = np.frombuffer(conn.recv_bytes(), dtype=np.float64)
+                conn.send_bytes(mine.tobytes())
+                res = np.maximum(other, mine) if op == 1 else other + mine  # rank 0's term first on both sides
+            assert other.size == count, (other.size, count)  # the ranks disagree on a collective's size
+            mine[:] = res
+            return 0
+
+        if world > 1:
+            _lib.check(lib.slp_comm_init_host(world, rank, allreduce, None))
+        r0, rows = row_block(m, world, rank)
+        a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=seed, row_offset=r0, rows=rows)
+        out = {"rows": rows}
+        cp = DeviceCP(a, b, c, lb, ub)
+        cp.iterate(iters)
+        out["cp_x"] = cp.x()
+        cp.close()
+        admm = DeviceADMM(a, b, c, lb, ub)
+        assert admm.reuse == 4
+        admm.iterate(iters)
+        out["admm_x"] = admm.x(n)
+        out["admm_report"] = admm.report()[:3]
+        admm.close()
+        a.close()
+        out["sizes"] = sizes
+        if world > 1:
+            _lib.check(lib.slp_comm_finalize())
+        q.put((rank, out))
+    except BaseException as e:  # noqa: BLE001 -- report instead of leaving the peer blocked on the pipe
+        import traceback
+
+        q.put((rank, {"error": traceback.format_exc() + repr(e)}))
+
+
+def _run(world, n, m, p, seed, iters):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ends = ctx.Pipe(duplex=True) if world == 2 else (None, None)
+    procs = [ctx.Process(target=_rank, args=(r, world, ends[r] if world == 2 else None, n, m, p, seed, iters, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = {}
+    for _ in range(world):
+        rank, out = q.get(timeout=600)
+        assert "error" not in out, out["error"]
+        res[rank] = out
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n,m,iters", [(30000, 40001, 70), (3000, 1, 12)])
+def test_two_ranks_on_one_gpu_match_the_single_process_run(n, m, iters):
+    """m = 40001: unequal row blocks (20001 / 20000), 70 iterations cross the level-4 refresh at iteration 64.
+    m = 1: rank 1's row block is EMPTY -- it must issue exactly the same collectives over zero-sized products."""
+    p, seed = 0.001, 3
+    one = _run(1, n, m, p, seed, iters)[0]
+    two = _run(2, n, m, p, seed, iters)
+    assert two[0]["rows"] + two[1]["rows"] == m and (m > 1 or two[1]["rows"] == 0)
+    assert two[0]["sizes"] == two[1]["sizes"] and len(two[0]["sizes"]) > 2 * iters
+    for key in ("cp_x", "admm_x"):
+        assert np.array_equal(two[0][key], two[1][key]), key  # replicas never drift apart
+        ref = one[key]
+        err = float(np.max(np.abs(two[0][key] - ref) / (1 + np.abs(ref))))
+        assert err < 1e-9, (key, err)
+    assert np.allclose(two[0]["admm_report"], two[1]["admm_report"], rtol=0, atol=0)
+    assert np.allclose(two[0]["admm_report"], one["admm_report"], rtol=1e-8, atol=1e-9)
