@@ -41,6 +41,10 @@ int slp_device_count(void);
 /* Bind this process to `device` and create the library's stream. */
 int slp_init(int device);
 int slp_synchronize(void);
+/* Device memory the library has freed is kept in a cache (keyed by size) for its next allocation instead of being
+ * returned to the driver; slp_trim() returns it all, slp_cached_bytes() tells how much is parked. */
+int slp_trim(void);
+int64_t slp_cached_bytes(void);
 const char *slp_last_error(void);
 /* Milliseconds the GPU spent between the two most recent slp_timer_start /
  * slp_timer_stop marks on the library's stream (HIP events). */
@@ -83,6 +87,14 @@ int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, do
  * scale 1 copies, -1 negates exactly. */
 slp_matrix *slp_matrix_gather_rows(slp_matrix *a, int64_t count, const int64_t *rows, const double *scale);
 int slp_matrix_spmv_kernel(slp_matrix *a, int transposed);
+/* M = gamma_eq A^T A + gamma_ineq I (N x N CSR, sorted rows, exact zeros dropped) formed on the device: replaces
+ * `(gamma_eq * a.T * a + gamma_ineq * eye).tocsr()` of ADMM.py:93-101, i.e. scipy's SMMP csr_matmat, with the same
+ * accumulation order per entry (shared rows increasingly, from 0.0) -- bit-identical values. */
+slp_matrix *slp_matrix_normal(slp_matrix *a, double gamma_eq, double gamma_ineq);
+/* a[:, keep] (keep[ncol] = 0 / 1; entries stay in storage order, columns renumbered) as a new device matrix: the
+ * column compaction of SparseLP.remove_fixed_variables (SparseLP.py:632-674).  With shift[ncol] != NULL also
+ * a_shift[nrow] = A * shift (csr_matvec order, unreduced matrix) for `b - A * shift` (:646-650); both host vectors. */
+slp_matrix *slp_matrix_remove_columns(slp_matrix *a, const unsigned char *keep, const double *shift, double *a_shift);
 /* Which derived copies the products may use: 0 (default) = the best the matrix qualifies for; 1 = no value dictionary
  * (fp64 entries in the strips: the general, any-values path); 2 = CSR kernels only.  Frees the strip copies built so
  * far; fails while a solver created on the matrix is alive. */
@@ -143,7 +155,7 @@ int slp_gs_solve(slp_gs *g, const double *b, const double *lower, const double *
 /* ---- ADMM: replaces lp_admm's loop (ADMM.py:143-268) -------------------- *
  * Inputs are the standard-form, row-normalised problem of ADMM.py:76-101:
  * A (m x N), b, c, lb, ub, x0 (all length N resp. m), M = gamma_eq A^T A +
- * gamma_ineq I (N x N, CSR).  One iteration:
+ * gamma_ineq I (N x N, CSR; m_indptr == NULL: formed on the device by slp_matrix_normal).  One iteration:
  *   y = -c + gamma_eq A^T b + gamma_ineq xp - A^T lambda      (:148)
  *   one projected Gauss-Seidel sweep of M x = y, in place on x (:162)
  *   xp = x (alias, :259) ; lambda += gamma_eq (A x - b)        (:261-263) */

@@ -6,12 +6,15 @@ explicit ``M = gamma_eq A^T A + gamma_ineq I`` (flags at ADMM.py:66-71).  Same
 signature, callback contract and return value (the first ``n`` entries of the
 standard-form iterate).
 
-Setup (row normalisation, slack standard form, ``M``) is done once on the host,
-like in the reference (tools.py of this package); the loop -- right-hand side
-with ``A^T lambda``, the level-scheduled Gauss-Seidel sweep, the multiplier
-update with ``A x`` and the report reductions -- runs on the GPU
-(pysparselp_amd/csrc/slp_admm.hip).
+Row normalisation and the slack standard form are computed on the host like in
+the reference (tools.py of this package); the standard-form matrix is uploaded
+ONCE and ``M = gamma_eq A^T A + gamma_ineq I`` is formed from it on the device
+(csrc/slp_spgemm.hip: scipy's SMMP accumulation order, bit-identical values).
+The loop -- right-hand side with ``A^T lambda``, the level-scheduled
+Gauss-Seidel sweep, the multiplier update with ``A x`` and the report
+reductions -- runs on the GPU (csrc/slp_admm.hip).
 """
+import os
 import time
 
 import numpy as np
@@ -25,6 +28,7 @@ class ADMMState:
     """Device-resident ADMM state (thin RAII wrapper of ``slp_admm``)."""
 
     def __init__(self, a, b, c, lb, ub, x0, m, gamma_eq, gamma_ineq, order=ORDER_AUTO):
+        """``m``: the explicit ``M`` (CSR arrays) or ``None`` to have it formed on the device from ``a``."""
         self._l = _lib.lib()
         self.N = a.shape[1]
         self.m = a.shape[0]
@@ -32,7 +36,7 @@ class ADMMState:
         assert b.size == self.m and c.size == self.N and lb.size == self.N and ub.size == self.N and x0.size == self.N
         self._h = _lib.check_handle(self._l.slp_admm_create(
             self.N, self.m, _lib.ptr(a.indptr), _lib.ptr(a.indices), _lib.ptr(a.data), _lib.ptr(b), _lib.ptr(c),
-            _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(x0), _lib.ptr(m.indptr), _lib.ptr(m.indices), _lib.ptr(m.data),
+            _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(x0), *((None, None, None) if m is None else (_lib.ptr(m.indptr), _lib.ptr(m.indices), _lib.ptr(m.data))),
             float(gamma_eq), float(gamma_ineq), int(order)))
 
     def close(self):
@@ -127,7 +131,8 @@ def lp_admm(
     c2, a, b, lb2, ub2, x_init = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
     if use_preconditioning:
         a, b = precondition_constraints(a, b, alpha=2)
-    m_mat = normal_matrix(a, gamma_eq, gamma_ineq)  # ADMM.py:93-101
+    # ADMM.py:93-101: M is formed on the device from the uploaded A (SLP_HOST_SPGEMM=1: scipy's product on the host instead)
+    m_mat = normal_matrix(a, gamma_eq, gamma_ineq) if os.environ.get("SLP_HOST_SPGEMM") == "1" else None
 
     state = ADMMState(a, b, c2, lb2, ub2, x_init, m_mat, gamma_eq, gamma_ineq, order)
     if xstep == "gauss_seidel_unbounded":  # the reference's use_unbounded_gauss_siedel flags (ADMM.py:164-181)

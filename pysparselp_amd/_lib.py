@@ -29,6 +29,8 @@ _SIGNATURES = {
     "slp_device_count": (c_int, []),
     "slp_init": (c_int, [c_int]),
     "slp_synchronize": (c_int, []),
+    "slp_trim": (c_int, []),
+    "slp_cached_bytes": (c_i64, []),
     "slp_last_error": (ctypes.c_char_p, []),
     "slp_timer_start": (c_int, []),
     "slp_timer_stop": (c_int, [c_vp]),
@@ -43,6 +45,8 @@ _SIGNATURES = {
     "slp_matrix_gather_rows": (c_vp, [c_vp, c_i64, c_vp, c_vp]),
     "slp_matrix_spmv_kernel": (c_int, [c_vp, c_int]),
     "slp_matrix_set_format": (c_int, [c_vp, c_int]),
+    "slp_matrix_normal": (c_vp, [c_vp, c_dbl, c_dbl]),
+    "slp_matrix_remove_columns": (c_vp, [c_vp, c_vp, c_vp, c_vp]),
     "slp_matrix_format_bytes": (c_i64, [c_vp, c_int]),
     "slp_cp_create": (c_vp, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_cp_create_on": (c_vp, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),

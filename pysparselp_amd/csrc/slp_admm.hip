@@ -688,7 +688,7 @@ slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr, const i
                           const int64_t *m_indptr, const int32_t *m_indices, const double *m_data, double gamma_eq,
                           double gamma_ineq, int order) {
     SLP_API_PTR({
-        SLP_REQUIRE(a_indptr && b && c && lb && ub && x0 && m_indptr, "slp_admm_create: NULL argument");
+        SLP_REQUIRE(a_indptr && b && c && lb && ub && x0, "slp_admm_create: NULL argument");
         auto *s = new slp_admm();
         try {
             s->a = slp_matrix_create(m, N, a_indptr, a_indices, a_data);
@@ -697,7 +697,24 @@ slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr, const i
             s->N = N; s->m = m; s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
             s->lanes_rows = lanes_for(s->a->a, order);
             s->lanes_cols = lanes_for(s->a->at, order);
-            gs_plan(s->plan, N, m_indptr, m_indices, m_data);
+            if (m_indptr) {
+                gs_plan(s->plan, N, m_indptr, m_indices, m_data);
+            } else {
+                // M = gamma_eq A^T A + gamma_ineq I formed on the device (slp_spgemm.hip, SMMP accumulation order); the
+                // level schedule of the sweep is still planned on the host from one download of M
+                slp_matrix *mm = slp_matrix_normal(s->a, gamma_eq, gamma_ineq);
+                if (!mm) throw Error(slp_last_error());
+                try {
+                    std::vector<i64> mp((size_t)N + 1);
+                    std::vector<i32> mj((size_t)mm->a.nnz);
+                    std::vector<double> mx((size_t)mm->a.nnz);
+                    mm->a.ptr.download(mp.data(), mp.size());
+                    mm->a.idx.download(mj.data(), mj.size());
+                    mm->a.val.download(mx.data(), mx.size());
+                    gs_plan(s->plan, N, mp.data(), mj.data(), mx.data());
+                } catch (...) { delete mm; throw; }
+                delete mm;
+            }
             s->b.upload(b, (size_t)m); s->c.upload(c, (size_t)N); s->lb.upload(lb, (size_t)N); s->ub.upload(ub, (size_t)N);
             s->x.upload(x0, (size_t)N);
             s->xp0.alloc((size_t)N); s->lam.alloc((size_t)m); s->lam.zero();

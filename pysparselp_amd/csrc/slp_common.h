@@ -71,37 +71,43 @@ bool trace_enabled();
 double trace_now();
 void trace_slow(const char *what, size_t bytes, double t0);
 
+// ---- device memory: a caching sub-allocator in front of hipMalloc / hipFree (slp_matrix.hip).
+// Returning multi-GB blocks to the driver and asking for new ones is erratic on this platform -- a hipMalloc that follows
+// large frees was measured at 1.1 - 3.4 s (profiles/r02_setup_trace_first.txt) against < 1 ms otherwise -- and the setup
+// phases allocate and drop tens of GB of temporaries (sort buffers, counts).  Freed blocks are kept, keyed by capacity, and
+// handed to the next request they fit (capacity within 2x of the request); slp_trim() or an out-of-memory retry releases
+// them.  Stream-ordered like hipFree here: every user of a block is on the library's one stream, and a block is only
+// reused by work enqueued later on that stream.
+void *dev_alloc(size_t bytes, size_t *capacity);
+void dev_free(void *p, size_t capacity);
+
 // ---- device buffer
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t cap = 0;  // bytes of the underlying block
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = 0; o.cap = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = 0; o.cap = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) {
-            const double t0 = trace_enabled() ? trace_now() : 0.0;
-            (void)hipFree(p);
-            if (t0 != 0.0) trace_slow("hipFree", n * sizeof(T), t0);
-        }
+        if (p) dev_free(p, cap);
         p = nullptr;
         n = 0;
+        cap = 0;
     }
     void alloc(size_t count) {
         release();
-        n = count;
         // never hand out a NULL device pointer for an empty vector
-        const double t0 = trace_enabled() ? trace_now() : 0.0;
-        SLP_HIP(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
-        if (t0 != 0.0) trace_slow("hipMalloc", count * sizeof(T), t0);
+        p = static_cast<T *>(dev_alloc((count ? count : 1) * sizeof(T), &cap));
+        n = count;
     }
     void upload(const T *host, size_t count) {
         if (count > n || !p) alloc(count);

@@ -4,6 +4,8 @@
 // (ChambollePockPPD.py:206,216,235,240 ; ADMM.py:95,148,220,262).
 #include <chrono>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <cstring>
 #include <cstdlib>
 
@@ -25,6 +27,60 @@ double trace_now() { return std::chrono::duration<double>(std::chrono::steady_cl
 void trace_slow(const char *what, size_t bytes, double t0) {
     const double ms = (trace_now() - t0) * 1e3;
     if (ms > 2.0) fprintf(stderr, "[slp trace]     %-10s %8.1f MB %9.3f ms\n", what, (double)bytes / 1e6, ms);
+}
+
+// ---- caching device allocator (slp_common.h) ---------------------------------------------------------------
+static std::multimap<size_t, void *> g_free_blocks;  // capacity -> block
+static size_t g_cached_bytes = 0;
+static std::mutex g_alloc_mutex;
+
+static void trim_cache() {
+    for (auto &kv : g_free_blocks) (void)hipFree(kv.second);
+    g_free_blocks.clear();
+    g_cached_bytes = 0;
+}
+
+void *dev_alloc(size_t bytes, size_t *capacity) {
+    static const bool off = [] { const char *e = getenv("SLP_NO_ALLOC_CACHE"); return e && e[0] == '1'; }();
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    if (!off) {
+        auto it = g_free_blocks.lower_bound(want);
+        if (it != g_free_blocks.end() && it->first <= 2 * want + (1u << 20)) {
+            void *p = it->second;
+            *capacity = it->first;
+            g_cached_bytes -= it->first;
+            g_free_blocks.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    const double t0 = trace_enabled() ? trace_now() : 0.0;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && !g_free_blocks.empty()) {  // out of memory with blocks parked in the cache: give them back, retry
+        (void)hipGetLastError();
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+        trim_cache();
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) throw Error(std::string("hipMalloc of ") + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+    if (t0 != 0.0) trace_slow("hipMalloc", want, t0);
+    *capacity = want;
+    return p;
+}
+
+void dev_free(void *p, size_t capacity) {
+    static const bool off = [] { const char *e = getenv("SLP_NO_ALLOC_CACHE"); return e && e[0] == '1'; }();
+    if (!p) return;
+    if (off || capacity == 0) {
+        const double t0 = trace_enabled() ? trace_now() : 0.0;
+        (void)hipFree(p);
+        if (t0 != 0.0) trace_slow("hipFree", capacity, t0);
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    g_free_blocks.emplace(capacity, p);
+    g_cached_bytes += capacity;
 }
 
 static Context g_ctx;
@@ -55,29 +111,35 @@ __global__ __launch_bounds__(kBlock) void k_spmv(i64 nrow, const i64 *__restrict
     }
 }
 
-__global__ void k_count_cols(i64 nnz, const i32 *__restrict__ idx, unsigned long long *__restrict__ count) {
-    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (i64)gridDim.x * blockDim.x)
-        atomicAdd(&count[idx[k]], 1ull);
+// ---- device transposition (build_transpose) ----------------------------------------------------------------
+// rowid[k] = the row of stored entry k: one wavefront per row, coalesced stores
+__global__ __launch_bounds__(kBlock) void k_expand_rows(i64 nrow, const i64 *__restrict__ ptr, i32 *__restrict__ rowid) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const i64 wave = ((i64)blockIdx.x * kBlock + threadIdx.x) / kWave, nwaves = (i64)gridDim.x * kBlock / kWave;
+    for (i64 r = wave; r < nrow; r += nwaves) {
+        const i64 s = ptr[r], e = ptr[r + 1];
+        for (i64 k = s + lane; k < e; k += kWave) rowid[k] = (i32)r;
+    }
 }
 
-__global__ void k_iota_u32(i64 n, unsigned int *__restrict__ p) {
-    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) p[k] = (unsigned int)k;
+// The row pointer of the transposed matrix from the SORTED column keys: tptr[c] = first position whose key is >= c.
+// Position p writes the pointer of every column in (key[p-1], key[p]] (a run of empty columns is written by the entry
+// that ends it); the last position also closes (key[nnz-1], ncol].  Replaces a histogram of 2e9 global atomics.
+__global__ void k_ptr_from_sorted(i64 nnz, i64 ncol, const unsigned int *__restrict__ key, i64 *__restrict__ tptr) {
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (i64)gridDim.x * blockDim.x) {
+        const i64 c = key[p], prev = p > 0 ? (i64)key[p - 1] : -1;
+        for (i64 j = prev + 1; j <= c; ++j) tptr[j] = p;
+        if (p == nnz - 1)
+            for (i64 j = c + 1; j <= ncol; ++j) tptr[j] = nnz;
+    }
 }
 
-// After the stable sort by column: position p of the transposed matrix holds
-// source entry perm[p]; its row in A is found by bisection in A's row pointer.
-__global__ void k_gather_transposed(i64 nnz, i64 nrow, const i64 *__restrict__ ptr, const double *__restrict__ val,
-                                    const unsigned int *__restrict__ perm, i32 *__restrict__ trow,
-                                    double *__restrict__ tval) {
+// After the stable sort by column: position p of the transposed matrix holds source entry perm[p].
+__global__ void k_gather_transposed(i64 nnz, const i32 *__restrict__ rowid, const double *__restrict__ val,
+                                    const unsigned int *__restrict__ perm, i32 *__restrict__ trow, double *__restrict__ tval) {
     for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (i64)gridDim.x * blockDim.x) {
         const i64 src = perm[p];
-        i64 lo = 0, hi = nrow;  // largest r with ptr[r] <= src
-        while (hi - lo > 1) {
-            const i64 mid = (lo + hi) >> 1;
-            if (ptr[mid] <= src) lo = mid;
-            else hi = mid;
-        }
-        trow[p] = (i32)lo;
+        trow[p] = rowid[src];
         tval[p] = val[src];
     }
 }
@@ -182,38 +244,34 @@ void build_transpose(slp_matrix *m) {
     t.ptr.alloc((size_t)t.nrow + 1);
     t.idx.alloc((size_t)a.nnz);
     t.val.alloc((size_t)a.nnz);
-    // column pointer: histogram + exclusive scan (integer atomics: order-independent)
-    DevBuf<unsigned long long> count((size_t)t.nrow + 1);
-    count.zero();
     if (a.nnz) {
-        hipLaunchKernelGGL(k_count_cols, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, a.idx.p, count.p);
-        SLP_HIP(hipGetLastError());
-    }
-    {
-        size_t bytes = 0;
-        SLP_HIP(rocprim::exclusive_scan(nullptr, bytes, count.p, (unsigned long long *)t.ptr.p, 0ull, (size_t)t.nrow + 1,
-                                        rocprim::plus<unsigned long long>(), st));
-        DevBuf<char> tmp(bytes);
-        SLP_HIP(rocprim::exclusive_scan(tmp.p, bytes, count.p, (unsigned long long *)t.ptr.p, 0ull, (size_t)t.nrow + 1,
-                                        rocprim::plus<unsigned long long>(), st));
-        SLP_HIP(hipStreamSynchronize(st));
-    }
-    count.release();
-    if (a.nnz) {
-        DevBuf<unsigned int> pos_in((size_t)a.nnz), pos_out((size_t)a.nnz), key_out((size_t)a.nnz);
-        hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, pos_in.p);
-        SLP_HIP(hipGetLastError());
+        // stable LSD radix sort of (column, position) pairs; positions come from a counting iterator
+        DevBuf<unsigned int> pos_out((size_t)a.nnz), key_out((size_t)a.nnz);
         unsigned int bits = 1;
         while (bits < 32 && ((i64)1 << bits) < a.ncol) ++bits;
         size_t bytes = 0;
         const unsigned int *keys_in = reinterpret_cast<const unsigned int *>(a.idx.p);
-        SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, key_out.p, pos_in.p, pos_out.p, (size_t)a.nnz, 0u, bits, st));
-        DevBuf<char> tmp(bytes);
-        SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys_in, key_out.p, pos_in.p, pos_out.p, (size_t)a.nnz, 0u, bits, st));
-        hipLaunchKernelGGL(k_gather_transposed, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, a.nrow, a.ptr.p,
-                           a.val.p, pos_out.p, t.idx.p, t.val.p);
+        rocprim::counting_iterator<unsigned int> pos_in(0u);
+        SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, key_out.p, pos_in, pos_out.p, (size_t)a.nnz, 0u, bits, st));
+        {
+            DevBuf<char> tmp(bytes);
+            SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys_in, key_out.p, pos_in, pos_out.p, (size_t)a.nnz, 0u, bits, st));
+            SLP_HIP(hipStreamSynchronize(st));
+        }
+        // column pointer straight from the sorted keys
+        hipLaunchKernelGGL(k_ptr_from_sorted, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, t.nrow, key_out.p, t.ptr.p);
         SLP_HIP(hipGetLastError());
         SLP_HIP(hipStreamSynchronize(st));
+        key_out.release();
+        // row of every source entry (coalesced expansion), then two gathers per transposed entry
+        DevBuf<i32> rowid((size_t)a.nnz);
+        hipLaunchKernelGGL(k_expand_rows, dim3(grid_for(a.nrow * kWave, kBlock)), dim3(kBlock), 0, st, a.nrow, a.ptr.p, rowid.p);
+        hipLaunchKernelGGL(k_gather_transposed, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, rowid.p, a.val.p, pos_out.p,
+                           t.idx.p, t.val.p);
+        SLP_HIP(hipGetLastError());
+        SLP_HIP(hipStreamSynchronize(st));
+    } else {
+        t.ptr.zero();
     }
     finish_stats(t);
     m->have_at = true;
@@ -372,6 +430,16 @@ int slp_init(int device) {
         c.ready = true;
     })
 }
+
+int slp_trim(void) {
+    SLP_API_INT({
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+        std::lock_guard<std::mutex> lock(g_alloc_mutex);
+        trim_cache();
+    })
+}
+
+int64_t slp_cached_bytes(void) { return (int64_t)g_cached_bytes; }
 
 int slp_synchronize(void) { SLP_API_INT({ SLP_HIP(hipStreamSynchronize(ctx().stream)); }) }
 

@@ -85,6 +85,26 @@ class DeviceMatrix:
         _lib.check(self._l.slp_matrix_download_rows(self._h, int(transposed), int(row0), int(count), None, _lib.ptr(indices), _lib.ptr(data)))
         return scipy.sparse.csr_matrix((data, indices, indptr - indptr[0]), shape=(count, ncol))
 
+    def normal_matrix(self, gamma_eq, gamma_ineq):
+        """``gamma_eq A^T A + gamma_ineq I`` as a new DeviceMatrix (ADMM.py:93-101), formed on the device in scipy's
+        accumulation order (bit-identical values, sorted rows, exact zeros dropped)."""
+        h = _lib.check_handle(self._l.slp_matrix_normal(self._h, float(gamma_eq), float(gamma_ineq)))
+        return DeviceMatrix(h, (self.shape[1], self.shape[1]))
+
+    def remove_columns(self, keep, shift=None):
+        """``(A[:, keep], A @ shift)``: the column compaction of ``SparseLP.remove_fixed_variables``
+        (SparseLP.py:632-674) on the device; ``keep`` is a boolean mask, entries stay in storage order.
+        ``A @ shift`` (csr_matvec order, unreduced matrix) is ``None`` without ``shift``."""
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        assert keep.size == self.shape[1]
+        a_shift = None
+        if shift is not None:
+            shift = _lib.f64(shift)
+            assert shift.size == self.shape[1]
+            a_shift = np.empty(self.shape[0])
+        h = _lib.check_handle(self._l.slp_matrix_remove_columns(self._h, _lib.ptr(keep), _lib.ptr(shift), _lib.ptr(a_shift)))
+        return DeviceMatrix(h, (self.shape[0], int(keep.sum()))), a_shift
+
     def set_format(self, policy):
         """0: best available copy; 1: no value dictionary (fp64 strip entries); 2: CSR kernels only."""
         _lib.check(self._l.slp_matrix_set_format(self._h, int(policy)))

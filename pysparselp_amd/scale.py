@@ -40,12 +40,25 @@ class DeviceCP:
 
     def __init__(self, a, b_upper, c, lb, ub, alpha=1.0, theta=1.0, order=ORDER_AUTO, m_eq=0, b_lower=None):
         self._l = _lib.lib()
+        self.n_full = a.shape[1]
+        c, b_upper, lb, ub = _lib.f64(c), _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
+        b_lower = None if b_lower is None else _lib.f64(b_lower)
+        self._stacked = self._reduced = None
+        # variables with ub == lb are dropped before the solve like SparseLP.solve does for this method
+        # (SparseLP.py:1244-1248 -> remove_fixed_variables :632-674) -- on the device: column compaction + b - A shift
+        self.free = ub > lb
+        self.shift = np.where(self.free, 0.0, lb)
+        if not self.free.all():
+            self._reduced, a_shift = a.remove_columns(self.free, self.shift)
+            a = self._reduced
+            b_upper = b_upper - a_shift          # equality rows: b_eq - A_eq shift ; inequality rows: b_upper - A_ineq shift
+            if b_lower is not None:
+                b_lower = b_lower - a_shift
+            c, lb, ub = c[self.free], lb[self.free], ub[self.free]
         self.n = a.shape[1]
-        self.c = _lib.f64(c)
-        b_upper, lb, ub = _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
-        self._stacked = None
+        self.c = np.ascontiguousarray(c)
         if b_lower is not None:
-            a, b_upper = self._one_sided(a, int(m_eq), _lib.f64(b_lower), b_upper)
+            a, b_upper = self._one_sided(a, int(m_eq), b_lower, b_upper)
         self.a = a
         self._h = _lib.check_handle(self._l.slp_cp_create_on(a._h, int(m_eq), _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
                                                              _lib.ptr(ub), None, float(alpha), float(theta), int(order)))
@@ -62,22 +75,33 @@ class DeviceCP:
         if getattr(self, "_h", None):
             self._l.slp_cp_destroy(self._h)
             self._h = None
-        if getattr(self, "_stacked", None) is not None:
-            self._stacked.close()
-            self._stacked = None
+        for name in ("_stacked", "_reduced"):
+            if getattr(self, name, None) is not None:
+                getattr(self, name).close()
+                setattr(self, name, None)
 
     __del__ = close
 
     def iterate(self, k):
         _lib.check(self._l.slp_cp_iterate(self._h, int(k)))
 
-    def x(self):
+    def x_reduced(self):
+        """The iterate over the free variables (what the solver works on)."""
         out = np.empty(self.n)
         _lib.check(self._l.slp_cp_get_x(self._h, _lib.ptr(out)))
         return out
 
+    def x(self):
+        """The iterate over ALL variables: free ones from the solver, fixed ones at their value (``m_change x + shift``)."""
+        if self.free.all():
+            return self.x_reduced()
+        out = self.shift.copy()
+        out[self.free] = self.x_reduced()
+        return out
+
     def objective(self):
-        return float(self.c.dot(self.x()))
+        """``c . x`` over the free variables (the reduced problem's objective, as the reference's callback reports it)."""
+        return float(self.c.dot(self.x_reduced()))
 
     def bench(self, k):
         ms = np.zeros(3)

@@ -1,0 +1,119 @@
+"""Device-side problem transforms (csrc/slp_spgemm.hip), all bit-exact:
+  * M = gamma_eq A^T A + gamma_ineq I (ADMM.py:93-101) against the reference-generated fixture and the oracle's SMMP
+    restatement (orc_normal_matrix), including empty columns, sums that cancel to exactly 0 and unsorted rows;
+  * the column compaction of SparseLP.remove_fixed_variables (SparseLP.py:632-674) against scipy's ``a[:, free]``,
+    and Chambolle-Pock over a DeviceMatrix with fixed variables against the oracle on the host-reduced LP.  -m gpu."""
+import numpy as np
+import pytest
+import scipy.sparse
+
+from conftest import csr_of, load_golden
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_csr(dev, ref):
+    got = dev.download()
+    assert got.shape == tuple(ref.shape)
+    assert np.array_equal(got.indptr, ref.indptr)
+    assert np.array_equal(got.indices, ref.indices)
+    assert np.array_equal(got.data, ref.data), np.max(np.abs(got.data - ref.data))
+
+
+def test_normal_matrix_matches_the_reference_fixture_bit_for_bit():
+    from pysparselp_amd.device import DeviceMatrix
+
+    d = load_golden("kernel_kats")
+    a3, m_ref = csr_of(d, "setup_A3"), csr_of(d, "setup_M")  # standard-form, row-normalised A and the reference's M
+    a = DeviceMatrix.from_csr(a3)
+    m = a.normal_matrix(2.0, 3.0)
+    _same_csr(m, m_ref)
+    assert np.array_equal(1.0 / m.download().diagonal(), d["setup_invD"])
+    m.close()
+    a.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_normal_matrix_matches_the_oracle_on_random_matrices(seed):
+    from pysparselp_amd.device import DeviceMatrix
+
+    rng = np.random.RandomState(seed)
+    rows, cols = int(rng.randint(1, 400)), int(rng.randint(1, 300))
+    a = scipy.sparse.random(rows, cols, density=rng.choice([0.01, 0.05, 0.3]), random_state=rng, format="csr")
+    a.data = np.round(rng.randn(a.nnz) * 4) / 4          # quarter-integers: sums cancel to exactly 0 now and then
+    if seed % 2:                                         # unsorted rows: entry order inside a row is part of the contract
+        perm = np.concatenate([s + rng.permutation(e - s) for s, e in zip(a.indptr[:-1], a.indptr[1:])]) if a.nnz else []
+        a = scipy.sparse.csr_matrix((a.data[perm], a.indices[perm], a.indptr), shape=a.shape) if a.nnz else a
+    if cols > 3:
+        a = a.tolil()
+        a[:, 1] = 0                                      # an empty column keeps its diagonal entry gamma_ineq
+        a = a.tocsr()
+        a.eliminate_zeros()
+    ref = oracle.normal_matrix(oracle.as_csr(a), 2.0, 3.0)
+    dev = DeviceMatrix.from_csr(a)
+    m = dev.normal_matrix(2.0, 3.0)
+    got = m.download()
+    assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    assert np.array_equal(got.data, ref.data)
+    m.close()
+    dev.close()
+
+
+def test_lp_admm_forms_m_on_the_device_and_still_matches_the_reference():
+    """lp_admm uploads the standard-form A once; M comes from the device product (not from scipy on the host)."""
+    import os
+
+    from conftest import Recorder, solver_args
+    from pysparselp_amd.ADMM import lp_admm
+
+    d = load_golden("lp_sc105")
+    keep = [it for it in d["admm_it"] if it <= 300]
+    assert os.environ.get("SLP_HOST_SPGEMM") != "1"
+    rec = Recorder(keep)
+    lp_admm(*solver_args(d), nb_iter=300, callback_func=rec, nb_iter_plot=1)
+    assert rec.it == keep
+    for got, ref in zip(rec.x, d["admm_x"]):
+        assert np.array_equal(got, ref)
+
+
+def test_remove_columns_matches_scipy_column_selection():
+    from pysparselp_amd.device import DeviceMatrix
+
+    rng = np.random.RandomState(3)
+    a = scipy.sparse.random(500, 300, density=0.05, random_state=rng, format="csr")
+    a.data = np.round(rng.randn(a.nnz) * 100) / 100
+    free = rng.rand(300) > 0.3
+    shift = np.where(free, 0.0, np.round(rng.randn(300) * 100) / 100)
+    dev = DeviceMatrix.from_csr(a)
+    red, a_shift = dev.remove_columns(free, shift)
+    _same_csr(red, a[:, free])
+    assert np.array_equal(a_shift, oracle.matvec(oracle.as_csr(a), shift))
+    red.close()
+    dev.close()
+
+
+def test_device_cp_with_fixed_variables_matches_the_oracle_on_the_reduced_lp():
+    """A device-resident LP whose bounds pin a fifth of the variables: DeviceCP reduces it on the device like
+    SparseLP.solve does on the host (remove_fixed_variables) and must give the oracle's iterates on the reduced LP."""
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    n, m = 3000, 5000
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, 0.01, seed=7)
+    s = a.download()
+    fixed = np.arange(n) % 5 == 0
+    lb2, ub2 = lb.copy(), ub.copy()
+    lb2[fixed] = ub2[fixed] = xf[fixed]
+    cp = DeviceCP(a, b, c, lb2, ub2)
+    cp.iterate(60)
+    x_red, x_full = cp.x_reduced(), cp.x()
+    cp.close()
+    a.close()
+    free = ~fixed
+    shift = np.where(free, 0.0, lb2)
+    b_red = b - oracle.matvec(oracle.as_csr(s), shift)               # SparseLP.py:649-650
+    x_ref, _ = oracle.chambolle_pock_ppd(c[free], None, None, s[:, free].tocsr(), None, b_red, lb2[free], ub2[free], nb_max_iter=60,
+                                         nb_iter_plot=10 ** 9)
+    assert np.array_equal(x_red, x_ref)
+    assert np.array_equal(x_full[free], x_ref) and np.array_equal(x_full[fixed], xf[fixed])
