@@ -77,10 +77,18 @@ def parse():
                         "the default all-inequality LP is the primary workload")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-general", action="store_true", help="skip the general (fp64 strip entries) block")
+    p.add_argument("--keep-csr", dest="release_csr", action="store_false",
+                   help="keep both CSR orientations resident during the timed region (default: released once the strip copies exist)")
     p.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU sample (default m / 10)")
     p.add_argument("--format", type=int, default=0, choices=[0, 1, 2],
                    help="slp_matrix_set_format policy of the timed run: 0 best available, 1 no value dictionary, 2 CSR kernels")
     return p.parse_args()
+
+
+def device_memory_in_use(lib):
+    free, total = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64)
+    _lib.check(lib.slp_device_memory(_lib.ptr(free), _lib.ptr(total)))
+    return float(total[0] - free[0]) / 1e9
 
 
 def spmv_bytes(nnz, rows, cols):
@@ -196,8 +204,8 @@ def general_block(lib, args, a, b, c, lb, ub, shape):
     ADMM setup without a dictionary row-normalises the matrix in place)."""
     from pysparselp_amd.scale import make_solver
 
-    _lib.check(lib.slp_matrix_set_format(a._h, 1))
     t0 = time.perf_counter()
+    _lib.check(lib.slp_matrix_set_format(a._h, 1))
     ax, which = spmv_block(lib, a, False, shape)
     aty, _ = spmv_block(lib, a, True, shape)
     t_build = time.perf_counter() - t0
@@ -257,6 +265,15 @@ def main():
     solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local)
     _lib.check(lib.slp_synchronize())
     t_gen = time.perf_counter() - t_gen
+    # Steady state keeps only what the iteration reads: when both orientations run on strip copies, the two CSR copies
+    # (48 GB at config 3) are dropped and the cached temporaries of the setup returned to the driver.
+    mem = {"in_use_after_setup_gb": device_memory_in_use(lib)}
+    released = args.release_csr and a.spmv_kernel(False) >= 1 and a.spmv_kernel(True) >= 1
+    if released:
+        a.release_csr()
+    _lib.check(lib.slp_trim())
+    mem["in_use_in_timed_region_gb"] = device_memory_in_use(lib)
+    mem["csr_released"] = bool(released)
 
     # ---- timed region: W warm-up steps, then exactly K steps between two barriers
     solver.iterate(args.warmup)
@@ -331,10 +348,14 @@ def main():
             "roofline": roofline,
             "objective_after_run": obj,
             "setup_seconds": t_gen,
+            "device_memory": mem,
         }
         solver.close()
         solver = None
         if world == 1 and not args.no_general and args.format == 0 and which >= 2 and args.method != "admm_blocks":
+            if released:  # the CSR entries are gone: the same rows again from the counter-based generator
+                a.close()
+                a = DeviceMatrix.random(rows, args.n, args.density, args.seed, r0)
             roofline["general_fp64"] = general_block(lib, args, a, b, c, lb, ub, shape)
         if world == 1 and not args.no_cpu_baseline and args.method != "admm_blocks":
             # (admm_blocks: the reference's per-block sparse LU of a KKT matrix with 5e5+ unknowns does not finish in

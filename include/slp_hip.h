@@ -99,6 +99,13 @@ slp_matrix *slp_matrix_remove_columns(slp_matrix *a, const unsigned char *keep, 
  * (fp64 entries in the strips: the general, any-values path); 2 = CSR kernels only.  Frees the strip copies built so
  * far; fails while a solver created on the matrix is alive. */
 int slp_matrix_set_format(slp_matrix *a, int policy);
+/* Drop the CSR entries (column indices and values, both orientations) of a matrix whose products run on strip copies in
+ * both orientations (slp_matrix_spmv_kernel >= 1): afterwards only the products -- and the solvers' iterations -- work;
+ * downloads, row gathers, format changes, slp_cp_report and new solver set-ups fail with a clear error.  At BASELINE
+ * config 3 this takes the resident matrix data from 66 GB (two CSR orientations + value-dictionary strips) to 17 GB. */
+int slp_matrix_release_csr(slp_matrix *a);
+/* hipMemGetInfo of the bound device. */
+int slp_device_memory(int64_t *free_bytes, int64_t *total_bytes);
 /* Bytes of the matrix copy that kernel reads per product (entries + per-strip metadata; CSR: 12 nnz + 8 (rows + 1)),
  * i.e. the matrix part of the HBM traffic one launch must generate; -1 = error. */
 int64_t slp_matrix_format_bytes(slp_matrix *a, int transposed);

@@ -45,6 +45,8 @@ _SIGNATURES = {
     "slp_matrix_gather_rows": (c_vp, [c_vp, c_i64, c_vp, c_vp]),
     "slp_matrix_spmv_kernel": (c_int, [c_vp, c_int]),
     "slp_matrix_set_format": (c_int, [c_vp, c_int]),
+    "slp_matrix_release_csr": (c_int, [c_vp]),
+    "slp_device_memory": (c_int, [c_vp, c_vp]),
     "slp_matrix_normal": (c_vp, [c_vp, c_dbl, c_dbl]),
     "slp_matrix_remove_columns": (c_vp, [c_vp, c_vp, c_vp, c_vp]),
     "slp_matrix_format_bytes": (c_i64, [c_vp, c_int]),

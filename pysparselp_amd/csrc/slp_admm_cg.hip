@@ -778,6 +778,7 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
     SLP_API_PTR({
         SLP_REQUIRE(a_ineq && b_upper && c && lb && ub, "slp_admm_cg_create_on: NULL argument");
         SLP_REQUIRE(m_eq >= 0 && m_eq <= a_ineq->a.nrow, "slp_admm_cg_create_on_mixed: m_eq out of range");
+        require_csr(a_ineq, "slp_admm_cg_create_on");  // the row norms are taken over the CSR entries
         Phase ph("slp_admm_cg_create_on");
         auto *s = new slp_admm_cg();
         try {

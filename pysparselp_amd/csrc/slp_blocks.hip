@@ -465,6 +465,7 @@ slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lo
     SLP_API_PTR({
         SLP_REQUIRE(a && b_upper && c && lb && ub, "slp_blocks_create_on: NULL argument");
         SLP_REQUIRE(m_eq >= 0 && m_eq <= a->a.nrow, "slp_blocks_create_on: m_eq out of range");
+        require_csr(a, "slp_blocks_create_on");
         SLP_REQUIRE(gamma > 0.0, "slp_blocks_create_on: gamma must be positive");
         auto *s = new slp_blocks();
         try {

@@ -250,6 +250,7 @@ struct slp_matrix {
     int format_policy = 0;       // slp_matrix_set_format: 0 auto, 1 no value dictionary (fp64 entries), 2 CSR kernels only
     bool scaled = false;         // the stored values were row-normalised in place by an ADMM setup (not idempotent)
     int borrowers = 0;           // live solvers created *_on this matrix (they hold raw pointers into its copies)
+    bool csr_released = false;   // slp_matrix_release_csr: entries only live in the strip copies (row pointers are kept)
 };
 
 namespace slp {
@@ -262,6 +263,7 @@ const StripJds *fast_format(slp_matrix *m, bool transposed);
 // y = A x (transposed: y = A^T x) with the best kernel for the matrix.
 void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int order);
 void invalidate_derived(slp_matrix *m);  // after the CSR values were modified in place
+void require_csr(const slp_matrix *m, const char *what);  // throws once slp_matrix_release_csr has dropped the CSR entries
 bool matrix_dictionary(slp_matrix *m);   // value_dictionary() of the matrix unless its format policy rules the dictionary out
 // two-stage deterministic reductions; result lands in out[0..k) (device), see slp_reduce.hip
 }  // namespace slp

@@ -554,6 +554,7 @@ slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const dou
                          const double *ub, const double *x0, double alpha, double theta, int order) {
     SLP_API_PTR({
         SLP_REQUIRE(a && b && c && lb && ub, "slp_cp_create_on: NULL argument");
+        require_csr(a, "slp_cp_create_on");  // the preconditioners are sums over the CSR entries
         slp_cp *s = cp_make(a, false, m_eq, b, c, lb, ub, x0, alpha, theta, order);
         ++a->borrowers;
         return s;
@@ -584,6 +585,7 @@ int slp_cp_dual_step(slp_cp *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); c
 int slp_cp_report(slp_cp *s, double out[5]) {
     SLP_API_INT({
         SLP_REQUIRE(s && out, "slp_cp_report: NULL argument");
+        require_csr(s->k, "slp_cp_report");  // the report's fused row pass walks the CSR
         hipStream_t st = ctx().stream;
         const CsrDev &a = s->k->a;
         int gc = grid_for(s->n, kBlock);

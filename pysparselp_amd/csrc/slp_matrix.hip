@@ -178,6 +178,7 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
     StripJds &f = transposed ? m->fat : m->fa;
     bool &tried = transposed ? m->tried_fat : m->tried_fa;
     if (!tried) {
+        require_csr(m, "building a strip copy");
         tried = true;
         if (m->format_policy == 2) return nullptr;  // CSR kernels only
         // few distinct stored values (rounded coefficients, +-1 patterns): 4-byte entries, values looked up in LDS
@@ -195,6 +196,12 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
     return f.ok ? &f : nullptr;
 }
 
+void require_csr(const slp_matrix *m, const char *what) {
+    if (m->csr_released)
+        throw Error(std::string(what) + ": the CSR entries of this matrix were released (slp_matrix_release_csr); only the products "
+                                        "over its strip copies remain");
+}
+
 bool matrix_dictionary(slp_matrix *m) { return m->format_policy == 0 && value_dictionary(m->a, m->vdict); }
 
 void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int order) {
@@ -203,6 +210,7 @@ void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int
         strip_spmv(*f, x, y);
         return;
     }
+    require_csr(m, "CSR product");
     launch_spmv(transposed ? m->at : m->a, x, y, order);
 }
 
@@ -233,6 +241,7 @@ void finish_stats(CsrDev &a) {  // fills a.max_row_len (kernel choices depend on
 // scipy's csc_matvec accumulates `y * A`.
 void build_transpose(slp_matrix *m) {
     if (m->have_at) return;
+    require_csr(m, "build_transpose");
     Phase ph("build_transpose");
     const CsrDev &a = m->a;
     CsrDev &t = m->at;
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(i64 count, const i64 *__
 
 static slp_matrix *matrix_gather_rows(slp_matrix *a, i64 count, const i64 *rows, const double *scale) {
     SLP_REQUIRE(a && count >= 0 && (count == 0 || (rows && scale)), "slp_matrix_gather_rows: bad arguments");
+    require_csr(a, "slp_matrix_gather_rows");
     for (i64 r = 0; r < count; ++r) SLP_REQUIRE(rows[r] >= 0 && rows[r] < a->a.nrow, "slp_matrix_gather_rows: row out of range");
     hipStream_t st = ctx().stream;
     auto *m = new slp_matrix();
@@ -488,6 +498,7 @@ int slp_matrix_spmv_t(slp_matrix *m, const double *y, double *out, int order) {
 int slp_matrix_download(slp_matrix *m, int transposed, int64_t *indptr, int32_t *indices, double *data) {
     SLP_API_INT({
         SLP_REQUIRE(m, "slp_matrix_download: NULL matrix");
+        require_csr(m, "slp_matrix_download");
         if (transposed) build_transpose(m);
         const CsrDev &a = transposed ? m->at : m->a;
         if (indptr) a.ptr.download(indptr, (size_t)a.nrow + 1);
@@ -500,6 +511,7 @@ int slp_matrix_download_rows(slp_matrix *m, int transposed, int64_t row0, int64_
                              double *data) {
     SLP_API_INT({
         SLP_REQUIRE(m, "slp_matrix_download_rows: NULL matrix");
+        require_csr(m, "slp_matrix_download_rows");
         if (transposed) build_transpose(m);
         const CsrDev &a = transposed ? m->at : m->a;
         SLP_REQUIRE(row0 >= 0 && count >= 0 && row0 + count <= a.nrow, "slp_matrix_download_rows: rows out of range");
@@ -516,9 +528,34 @@ int slp_matrix_download_rows(slp_matrix *m, int transposed, int64_t row0, int64_
     })
 }
 
+int slp_matrix_release_csr(slp_matrix *m) {
+    SLP_API_INT({
+        SLP_REQUIRE(m, "slp_matrix_release_csr: NULL matrix");
+        if (m->csr_released) return 0;
+        const StripJds *f0 = fast_format(m, false), *f1 = fast_format(m, true);
+        SLP_REQUIRE(f0 && f1, "slp_matrix_release_csr: the matrix does not run on strip copies in both orientations; its CSR arrays "
+                              "are the only copy of the entries");
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+        m->a.idx.release(); m->a.val.release();
+        m->at.idx.release(); m->at.val.release();
+        m->csr_released = true;
+    })
+}
+
+int slp_device_memory(int64_t *free_bytes, int64_t *total_bytes) {
+    SLP_API_INT({
+        ctx();
+        size_t f = 0, t = 0;
+        SLP_HIP(hipMemGetInfo(&f, &t));
+        if (free_bytes) *free_bytes = (int64_t)f;
+        if (total_bytes) *total_bytes = (int64_t)t;
+    })
+}
+
 int slp_matrix_set_format(slp_matrix *m, int policy) {
     SLP_API_INT({
         SLP_REQUIRE(m && policy >= 0 && policy <= 2, "slp_matrix_set_format: bad arguments");
+        require_csr(m, "slp_matrix_set_format");
         SLP_REQUIRE(m->borrowers == 0, "slp_matrix_set_format: a solver created on this matrix is still alive (it holds pointers "
                                        "into the copies this call would free)");
         if (policy == m->format_policy) return 0;

@@ -112,6 +112,7 @@ static void exclusive_scan(const T *in, T *out, size_t count) {
 
 static slp_matrix *matrix_normal(slp_matrix *a, double gamma_eq, double gamma_ineq) {
     SLP_REQUIRE(a, "slp_matrix_normal: NULL matrix");
+    require_csr(a, "slp_matrix_normal");
     Phase ph("slp_matrix_normal");
     hipStream_t st = ctx().stream;
     build_transpose(a);  // CSC of A, rows increasing inside every column (csr_tocsc order)
@@ -203,6 +204,7 @@ __global__ void k_rc_fill(i64 nrow, const i64 *__restrict__ ptr, const i32 *__re
 static slp_matrix *matrix_remove_columns(slp_matrix *a, const unsigned char *keep, const double *shift, double *a_shift) {
     SLP_REQUIRE(a && keep, "slp_matrix_remove_columns: NULL argument");
     SLP_REQUIRE((shift == nullptr) == (a_shift == nullptr), "slp_matrix_remove_columns: shift and a_shift go together");
+    require_csr(a, "slp_matrix_remove_columns");
     Phase ph("slp_matrix_remove_columns");
     hipStream_t st = ctx().stream;
     const CsrDev &r = a->a;

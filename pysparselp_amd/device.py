@@ -105,6 +105,11 @@ class DeviceMatrix:
         h = _lib.check_handle(self._l.slp_matrix_remove_columns(self._h, _lib.ptr(keep), _lib.ptr(shift), _lib.ptr(a_shift)))
         return DeviceMatrix(h, (self.shape[0], int(keep.sum()))), a_shift
 
+    def release_csr(self):
+        """Keep only the strip copies (both orientations must run on them): products and solver iterations keep working,
+        everything that needs the CSR entries raises."""
+        _lib.check(self._l.slp_matrix_release_csr(self._h))
+
     def set_format(self, policy):
         """0: best available copy; 1: no value dictionary (fp64 strip entries); 2: CSR kernels only."""
         _lib.check(self._l.slp_matrix_set_format(self._h, int(policy)))

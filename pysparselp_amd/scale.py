@@ -38,15 +38,17 @@ def one_sided_rows(m, m_eq, b_lower, b_upper):
 class DeviceCP:
     """Chambolle-Pock (reference ChambollePockPPD.py:195-343) on a DeviceMatrix."""
 
-    def __init__(self, a, b_upper, c, lb, ub, alpha=1.0, theta=1.0, order=ORDER_AUTO, m_eq=0, b_lower=None):
+    def __init__(self, a, b_upper, c, lb, ub, alpha=1.0, theta=1.0, order=ORDER_AUTO, m_eq=0, b_lower=None, remove_fixed=False):
+        """``remove_fixed=False`` is the reference's ``chambolle_pock_ppd`` function on the LP as given;
+        ``remove_fixed=True`` adds what ``SparseLP.solve`` does before calling it (SparseLP.py:1244-1248): variables with
+        ``ub == lb`` are dropped -- here on the device (column compaction + ``b - A shift``)."""
         self._l = _lib.lib()
         self.n_full = a.shape[1]
         c, b_upper, lb, ub = _lib.f64(c), _lib.f64(b_upper), _lib.f64(lb), _lib.f64(ub)
         b_lower = None if b_lower is None else _lib.f64(b_lower)
         self._stacked = self._reduced = None
-        # variables with ub == lb are dropped before the solve like SparseLP.solve does for this method
-        # (SparseLP.py:1244-1248 -> remove_fixed_variables :632-674) -- on the device: column compaction + b - A shift
-        self.free = ub > lb
+        # remove_fixed_variables (SparseLP.py:632-674) on the device: column compaction + b - A shift
+        self.free = (ub > lb) if remove_fixed else np.ones(lb.size, dtype=bool)
         self.shift = np.where(self.free, 0.0, lb)
         if not self.free.all():
             self._reduced, a_shift = a.remove_columns(self.free, self.shift)
