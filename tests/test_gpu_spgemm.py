@@ -107,7 +107,7 @@ def test_device_cp_with_fixed_variables_matches_the_oracle_on_the_reduced_lp():
     lb2[pin] = ub2[pin] = xf[pin]
     fixed = ~(ub2 > lb2)                      # the pinned fifth plus the few the generator fixes itself (t == 0)
     assert fixed.sum() > pin.sum()
-    cp = DeviceCP(a, b, c, lb2, ub2, remove_fixed=True)
+    cp = DeviceCP(a, b, c, lb2, ub2, remove_fixed=True, order=1)  # SLP_ORDER_SEQUENTIAL: bit-exact row sums at 30 entries per row
     cp.iterate(60)
     x_red, x_full = cp.x_reduced(), cp.x()
     cp.close()
