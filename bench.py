@@ -233,7 +233,7 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("SLP_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # SLP_DEVICE: several ranks on one GPU (tests)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     lib = _lib.lib(local)

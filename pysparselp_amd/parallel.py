@@ -60,9 +60,13 @@ def _recv_exact(conn, nbytes):
     return buf
 
 
+MAGIC = b"SLPRDZV1"
+PORT_TRIES = 8
+
+
 def rendezvous_port():
     """The launcher's own store owns MASTER_PORT (torch.distributed.run keeps a TCPStore there), so the id exchange
-    uses the next port; SLP_RDZV_PORT overrides."""
+    starts at the next port; SLP_RDZV_PORT overrides."""
     if "SLP_RDZV_PORT" in os.environ:
         return int(os.environ["SLP_RDZV_PORT"])
     return int(os.environ.get("MASTER_PORT", "29511")) + 1
@@ -70,8 +74,9 @@ def rendezvous_port():
 
 def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300.0):
     """Rank 0 creates the 128-byte RCCL unique id (``make_id()``) and serves it to the other ``world - 1`` ranks over TCP
-    on ``addr:port`` (default MASTER_ADDR : MASTER_PORT + 1); every rank returns the same 128 bytes.  Each client sends
-    its rank first, so a stray connection cannot take a rank's place."""
+    on ``addr`` (default MASTER_ADDR), on the first free port of ``port .. port + 7`` (default MASTER_PORT + 1 ...); every
+    rank returns the same 128 bytes.  A client sends a magic word and its rank and expects the magic word back, so a
+    foreign listener on one of the candidate ports is skipped and a stray connection cannot take a rank's place."""
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = rendezvous_port() if port is None else int(port)
     if rank == 0:
@@ -79,40 +84,142 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300
         assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
         if world == 1:
             return bytes(uid)
-        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
+        srv = None
+        for p in range(port, port + PORT_TRIES):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((addr, p))
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise OSError(f"rendezvous: no free port in {port}..{port + PORT_TRIES - 1} on {addr}")
+        with srv:
             srv.listen(world)
             srv.settimeout(timeout)
             served = set()
             while len(served) < world - 1:
                 conn, _ = srv.accept()
                 with conn:
-                    conn.settimeout(timeout)
-                    peer = int.from_bytes(_recv_exact(conn, 4), "little")
-                    if 0 < peer < world and peer not in served:
-                        conn.sendall(bytes(uid))
+                    conn.settimeout(10.0)
+                    try:
+                        hello = _recv_exact(conn, len(MAGIC) + 4)
+                    except (ConnectionError, socket.timeout, OSError):
+                        continue
+                    peer = int.from_bytes(hello[len(MAGIC):], "little")
+                    if hello[:len(MAGIC)] == MAGIC and 0 < peer < world and peer not in served:
+                        conn.sendall(MAGIC + bytes(uid))
                         served.add(peer)
         return bytes(uid)
     deadline = time.monotonic() + timeout
     while True:
-        try:
-            with socket.create_connection((addr, port), timeout=5.0) as conn:
+        for p in range(port, port + PORT_TRIES):
+            try:
+                with socket.create_connection((addr, p), timeout=5.0) as conn:
+                    conn.settimeout(10.0)
+                    conn.sendall(MAGIC + int(rank).to_bytes(4, "little"))
+                    reply = _recv_exact(conn, len(MAGIC) + 128)
+                    if reply[:len(MAGIC)] == MAGIC:
+                        return reply[len(MAGIC):]
+            except (ConnectionError, socket.timeout, OSError):
+                pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rendezvous: rank 0 did not answer on {addr}:{port}..{port + PORT_TRIES - 1}")
+        time.sleep(0.05)
+
+
+class HostTcpAllreduce:
+    """All-reduce over TCP through rank 0 for ``slp_comm_init_host`` (SLP_COMM_TRANSPORT=host): every rank sends its buffer to
+    rank 0, which adds them in rank order and sends the result back -- the same bits on every rank.  A debugging / test
+    transport (several ranks of the partitioned device code on ONE GPU, where RCCL refuses to run); never the fast path."""
+
+    def __init__(self, rank, world, addr=None, port=None, timeout=300.0):
+        import numpy as np
+
+        self._np = np
+        self.rank, self.world = int(rank), int(world)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = rendezvous_port() + PORT_TRIES if port is None else int(port)
+        self.peers = {}
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            while len(self.peers) < self.world - 1:
+                conn, _ = srv.accept()
                 conn.settimeout(timeout)
-                conn.sendall(int(rank).to_bytes(4, "little"))
-                return _recv_exact(conn, 128)
-        except (ConnectionRefusedError, ConnectionResetError, socket.timeout, OSError):
-            if time.monotonic() > deadline:
-                raise
-            time.sleep(0.05)
+                hello = _recv_exact(conn, len(MAGIC) + 4)
+                peer = int.from_bytes(hello[len(MAGIC):], "little")
+                if hello[:len(MAGIC)] == MAGIC and 0 < peer < self.world and peer not in self.peers:
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.peers[peer] = conn
+                else:
+                    conn.close()
+            srv.close()
+        else:
+            deadline = time.monotonic() + timeout
+            while True:
+                try:
+                    conn = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.monotonic() > deadline:
+                        raise
+                    time.sleep(0.05)
+            conn.settimeout(timeout)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            conn.sendall(MAGIC + self.rank.to_bytes(4, "little"))
+            self.peers[0] = conn
+        self.callback = _lib.HOST_ALLREDUCE_FN(self._allreduce)
+
+    def _allreduce(self, buf, count, op, user):
+        np = self._np
+        try:
+            mine = np.ctypeslib.as_array(buf, shape=(count,))
+            if self.rank == 0:
+                acc = mine.copy()
+                for peer in sorted(self.peers):
+                    other = np.frombuffer(_recv_exact(self.peers[peer], 8 * count), dtype=np.float64)
+                    acc = np.maximum(acc, other) if op == 1 else acc + other
+                data = acc.tobytes()
+                for peer in sorted(self.peers):
+                    self.peers[peer].sendall(data)
+                mine[:] = acc
+            else:
+                self.peers[0].sendall(mine.tobytes())
+                mine[:] = np.frombuffer(_recv_exact(self.peers[0], 8 * count), dtype=np.float64)
+            return 0
+        except Exception:  # noqa: BLE001 -- the C side turns a non-zero return into an SlpError
+            return 1
+
+    def close(self):
+        for c in self.peers.values():
+            c.close()
+        self.peers = {}
+
+
+_host_transport = None
 
 
 def init_comm_from_env(rank=None, world=None):
-    """Create the RCCL communicator inside libslp_hip.so for this process's GPU; rank / world size default to the
-    launcher's RANK / WORLD_SIZE."""
+    """Create the communicator inside libslp_hip.so for this process's GPU; rank / world size default to the launcher's
+    RANK / WORLD_SIZE.  RCCL unless SLP_COMM_TRANSPORT=host (``HostTcpAllreduce``)."""
+    global _host_transport
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
     lib = _lib.lib()
+    if os.environ.get("SLP_COMM_TRANSPORT") == "host":
+        _host_transport = HostTcpAllreduce(rank, world)
+        if world == 1:
+            _host_transport.callback = _lib.HOST_ALLREDUCE_FN(lambda buf, count, op, user: 0)
+        _lib.check(lib.slp_comm_init_host(world, rank, _host_transport.callback, None))
+        return
 
     def make_id():
         buf = ctypes.create_string_buffer(128)

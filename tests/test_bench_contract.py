@@ -58,3 +58,36 @@ def test_live_bench_line(method):
     d = json.loads(lines[0])
     check_line(d, need_cpu_baseline=True)
     assert d["steps"] == 4 and d["warmup"] == 1 and d["n_gpus"] == 1
+
+
+def _launch(nproc, extra_env, port):
+    env = dict(os.environ, **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(nproc), "--steps", "4", "--warmup", "2",
+           "--n", "30000", "--m", "40000", "--density", "0.001", "--no-cpu-baseline", "--no-general"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_under_the_launcher_one_rank_rccl():
+    """The driver's launch line with N = 1 and the N > 1 plumbing forced on: launcher env, TCP id exchange, a one-rank
+    RCCL communicator, the packed exchange (2 collectives per ADMM iteration)."""
+    d = _launch(1, {"SLP_BENCH_FORCE_DIST": "1", "SLP_FORCE_DISTRIBUTED": "1", "SLP_STRIP_MIN_NNZ": "1"}, 29631)
+    check_line(d, need_cpu_baseline=False)
+    assert d["n_gpus"] == 1 and d["config"]["collectives_per_iteration"] == 2.0
+
+
+@pytest.mark.gpu
+def test_bench_under_the_launcher_two_ranks_on_one_gpu():
+    """--gpus 2 on ONE device through the host transport (RCCL refuses two ranks on one GPU): row partition, rank-0-only
+    output, max-over-ranks timing, whole-job rate; the objective must agree with the single-process run."""
+    two = _launch(2, {"SLP_DEVICE": "0", "SLP_COMM_TRANSPORT": "host", "SLP_STRIP_MIN_NNZ": "1"}, 29641)
+    check_line(two, need_cpu_baseline=False)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["collectives_per_iteration"] == 2.0
+    one = _launch(1, {"SLP_STRIP_MIN_NNZ": "1"}, 29651)
+    assert two["config"]["nnz"] == one["config"]["nnz"]
+    assert abs(two["objective_after_run"] - one["objective_after_run"]) <= 1e-9 * (1 + abs(one["objective_after_run"]))
