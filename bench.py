@@ -67,8 +67,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--n", type=int, default=1_000_000, help="variables")
-    p.add_argument("--m", type=int, default=2_000_000, help="inequality constraints")
+    # (--vars / --rows: spellings that torch.distributed.run's own parser does not mistake for abbreviations of its options)
+    p.add_argument("--n", "--vars", dest="n", type=int, default=1_000_000, help="variables")
+    p.add_argument("--m", "--rows", dest="m", type=int, default=2_000_000, help="inequality constraints")
     p.add_argument("--density", type=float, default=1e-3)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--method", default="admm", choices=["admm", "chambolle_pock_ppd", "admm_blocks"])

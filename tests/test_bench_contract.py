@@ -64,7 +64,7 @@ def _launch(nproc, extra_env, port):
     env = dict(os.environ, **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(nproc), "--steps", "4", "--warmup", "2",
-           "--n", "30000", "--m", "40000", "--density", "0.001", "--no-cpu-baseline", "--no-general"]
+           "--vars", "30000", "--rows", "40000", "--density", "0.001", "--no-cpu-baseline", "--no-general"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
