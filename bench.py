@@ -279,8 +279,8 @@ def main():
     # ---- timed region: W warm-up steps, then exactly K steps between two barriers
     solver.iterate(args.warmup)
     cg0 = solver.cg_steps() if args.method == "admm_blocks" else 0
-    coll0 = int(lib.slp_comm_collectives())
     _lib.check(lib.slp_comm_barrier())
+    coll0 = int(lib.slp_comm_collectives())
     t0 = time.perf_counter()
     solver.iterate(args.steps)
     _lib.check(lib.slp_comm_barrier())
