@@ -173,6 +173,21 @@ slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr,
                           const double *ub, const double *x0, const int64_t *m_indptr,
                           const int32_t *m_indices, const double *m_data,
                           double gamma_eq, double gamma_ineq, int order);
+/* The same solver from the LP as lp_admm receives it -- the whole setup chain of ADMM.py:73-101 runs on the device:
+ * both constraint blocks are uploaded once, row normalisation of each (tools.py:272-290), slack standard form
+ * (tools.py:88-127), row normalisation of the stacked system (use_preconditioning), M and A^T b are computed in HBM with
+ * the reference's entry and accumulation orders (bit-identical state).  eq_indptr == NULL: no equality block;
+ * b_lower / b_upper == NULL: -inf / +inf; x0 == NULL: zeros.  The inequality block is required (tools.py:92). */
+slp_admm *slp_admm_create_lp(int64_t n, int64_t m_eq, const int64_t *eq_indptr, const int32_t *eq_indices,
+                             const double *eq_data, const double *b_eq, int64_t m_ineq, const int64_t *in_indptr,
+                             const int32_t *in_indices, const double *in_data, const double *b_lower,
+                             const double *b_upper, const double *c, const double *lb, const double *ub,
+                             const double *x0, double gamma_eq, double gamma_ineq, int use_preconditioning, int order);
+/* The setup transforms on their own (tests, other callers): rows scaled to unit 2-norm -- new matrix with scipy's entry
+ * order for `diags(1/s) * A` (each row reversed, exact zeros dropped), b / b2 (host, may be NULL) scaled in place -- and
+ * the slack standard form [[A_eq, 0], [A_ineq, -I]] with rows sorted by column (a_eq may be NULL). */
+slp_matrix *slp_matrix_precondition_rows(slp_matrix *a, double *b, double *b2);
+slp_matrix *slp_matrix_standard_form(slp_matrix *a_eq, slp_matrix *a_ineq);
 void slp_admm_destroy(slp_admm *s);
 /* x-step of the iteration; call before the first iteration.
  * 0 (default): one projected Gauss-Seidel sweep, the flags the reference ships (ADMM.py:66-71,:162).

@@ -6,13 +6,17 @@ explicit ``M = gamma_eq A^T A + gamma_ineq I`` (flags at ADMM.py:66-71).  Same
 signature, callback contract and return value (the first ``n`` entries of the
 standard-form iterate).
 
-Row normalisation and the slack standard form are computed on the host like in
-the reference (tools.py of this package); the standard-form matrix is uploaded
-ONCE and ``M = gamma_eq A^T A + gamma_ineq I`` is formed from it on the device
-(csrc/slp_spgemm.hip: scipy's SMMP accumulation order, bit-identical values).
-The loop -- right-hand side with ``A^T lambda``, the level-scheduled
-Gauss-Seidel sweep, the multiplier update with ``A x`` and the report
-reductions -- runs on the GPU (csrc/slp_admm.hip).
+The two constraint blocks are uploaded once, as the caller holds them; the whole
+setup chain of ADMM.py:73-101 -- row normalisation of each block, slack standard
+form, row normalisation of the stacked system, ``M = gamma_eq A^T A + gamma_ineq I``
+and ``A^T b`` -- runs on the device (``slp_admm_create_lp``, csrc/slp_spgemm.hip)
+with scipy's entry orders and accumulation orders, so the state is bit-identical
+to the reference's.  (``SLP_HOST_SETUP=1`` prepares the same arrays with the numpy
+restatement in tools.py instead and uploads them; the tests compare the two.)
+Only the level schedule of the Gauss-Seidel sweep is planned on the host, from
+one download of ``M``.  The loop -- right-hand side with ``A^T lambda``, the
+level-scheduled Gauss-Seidel sweep, the multiplier update with ``A x`` and the
+report reductions -- runs on the GPU (csrc/slp_admm.hip).
 """
 import os
 import time
@@ -38,6 +42,31 @@ class ADMMState:
             self.N, self.m, _lib.ptr(a.indptr), _lib.ptr(a.indices), _lib.ptr(a.data), _lib.ptr(b), _lib.ptr(c),
             _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(x0), *((None, None, None) if m is None else (_lib.ptr(m.indptr), _lib.ptr(m.indices), _lib.ptr(m.data))),
             float(gamma_eq), float(gamma_ineq), int(order)))
+
+    @classmethod
+    def from_lp(cls, c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0, gamma_eq, gamma_ineq, use_preconditioning=True,
+                order=ORDER_AUTO):
+        """The solver state from the LP as ``lp_admm`` receives it; all setup transforms run on the device."""
+        from .tools import CsrArrays
+
+        self = cls.__new__(cls)
+        self._l = _lib.lib()
+        a_eq, a_ineq = CsrArrays.from_any(a_eq), CsrArrays.from_any(a_ineq)
+        if a_ineq is None:  # what the reference does on this input (tools.py:92-127)
+            raise UnboundLocalError("local variable 'a_eq2' referenced before assignment (no inequality constraints)")
+        n = a_ineq.shape[1]
+        c, lb, ub = _lib.f64(c), _lib.f64(lb), _lib.f64(ub)
+        m_eq = a_eq.shape[0] if a_eq is not None else 0
+        m_ineq = a_ineq.shape[0]
+        self.N, self.m = n + m_ineq, m_eq + m_ineq
+        opt = lambda v: None if v is None else _lib.f64(v)  # noqa: E731
+        beq, b_lower, b_upper, x0 = opt(beq), opt(b_lower), opt(b_upper), opt(x0)
+        eq = (None, None, None) if a_eq is None else (_lib.ptr(a_eq.indptr), _lib.ptr(a_eq.indices), _lib.ptr(a_eq.data))
+        self._h = _lib.check_handle(self._l.slp_admm_create_lp(
+            n, m_eq, *eq, _lib.ptr(beq), m_ineq, _lib.ptr(a_ineq.indptr), _lib.ptr(a_ineq.indices), _lib.ptr(a_ineq.data),
+            _lib.ptr(b_lower), _lib.ptr(b_upper), _lib.ptr(c), _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(x0), float(gamma_eq),
+            float(gamma_ineq), int(bool(use_preconditioning)), int(order)))
+        return self
 
     def close(self):
         if getattr(self, "_h", None):
@@ -121,20 +150,22 @@ def lp_admm(
         raise ValueError(f"unknown xstep {xstep!r}")
     c = _lib.f64(c)
     n = c.size
-    if x0 is None:
-        x0 = np.zeros(n)
-    # ADMM.py:76-91: scale the rows, add one slack per inequality, scale the stacked rows again
-    if a_eq is not None:
-        a_eq, beq = precondition_constraints(a_eq, beq, alpha=2)
-    if a_ineq is not None:
-        a_ineq, b_lower, b_upper = precondition_constraints(a_ineq, b_lower, b_upper, alpha=2)
-    c2, a, b, lb2, ub2, x_init = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
-    if use_preconditioning:
-        a, b = precondition_constraints(a, b, alpha=2)
-    # ADMM.py:93-101: M is formed on the device from the uploaded A (SLP_HOST_SPGEMM=1: scipy's product on the host instead)
-    m_mat = normal_matrix(a, gamma_eq, gamma_ineq) if os.environ.get("SLP_HOST_SPGEMM") == "1" else None
-
-    state = ADMMState(a, b, c2, lb2, ub2, x_init, m_mat, gamma_eq, gamma_ineq, order)
+    if os.environ.get("SLP_HOST_SETUP") == "1":
+        # the numpy restatement of the setup chain (tools.py), then one upload of the finished arrays
+        if x0 is None:
+            x0 = np.zeros(n)
+        if a_eq is not None:
+            a_eq, beq = precondition_constraints(a_eq, beq, alpha=2)
+        if a_ineq is not None:
+            a_ineq, b_lower, b_upper = precondition_constraints(a_ineq, b_lower, b_upper, alpha=2)
+        c2, a, b, lb2, ub2, x_init = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
+        if use_preconditioning:
+            a, b = precondition_constraints(a, b, alpha=2)
+        m_mat = normal_matrix(a, gamma_eq, gamma_ineq) if os.environ.get("SLP_HOST_SPGEMM") == "1" else None
+        state = ADMMState(a, b, c2, lb2, ub2, x_init, m_mat, gamma_eq, gamma_ineq, order)
+    else:
+        # ADMM.py:76-101 on the device: blocks uploaded once, nothing else crosses PCIe but M's download for the level plan
+        state = ADMMState.from_lp(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0, gamma_eq, gamma_ineq, use_preconditioning, order)
     if xstep == "gauss_seidel_unbounded":  # the reference's use_unbounded_gauss_siedel flags (ADMM.py:164-181)
         state.set_xstep(1)
     try:

@@ -683,6 +683,46 @@ int slp_gs_solve(slp_gs *g, const double *b, const double *lower, const double *
     })
 }
 
+// everything after s->a, b, c, lb, ub, x are on the device: transposed copy, M's level schedule (M from the host arrays or,
+// without them, formed on the device), the constant part of the right-hand side
+static void admm_finish_create(slp_admm *s, const int64_t *m_indptr, const int32_t *m_indices, const double *m_data) {
+    const i64 N = s->N, m = s->m;
+    build_transpose(s->a);
+    s->lanes_rows = lanes_for(s->a->a, s->order);
+    s->lanes_cols = lanes_for(s->a->at, s->order);
+    if (m_indptr) {
+        gs_plan(s->plan, N, m_indptr, m_indices, m_data);
+    } else {
+        // M = gamma_eq A^T A + gamma_ineq I formed on the device (slp_spgemm.hip, SMMP accumulation order); the
+        // level schedule of the sweep is still planned on the host from one download of M
+        slp_matrix *mm = slp_matrix_normal(s->a, s->gamma_eq, s->gamma_ineq);
+        if (!mm) throw Error(slp_last_error());
+        try {
+            std::vector<i64> mp((size_t)N + 1);
+            std::vector<i32> mj((size_t)mm->a.nnz);
+            std::vector<double> mx((size_t)mm->a.nnz);
+            mm->a.ptr.download(mp.data(), mp.size());
+            mm->a.idx.download(mj.data(), mj.size());
+            mm->a.val.download(mx.data(), mx.size());
+            gs_plan(s->plan, N, mp.data(), mj.data(), mx.data());
+        } catch (...) { delete mm; throw; }
+        delete mm;
+    }
+    s->xp0.alloc((size_t)N); s->lam.alloc((size_t)m); s->lam.zero();
+    s->lin.alloc((size_t)N); s->lin.zero();
+    s->q.alloc((size_t)N); s->y.alloc((size_t)N);
+    s->rowparts.alloc((size_t)kAdmmPartials * 3); s->colparts.alloc((size_t)kAdmmPartials * 3); s->out.alloc(8);
+    hipStream_t st = ctx().stream;
+    if (N) {
+        hipLaunchKernelGGL(k_max0, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, st, N, s->x.p, s->xp0.p);
+        // A^T b in the reference's accumulation order (ADMM.py:95), then q
+        launch_spmv(s->a->at, s->b.p, s->y.p, s->order == SLP_ORDER_AUTO ? SLP_ORDER_AUTO : s->order);
+        hipLaunchKernelGGL(k_admm_q, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, st, N, s->c.p, s->y.p, s->gamma_eq, s->q.p);
+        SLP_HIP(hipGetLastError());
+    }
+    SLP_HIP(hipStreamSynchronize(st));
+}
+
 slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr, const int32_t *a_indices, const double *a_data,
                           const double *b, const double *c, const double *lb, const double *ub, const double *x0,
                           const int64_t *m_indptr, const int32_t *m_indices, const double *m_data, double gamma_eq,
@@ -693,44 +733,80 @@ slp_admm *slp_admm_create(int64_t N, int64_t m, const int64_t *a_indptr, const i
         try {
             s->a = slp_matrix_create(m, N, a_indptr, a_indices, a_data);
             if (!s->a) throw Error(slp_last_error());
-            build_transpose(s->a);
             s->N = N; s->m = m; s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
-            s->lanes_rows = lanes_for(s->a->a, order);
-            s->lanes_cols = lanes_for(s->a->at, order);
-            if (m_indptr) {
-                gs_plan(s->plan, N, m_indptr, m_indices, m_data);
-            } else {
-                // M = gamma_eq A^T A + gamma_ineq I formed on the device (slp_spgemm.hip, SMMP accumulation order); the
-                // level schedule of the sweep is still planned on the host from one download of M
-                slp_matrix *mm = slp_matrix_normal(s->a, gamma_eq, gamma_ineq);
-                if (!mm) throw Error(slp_last_error());
-                try {
-                    std::vector<i64> mp((size_t)N + 1);
-                    std::vector<i32> mj((size_t)mm->a.nnz);
-                    std::vector<double> mx((size_t)mm->a.nnz);
-                    mm->a.ptr.download(mp.data(), mp.size());
-                    mm->a.idx.download(mj.data(), mj.size());
-                    mm->a.val.download(mx.data(), mx.size());
-                    gs_plan(s->plan, N, mp.data(), mj.data(), mx.data());
-                } catch (...) { delete mm; throw; }
-                delete mm;
-            }
             s->b.upload(b, (size_t)m); s->c.upload(c, (size_t)N); s->lb.upload(lb, (size_t)N); s->ub.upload(ub, (size_t)N);
             s->x.upload(x0, (size_t)N);
-            s->xp0.alloc((size_t)N); s->lam.alloc((size_t)m); s->lam.zero();
-            s->lin.alloc((size_t)N); s->lin.zero();
-            s->q.alloc((size_t)N); s->y.alloc((size_t)N);
-            s->rowparts.alloc((size_t)kAdmmPartials * 3); s->colparts.alloc((size_t)kAdmmPartials * 3); s->out.alloc(8);
-            hipStream_t st = ctx().stream;
-            if (N) {
-                hipLaunchKernelGGL(k_max0, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, st, N, s->x.p, s->xp0.p);
-                // A^T b in the reference's accumulation order (ADMM.py:95), then q
-                launch_spmv(s->a->at, s->b.p, s->y.p, order == SLP_ORDER_AUTO ? SLP_ORDER_AUTO : order);
-                hipLaunchKernelGGL(k_admm_q, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, st, N, s->c.p, s->y.p, gamma_eq, s->q.p);
-                SLP_HIP(hipGetLastError());
+            admm_finish_create(s, m_indptr, m_indices, m_data);
+        } catch (...) { slp_admm_destroy(s); throw; }
+        return s;
+    })
+}
+
+__global__ void k_fill_const(i64 n, double v, double *__restrict__ p) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) p[j] = v;
+}
+
+// The whole setup chain of lp_admm on the device (ADMM.py:73-101): the two constraint blocks are uploaded as the caller
+// holds them, then -- row normalisation of each block (tools.py:272-290), slack standard form (tools.py:88-127), row
+// normalisation of the stacked system, M (slp_matrix_normal), A^T b -- run in HBM with the reference's entry orders and
+// accumulation orders, so the state equals the host-prepared one bit for bit.
+slp_admm *slp_admm_create_lp(int64_t n, int64_t m_eq, const int64_t *eq_indptr, const int32_t *eq_indices, const double *eq_data,
+                             const double *b_eq, int64_t m_ineq, const int64_t *in_indptr, const int32_t *in_indices,
+                             const double *in_data, const double *b_lower, const double *b_upper, const double *c, const double *lb,
+                             const double *ub, const double *x0, double gamma_eq, double gamma_ineq, int use_preconditioning, int order) {
+    SLP_API_PTR({
+        SLP_REQUIRE(n >= 0 && m_eq >= 0 && m_ineq >= 0 && c && lb && ub, "slp_admm_create_lp: bad arguments");
+        SLP_REQUIRE(in_indptr, "slp_admm_create_lp: the inequality block is required (the reference's standard form is undefined "
+                               "without it, tools.py:92)");
+        SLP_REQUIRE(m_eq == 0 || (eq_indptr && b_eq), "slp_admm_create_lp: NULL equality block");
+        hipStream_t st = ctx().stream;
+        auto *s = new slp_admm();
+        slp_matrix *ae = nullptr, *ai = nullptr, *ae2 = nullptr, *ai2 = nullptr, *a2 = nullptr;
+        auto drop = [&]() { delete ae; delete ai; delete ae2; delete ai2; delete a2; ae = ai = ae2 = ai2 = a2 = nullptr; };
+        try {
+            const i64 m = m_eq + m_ineq, N = n + m_ineq;
+            s->N = N; s->m = m; s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
+            if (eq_indptr) {  // a 0-row equality block stays a block, like `a_eq is not None` in the reference
+                ae = slp_matrix_create(m_eq, n, eq_indptr, eq_indices, eq_data);
+                if (!ae) throw Error(slp_last_error());
+            }
+            ai = slp_matrix_create(m_ineq, n, in_indptr, in_indices, in_data);
+            if (!ai) throw Error(slp_last_error());
+            // right-hand sides and bounds of the stacked system: b = [b_eq; 0], lb = [lb; b_lower], ub = [ub; b_upper], c = [c; 0]
+            s->b.alloc((size_t)m); s->b.zero();
+            s->c.alloc((size_t)N); s->c.zero();
+            s->lb.alloc((size_t)N); s->ub.alloc((size_t)N); s->x.alloc((size_t)N); s->x.zero();
+            if (m_eq) SLP_HIP(hipMemcpyAsync(s->b.p, b_eq, (size_t)m_eq * sizeof(double), hipMemcpyHostToDevice, st));
+            if (n) {
+                SLP_HIP(hipMemcpyAsync(s->c.p, c, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+                SLP_HIP(hipMemcpyAsync(s->lb.p, lb, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+                SLP_HIP(hipMemcpyAsync(s->ub.p, ub, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+                if (x0) SLP_HIP(hipMemcpyAsync(s->x.p, x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+            }
+            if (m_ineq) {
+                if (b_lower) SLP_HIP(hipMemcpyAsync(s->lb.p + n, b_lower, (size_t)m_ineq * sizeof(double), hipMemcpyHostToDevice, st));
+                else hipLaunchKernelGGL(k_fill_const, dim3(grid_for(m_ineq, kBlock)), dim3(kBlock), 0, st, m_ineq, -__builtin_inf(), s->lb.p + n);
+                if (b_upper) SLP_HIP(hipMemcpyAsync(s->ub.p + n, b_upper, (size_t)m_ineq * sizeof(double), hipMemcpyHostToDevice, st));
+                else hipLaunchKernelGGL(k_fill_const, dim3(grid_for(m_ineq, kBlock)), dim3(kBlock), 0, st, m_ineq, __builtin_inf(), s->ub.p + n);
+            }
+            SLP_HIP(hipStreamSynchronize(st));  // the host buffers may go away
+            // ADMM.py:76-83: scale the rows of each block (the slack bounds are scaled with their rows; -inf / inf stay)
+            if (ae) ae2 = matrix_precondition_rows(ae, s->b.p, nullptr);
+            ai2 = matrix_precondition_rows(ai, s->lb.p + n, s->ub.p + n);
+            // :84-86: [A_eq 0; A_ineq -I]; x0 = [x0; A_ineq x0] with the scaled block (csr_matvec over its stored order)
+            a2 = matrix_standard_form(ae2, ai2);
+            if (m_ineq) launch_spmv(ai2->a, s->x.p, s->x.p + n, SLP_ORDER_SEQUENTIAL);
+            // :90-91: scale the rows of the stacked system
+            if (use_preconditioning) {
+                s->a = matrix_precondition_rows(a2, s->b.p, nullptr);
+            } else {
+                s->a = a2;
+                a2 = nullptr;
             }
             SLP_HIP(hipStreamSynchronize(st));
-        } catch (...) { slp_admm_destroy(s); throw; }
+            drop();
+            admm_finish_create(s, nullptr, nullptr, nullptr);
+        } catch (...) { drop(); slp_admm_destroy(s); throw; }
         return s;
     })
 }

@@ -262,6 +262,9 @@ void launch_spmv(const CsrDev &a, const double *x, double *y, int order);
 const StripJds *fast_format(slp_matrix *m, bool transposed);
 // y = A x (transposed: y = A^T x) with the best kernel for the matrix.
 void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int order);
+// device-side setup transforms of lp_admm (slp_spgemm.hip); b / b2: device vectors scaled in place (may be NULL)
+slp_matrix *matrix_precondition_rows(slp_matrix *a, double *b, double *b2);
+slp_matrix *matrix_standard_form(slp_matrix *a_eq, slp_matrix *a_ineq);
 void invalidate_derived(slp_matrix *m);  // after the CSR values were modified in place
 void require_csr(const slp_matrix *m, const char *what);  // throws once slp_matrix_release_csr has dropped the CSR entries
 bool matrix_dictionary(slp_matrix *m);   // value_dictionary() of the matrix unless its format policy rules the dictionary out

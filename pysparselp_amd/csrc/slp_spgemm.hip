@@ -248,11 +248,222 @@ static slp_matrix *matrix_remove_columns(slp_matrix *a, const unsigned char *kee
     return m;
 }
 
+// ---- row normalisation: precondition_constraints (tools.py:272-290), alpha = 2 ----------------------------------
+// s_i = sqrt(sum_k |a_ik|^2) accumulated in storage order (scipy csr_matvec of |A|^2 against ones), 0 -> 1; the scaled
+// matrix is scipy's `diags(1/s) * A`: entry (1/s_i) a_ik, each ROW STORED IN REVERSED ENTRY ORDER (csr_matmat walks a
+// linked list of the touched columns, last touched first) and entries that underflow to exactly 0 dropped.
+__global__ void k_pre_norm(i64 nrow, const i64 *__restrict__ ptr, const double *__restrict__ val, double *__restrict__ inv,
+                           u64 *__restrict__ len) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
+        double sum = 0.0;
+        for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) {
+            const double a = fabs(val[k]);
+            sum += a * a;
+        }
+        double nrm = sqrt(sum);
+        if (nrm == 0.0) nrm = 1.0;
+        const double iv = 1.0 / nrm;
+        inv[r] = iv;
+        u64 c = 0;
+        for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) c += (iv * val[k] != 0.0) ? 1 : 0;
+        len[r] = c;
+    }
+}
+
+__global__ void k_pre_fill(i64 nrow, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, const double *__restrict__ val,
+                           const double *__restrict__ inv, const i64 *__restrict__ optr, i32 *__restrict__ oidx, double *__restrict__ oval) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
+        const double iv = inv[r];
+        i64 o = optr[r];
+        for (i64 k = ptr[r + 1] - 1; k >= ptr[r]; --k) {
+            const double v = iv * val[k];
+            if (v != 0.0) {
+                oidx[o] = idx[k];
+                oval[o] = v;
+                ++o;
+            }
+        }
+    }
+}
+
+__global__ void k_scale_vec(i64 n, const double *__restrict__ inv, double *__restrict__ b) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) b[i] = inv[i] * b[i];  // inf stays inf
+}
+
+slp_matrix *matrix_precondition_rows(slp_matrix *a, double *b, double *b2) {
+    SLP_REQUIRE(a, "precondition_rows: NULL matrix");
+    require_csr(a, "precondition_rows");
+    hipStream_t st = ctx().stream;
+    const CsrDev &r = a->a;
+    const i64 rows = r.nrow;
+    auto *m = new slp_matrix();
+    try {
+        DevBuf<double> inv((size_t)rows);
+        DevBuf<u64> len((size_t)rows + 1);
+        len.zero();
+        const int g = grid_for(rows, kBlock);
+        if (rows) hipLaunchKernelGGL(k_pre_norm, dim3(g), dim3(kBlock), 0, st, rows, r.ptr.p, r.val.p, inv.p, len.p);
+        SLP_HIP(hipGetLastError());
+        m->a.nrow = rows;
+        m->a.ncol = r.ncol;
+        m->a.ptr.alloc((size_t)rows + 1);
+        exclusive_scan(len.p, reinterpret_cast<u64 *>(m->a.ptr.p), (size_t)rows + 1);
+        i64 nnz = 0;
+        SLP_HIP(hipMemcpyAsync(&nnz, m->a.ptr.p + rows, sizeof(i64), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipStreamSynchronize(st));
+        m->a.nnz = nnz;
+        m->a.idx.alloc((size_t)nnz);
+        m->a.val.alloc((size_t)nnz);
+        if (rows) {
+            hipLaunchKernelGGL(k_pre_fill, dim3(g), dim3(kBlock), 0, st, rows, r.ptr.p, r.idx.p, r.val.p, inv.p, m->a.ptr.p, m->a.idx.p,
+                               m->a.val.p);
+            if (b) hipLaunchKernelGGL(k_scale_vec, dim3(g), dim3(kBlock), 0, st, rows, inv.p, b);
+            if (b2) hipLaunchKernelGGL(k_scale_vec, dim3(g), dim3(kBlock), 0, st, rows, inv.p, b2);
+        }
+        SLP_HIP(hipGetLastError());
+        SLP_HIP(hipStreamSynchronize(st));
+        finish_stats(m->a);
+    } catch (...) {
+        delete m;
+        throw;
+    }
+    return m;
+}
+
+// ---- slack standard form: convert_to_standard_form_with_bounds (tools.py:88-127) ---------------------------------
+// A = [[A_eq, 0], [A_ineq, -I]] as scipy's vstack / hstack / tocsr leave it: rows sorted by column, duplicate (row, column)
+// pairs summed in their original order.
+__global__ void k_sf_count(i64 me, i64 mi, const i64 *__restrict__ eptr, const i64 *__restrict__ iptr, u64 *__restrict__ len) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < me + mi; r += (i64)gridDim.x * blockDim.x)
+        len[r] = r < me ? (u64)(eptr[r + 1] - eptr[r]) : (u64)(iptr[r - me + 1] - iptr[r - me]) + 1;
+}
+
+__global__ void k_sf_fill(i64 me, i64 mi, i64 n, const i64 *__restrict__ eptr, const i32 *__restrict__ eidx, const double *__restrict__ eval,
+                          const i64 *__restrict__ iptr, const i32 *__restrict__ iidx, const double *__restrict__ ival,
+                          const i64 *__restrict__ optr, unsigned int *__restrict__ okey, double *__restrict__ oval) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < me + mi; r += (i64)gridDim.x * blockDim.x) {
+        i64 o = optr[r];
+        if (r < me) {
+            for (i64 k = eptr[r]; k < eptr[r + 1]; ++k, ++o) { okey[o] = (unsigned int)eidx[k]; oval[o] = eval[k]; }
+        } else {
+            const i64 i = r - me;
+            for (i64 k = iptr[i]; k < iptr[i + 1]; ++k, ++o) { okey[o] = (unsigned int)iidx[k]; oval[o] = ival[k]; }
+            okey[o] = (unsigned int)(n + i);
+            oval[o] = -1.0;
+        }
+    }
+}
+
+// unique columns per (sorted) row
+__global__ void k_sf_unique(i64 rows, const i64 *__restrict__ ptr, const unsigned int *__restrict__ key, u64 *__restrict__ len) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (i64)gridDim.x * blockDim.x) {
+        u64 c = 0;
+        for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) c += (k == ptr[r] || key[k] != key[k - 1]) ? 1 : 0;
+        len[r] = c;
+    }
+}
+
+__global__ void k_sf_merge(i64 rows, const i64 *__restrict__ ptr, const unsigned int *__restrict__ key, const double *__restrict__ val,
+                           const i64 *__restrict__ optr, i32 *__restrict__ oidx, double *__restrict__ oval) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (i64)gridDim.x * blockDim.x) {
+        i64 o = optr[r] - 1;
+        for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) {
+            if (k == ptr[r] || key[k] != key[k - 1]) {
+                ++o;
+                oidx[o] = (i32)key[k];
+                oval[o] = val[k];
+            } else {
+                oval[o] = oval[o] + val[k];  // duplicates summed left to right, like COO -> CSR
+            }
+        }
+    }
+}
+
+slp_matrix *matrix_standard_form(slp_matrix *ae, slp_matrix *ai) {
+    SLP_REQUIRE(ai, "standard_form: the inequality block is required (tools.py:92)");
+    require_csr(ai, "standard_form");
+    if (ae) require_csr(ae, "standard_form");
+    hipStream_t st = ctx().stream;
+    const i64 me = ae ? ae->a.nrow : 0, mi = ai->a.nrow, n = ai->a.ncol, rows = me + mi;
+    SLP_REQUIRE(!ae || ae->a.ncol == n, "standard_form: A_eq and A_ineq differ in their column count");
+    SLP_REQUIRE(n + mi < ((i64)1 << 31), "standard_form: column count must fit int32");
+    auto *m = new slp_matrix();
+    try {
+        const int g = grid_for(rows, kBlock);
+        DevBuf<u64> len((size_t)rows + 1);
+        DevBuf<i64> tptr((size_t)rows + 1);
+        len.zero();
+        if (rows) hipLaunchKernelGGL(k_sf_count, dim3(g), dim3(kBlock), 0, st, me, mi, ae ? ae->a.ptr.p : nullptr, ai->a.ptr.p, len.p);
+        SLP_HIP(hipGetLastError());
+        exclusive_scan(len.p, reinterpret_cast<u64 *>(tptr.p), (size_t)rows + 1);
+        i64 total = 0;
+        SLP_HIP(hipMemcpyAsync(&total, tptr.p + rows, sizeof(i64), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipStreamSynchronize(st));
+        SLP_REQUIRE(total < (i64)0x7fffffffll, "standard_form: more than 2^31-1 stored entries");
+        DevBuf<unsigned int> key((size_t)total), key2((size_t)total);
+        DevBuf<double> val((size_t)total), val2((size_t)total);
+        if (rows)
+            hipLaunchKernelGGL(k_sf_fill, dim3(g), dim3(kBlock), 0, st, me, mi, n, ae ? ae->a.ptr.p : nullptr, ae ? ae->a.idx.p : nullptr,
+                               ae ? ae->a.val.p : nullptr, ai->a.ptr.p, ai->a.idx.p, ai->a.val.p, tptr.p, key.p, val.p);
+        SLP_HIP(hipGetLastError());
+        unsigned int bits = 1;
+        while (bits < 32 && ((i64)1 << bits) < n + mi) ++bits;
+        if (total) {  // stable sort of every row by column
+            size_t bytes = 0;
+            SLP_HIP(rocprim::segmented_radix_sort_pairs(nullptr, bytes, key.p, key2.p, val.p, val2.p, (unsigned int)total, (unsigned int)rows,
+                                                        tptr.p, tptr.p + 1, 0u, bits, st));
+            DevBuf<char> tmp(bytes);
+            SLP_HIP(rocprim::segmented_radix_sort_pairs(tmp.p, bytes, key.p, key2.p, val.p, val2.p, (unsigned int)total, (unsigned int)rows,
+                                                        tptr.p, tptr.p + 1, 0u, bits, st));
+            SLP_HIP(hipStreamSynchronize(st));
+        }
+        len.zero();
+        if (rows) hipLaunchKernelGGL(k_sf_unique, dim3(g), dim3(kBlock), 0, st, rows, tptr.p, key2.p, len.p);
+        SLP_HIP(hipGetLastError());
+        m->a.nrow = rows;
+        m->a.ncol = n + mi;
+        m->a.ptr.alloc((size_t)rows + 1);
+        exclusive_scan(len.p, reinterpret_cast<u64 *>(m->a.ptr.p), (size_t)rows + 1);
+        i64 nnz = 0;
+        SLP_HIP(hipMemcpyAsync(&nnz, m->a.ptr.p + rows, sizeof(i64), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipStreamSynchronize(st));
+        m->a.nnz = nnz;
+        m->a.idx.alloc((size_t)nnz);
+        m->a.val.alloc((size_t)nnz);
+        if (rows) hipLaunchKernelGGL(k_sf_merge, dim3(g), dim3(kBlock), 0, st, rows, tptr.p, key2.p, val2.p, m->a.ptr.p, m->a.idx.p, m->a.val.p);
+        SLP_HIP(hipGetLastError());
+        SLP_HIP(hipStreamSynchronize(st));
+        finish_stats(m->a);
+    } catch (...) {
+        delete m;
+        throw;
+    }
+    return m;
+}
+
 }  // namespace slp
 
 using namespace slp;
 
 extern "C" {
+
+slp_matrix *slp_matrix_precondition_rows(slp_matrix *a, double *b, double *b2) {
+    SLP_API_PTR({
+        SLP_REQUIRE(a, "slp_matrix_precondition_rows: NULL matrix");
+        const size_t rows = (size_t)a->a.nrow;
+        DevBuf<double> db, db2;
+        if (b) db.upload(b, rows);
+        if (b2) db2.upload(b2, rows);
+        slp_matrix *m = matrix_precondition_rows(a, b ? db.p : nullptr, b2 ? db2.p : nullptr);
+        if (b) db.download(b, rows);
+        if (b2) db2.download(b2, rows);
+        return m;
+    })
+}
+
+slp_matrix *slp_matrix_standard_form(slp_matrix *a_eq, slp_matrix *a_ineq) {
+    SLP_API_PTR({ return matrix_standard_form(a_eq, a_ineq); })
+}
 
 slp_matrix *slp_matrix_normal(slp_matrix *a, double gamma_eq, double gamma_ineq) {
     SLP_API_PTR({ return matrix_normal(a, gamma_eq, gamma_ineq); })

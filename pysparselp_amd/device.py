@@ -91,6 +91,22 @@ class DeviceMatrix:
         h = _lib.check_handle(self._l.slp_matrix_normal(self._h, float(gamma_eq), float(gamma_ineq)))
         return DeviceMatrix(h, (self.shape[1], self.shape[1]))
 
+    def precondition_rows(self, b=None, b2=None):
+        """``precondition_constraints(a, b, b2, alpha=2)`` of the reference (tools.py:272-290) on the device:
+        ``(A_scaled, b_scaled, b2_scaled)`` -- rows of unit 2-norm stored in scipy's order for ``diags(1/s) * A``."""
+        b = None if b is None else _lib.f64(b).copy()
+        b2 = None if b2 is None else _lib.f64(b2).copy()
+        h = _lib.check_handle(self._l.slp_matrix_precondition_rows(self._h, _lib.ptr(b), _lib.ptr(b2)))
+        return DeviceMatrix(h, self.shape), b, b2
+
+    @staticmethod
+    def standard_form(a_eq, a_ineq):
+        """``[[A_eq, 0], [A_ineq, -I]]`` (tools.py:88-127) from two DeviceMatrix blocks (``a_eq`` may be None)."""
+        l = _lib.lib()
+        h = _lib.check_handle(l.slp_matrix_standard_form(None if a_eq is None else a_eq._h, a_ineq._h))
+        me = 0 if a_eq is None else a_eq.shape[0]
+        return DeviceMatrix(h, (me + a_ineq.shape[0], a_ineq.shape[1] + a_ineq.shape[0]))
+
     def remove_columns(self, keep, shift=None):
         """``(A[:, keep], A @ shift)``: the column compaction of ``SparseLP.remove_fixed_variables``
         (SparseLP.py:632-674) on the device; ``keep`` is a boolean mask, entries stay in storage order.

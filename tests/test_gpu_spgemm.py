@@ -119,3 +119,88 @@ def test_device_cp_with_fixed_variables_matches_the_oracle_on_the_reduced_lp():
                                          nb_iter_plot=10 ** 9)
     assert np.array_equal(x_red, x_ref)
     assert np.array_equal(x_full[free], x_ref) and np.array_equal(x_full[fixed], lb2[fixed])
+
+
+def test_setup_chain_on_the_device_matches_the_reference_fixture():
+    """ADMM.py:76-91 on the device: row scaling of both blocks, slack standard form, row scaling of the stacked system --
+    against the arrays captured from the reference (kernel_kats.npz) and against the numpy restatement in tools.py."""
+    from pysparselp_amd import tools
+    from pysparselp_amd.device import DeviceMatrix
+
+    d = load_golden("kernel_kats")
+    ae, ai = DeviceMatrix.from_csr(csr_of(d, "setup_Ae")), DeviceMatrix.from_csr(csr_of(d, "setup_Ai"))
+    ae2, be, _ = ae.precondition_rows(d["setup_be"])
+    ai2, bl, bu = ai.precondition_rows(d["setup_bl"], d["setup_bu"])
+    h_ae, h_be = tools.precondition_constraints(csr_of(d, "setup_Ae"), d["setup_be"])
+    h_ai, h_bl, h_bu = tools.precondition_constraints(csr_of(d, "setup_Ai"), d["setup_bl"], d["setup_bu"])
+    _same_csr(ae2, h_ae)
+    _same_csr(ai2, h_ai)
+    assert np.array_equal(be, h_be) and np.array_equal(bl, h_bl) and np.array_equal(bu, h_bu)
+    a2 = DeviceMatrix.standard_form(ae2, ai2)
+    b2 = np.concatenate((be, np.zeros(ai.shape[0])))
+    a3, b3, _ = a2.precondition_rows(b2)
+    _same_csr(a3, csr_of(d, "setup_A3"))
+    assert np.array_equal(b3, d["setup_b3"])
+    assert np.array_equal(np.concatenate((d["setup_lb"], bl)), d["setup_lb2"])
+    assert np.array_equal(np.concatenate((d["setup_ub"], bu)), d["setup_ub2"])
+    for m in (ae, ai, ae2, ai2, a2, a3):
+        m.close()
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_setup_transforms_match_the_host_restatement_on_random_blocks(seed):
+    """Unsorted rows, empty rows, duplicate (row, column) pairs, values that underflow to 0 when scaled."""
+    from pysparselp_amd import tools
+    from pysparselp_amd.device import DeviceMatrix
+
+    rng = np.random.RandomState(100 + seed)
+    n, me, mi = int(rng.randint(2, 60)), int(rng.randint(0, 40)), int(rng.randint(1, 50))
+
+    def block(rows):
+        lens = rng.randint(0, 6, size=rows)
+        indptr = np.concatenate(([0], np.cumsum(lens)))
+        indices = rng.randint(0, n, size=indptr[-1]).astype(np.int32)  # unsorted, duplicates possible
+        data = np.round(rng.randn(indptr[-1]) * 8) / 8
+        if data.size > 3:
+            data[0] = 5e-324      # scaled by 1/||row|| < 1 it underflows to exactly 0 and is dropped
+            data[1] = 1e300
+        return scipy.sparse.csr_matrix((data, indices, indptr), shape=(rows, n))
+
+    a_eq, a_in = block(me), block(mi)
+    be, bl, bu = rng.randn(me), np.where(rng.rand(mi) < 0.3, -np.inf, rng.randn(mi)), np.where(rng.rand(mi) < 0.3, np.inf, rng.randn(mi) + 3)
+    c, lb, ub, x0 = rng.randn(n), -rng.rand(n), rng.rand(n), rng.randn(n)
+    hae, hbe = tools.precondition_constraints(a_eq, be)
+    hai, hbl, hbu = tools.precondition_constraints(a_in, bl, bu)
+    c2, ha2, hb2, lb2, ub2, hx = tools.convert_to_standard_form_with_bounds(c, hae if me else None, hbe if me else None, hai, hbl, hbu, lb, ub, x0)
+    ha3, hb3 = tools.precondition_constraints(ha2, hb2)
+    dae, dai = DeviceMatrix.from_csr(a_eq), DeviceMatrix.from_csr(a_in)
+    dae2, dbe, _ = dae.precondition_rows(be)
+    dai2, dbl, dbu = dai.precondition_rows(bl, bu)
+    _same_csr(dae2, hae)
+    _same_csr(dai2, hai)
+    assert np.array_equal(dbe, hbe) and np.array_equal(dbl, hbl) and np.array_equal(dbu, hbu)
+    da2 = DeviceMatrix.standard_form(dae2 if me else None, dai2)
+    _same_csr(da2, ha2)
+    da3, db3, _ = da2.precondition_rows(hb2)
+    _same_csr(da3, ha3)
+    assert np.array_equal(db3, hb3)
+    assert np.array_equal(dai2.matvec(x0, 1), hx[n:])       # the slack part of x0: A_ineq' x0 in the scaled block's stored order
+
+
+@pytest.mark.parametrize("case", ["sc50a", "potts8", "random1"])
+def test_lp_admm_device_setup_equals_host_setup(case, monkeypatch):
+    """The same iterates bit for bit whether ADMM.py:76-101 runs on the device (default) or in numpy (SLP_HOST_SETUP=1)."""
+    from conftest import Recorder, solver_args
+    from pysparselp_amd.ADMM import lp_admm
+
+    d = load_golden("lp_" + case)
+    runs = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("SLP_HOST_SETUP", host)
+        rec = Recorder()
+        x = lp_admm(*solver_args(d), nb_iter=120, callback_func=rec, nb_iter_plot=20)
+        runs.append((x, rec))
+    assert np.array_equal(runs[0][0], runs[1][0])
+    for u, v in zip(runs[0][1].x, runs[1][1].x):
+        assert np.array_equal(u, v)
+    assert runs[0][1].e1 == runs[1][1].e1 and runs[0][1].veq == runs[1][1].veq
