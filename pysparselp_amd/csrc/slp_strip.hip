@@ -49,7 +49,10 @@ constexpr int kWideColShift = 11; // wide dictionary entry: value id in the low 
 constexpr int kDictU1 = 8, kDictU2 = 8;  // entry-pair loads in flight per lane (one / two right-hand sides)
 constexpr int kStripT = 1024;    // threads per workgroup
 constexpr int kStripR = 2048;    // rows per block (two per thread)
-constexpr int kStripSL = 256;    // slots (max entries of one row inside one strip)
+constexpr int kStripSL = 256;
+#ifndef SLP_NT_DEFAULT
+#define SLP_NT_DEFAULT 0
+#endif    // slots (max entries of one row inside one strip)
 static_assert(kStripC % 2 == 0 && kDictC % 2 == 0 && kStripR == 2 * kStripT, "strip geometry");
 
 // ---- distinct stored values ------------------------------------------------------
@@ -231,12 +234,35 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
     }
 }
 
+// Entry streams are read exactly once per product: non-temporal loads keep them from displacing the x-tiles (which
+// every workgroup re-reads) in the caches.  NT is a template switch so that both forms can be timed (SLP_NT_LOADS=0/1).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 ld_stream(const double2 *p) {
+    if (!NT) return *p;
+    const f64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f64x2_t *>(p));
+    return make_double2(v.x, v.y);
+}
+template <bool NT>
+__device__ __forceinline__ ushort2 ld_stream(const ushort2 *p) {
+    if (!NT) return *p;
+    const unsigned int v = __builtin_nontemporal_load(reinterpret_cast<const unsigned int *>(p));
+    return make_ushort2((unsigned short)(v & 0xffffu), (unsigned short)(v >> 16));
+}
+template <bool NT>
+__device__ __forceinline__ uint2 ld_stream(const uint2 *p) {
+    if (!NT) return *p;
+    const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t *>(p));
+    return make_uint2(v.x, v.y);
+}
+
 // ---- the product ---------------------------------------------------------------
 // One workgroup per row block; 60 KB x-tile + 16 KB running sums + 1 KB slot offsets of LDS
 // (two workgroups per CU).  out[row] = sum over the row (single accumulator, storage order).
 // ABLATE != 0 is instantiated only in the -DSLP_ABLATION build (timing experiments, wrong results): 1 = no x-tile
 // staging, 2 = no entry streaming
-template <int ABLATE>
+template <int ABLATE, bool NT>
 __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                            const unsigned short *__restrict__ perm,
                                                            const unsigned char *__restrict__ slen,
@@ -278,8 +304,8 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
         for (; s + 4 <= n0; s += 4) {  // four independent 16-byte + 4-byte loads in flight per lane
             const unsigned int o0 = (offs[s] >> 1) + p, o1 = (offs[s + 1] >> 1) + p, o2 = (offs[s + 2] >> 1) + p,
                                o3 = (offs[s + 3] >> 1) + p;
-            const double2 w0 = v2[o0], w1 = v2[o1], w2 = v2[o2], w3 = v2[o3];
-            const ushort2 j0 = c2[o0], j1 = c2[o1], j2 = c2[o2], j3 = c2[o3];
+            const double2 w0 = ld_stream<NT>(v2 + o0), w1 = ld_stream<NT>(v2 + o1), w2 = ld_stream<NT>(v2 + o2), w3 = ld_stream<NT>(v2 + o3);
+            const ushort2 j0 = ld_stream<NT>(c2 + o0), j1 = ld_stream<NT>(c2 + o1), j2 = ld_stream<NT>(c2 + o2), j3 = ld_stream<NT>(c2 + o3);
             a0 += w0.x * xt[j0.x];
             a0 += w1.x * xt[j1.x];
             a0 += w2.x * xt[j2.x];
@@ -291,8 +317,8 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
         }
         for (; s < n0; ++s) {
             const unsigned int o = (offs[s] >> 1) + p;
-            const double2 w = v2[o];
-            const ushort2 j = c2[o];
+            const double2 w = ld_stream<NT>(v2 + o);
+            const ushort2 j = ld_stream<NT>(c2 + o);
             a0 += w.x * xt[j.x];
             if (s < n1) a1 += w.y * xt[j.y];
         }
@@ -394,7 +420,7 @@ __global__ __launch_bounds__(kStripT, 4) void k_strip_spmv2(i64 nrow, i64 ncol, 
 // {id0, id1, col0, col1}; the value is dict[id] read from LDS -- the same fp64 number the CSR holds, so every
 // row sum is still the sequential single-accumulator sum, bit for bit.  NV = 1: 46 KB x-tile + 16 KB sums
 // + 16 KB dictionary + 1 KB offsets = 79 KB (two workgroups per CU); NV = 2: 141 KB (one per CU).
-template <int NV>
+template <int NV, bool NT>
 __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                                          const unsigned short *__restrict__ perm,
                                                                          const unsigned char *__restrict__ slen,
@@ -486,7 +512,7 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
 #pragma unroll
             for (int i = 0; i < kDictU; ++i) of[i] = so[s + i];
 #pragma unroll
-            for (int i = 0; i < kDictU; ++i) q[i] = e2[(s + i < n0) ? (of[i] >> 1) + p : p];
+            for (int i = 0; i < kDictU; ++i) q[i] = ld_stream<NT>(e2 + ((s + i < n0) ? (of[i] >> 1) + p : p));
 #pragma unroll
             for (int i = 0; i < kDictU; ++i)
                 if (s + i < n0) SLP_DSTRIP_STEP(q[i], s + i < n1)
@@ -846,6 +872,11 @@ bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int varian
     return variant == 2 ? strip_build_c<kQuadC, 4>(a, f, dict) : strip_build_c<kDictC, 2>(a, f, dict);
 }
 
+static bool nt_loads() {  // SLP_NT_LOADS=0 / 1: plain / non-temporal entry loads in the LDS-strip kernels
+    static const int v = [] { const char *e = getenv("SLP_NT_LOADS"); return e ? atoi(e) : SLP_NT_DEFAULT; }();
+    return v != 0;
+}
+
 static void wide_launch(const StripJds &f, int nv, const double *x0, const double *x1, double *o0, double *o1) {
     const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
     hipStream_t st = ctx().stream;
@@ -872,26 +903,33 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
             hipLaunchKernelGGL((k_qstrip_spmv<1>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
                                f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
                                (double *)nullptr);
+        else if (nt_loads())
+            hipLaunchKernelGGL((k_dstrip_spmv<1, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
+                               f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
+                               (double *)nullptr);
         else
-        hipLaunchKernelGGL((k_dstrip_spmv<1>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T,
-                           f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                           (double *)nullptr);
+            hipLaunchKernelGGL((k_dstrip_spmv<1, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
+                               f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
+                               (double *)nullptr);
         if (f.S > 1)
             hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
         SLP_HIP(hipGetLastError());
         return;
     }
 #define SLP_STRIP_LAUNCH(A)                                                                                                        \
-    hipLaunchKernelGGL((k_strip_spmv<A>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, \
+    hipLaunchKernelGGL((k_strip_spmv<A, NTF>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, \
                        f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out)
+    const bool nt = nt_loads();
 #ifdef SLP_ABLATION  // `make ablation` (tools/ablate_strip.py) only: the ablated kernels return WRONG sums; not in libslp_hip.so
     const char *e = getenv("SLP_STRIP_ABLATE");
     const int ab = e ? atoi(e) : 0;
+    constexpr bool NTF = false;
     if (ab == 1) SLP_STRIP_LAUNCH(1);
     else if (ab == 2) SLP_STRIP_LAUNCH(2);
     else
 #endif
-    SLP_STRIP_LAUNCH(0);
+    if (nt) { constexpr bool NTF = true; SLP_STRIP_LAUNCH(0); }
+    else { constexpr bool NTF = false; SLP_STRIP_LAUNCH(0); }
 #undef SLP_STRIP_LAUNCH
     if (f.S > 1)
         hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
@@ -916,7 +954,7 @@ void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *
         hipLaunchKernelGGL((k_qstrip_spmv<2>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
                            f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1);
     else if (f.D > 0)
-        hipLaunchKernelGGL((k_dstrip_spmv<2>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
+        hipLaunchKernelGGL((k_dstrip_spmv<2, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
                            f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1);
     else
         hipLaunchKernelGGL(k_strip_spmv2, dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,

@@ -163,7 +163,7 @@ def test_setup_transforms_match_the_host_restatement_on_random_blocks(seed):
         data = np.round(rng.randn(indptr[-1]) * 8) / 8
         if data.size > 3:
             data[0] = 5e-324      # scaled by 1/||row|| < 1 it underflows to exactly 0 and is dropped
-            data[1] = 1e300
+            data[1] = 1e150      # its square is still finite
         return scipy.sparse.csr_matrix((data, indices, indptr), shape=(rows, n))
 
     a_eq, a_in = block(me), block(mi)
