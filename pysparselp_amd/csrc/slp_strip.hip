@@ -51,7 +51,7 @@ constexpr int kStripT = 1024;    // threads per workgroup
 constexpr int kStripR = 2048;    // rows per block (two per thread)
 constexpr int kStripSL = 256;
 #ifndef SLP_NT_DEFAULT
-#define SLP_NT_DEFAULT 0
+#define SLP_NT_DEFAULT 2  // fp64 strips: non-temporal 16-byte value loads (3.52 vs 3.88 ms at config 3), plain 4-byte column loads
 #endif    // slots (max entries of one row inside one strip)
 static_assert(kStripC % 2 == 0 && kDictC % 2 == 0 && kStripR == 2 * kStripT, "strip geometry");
 
@@ -262,7 +262,7 @@ __device__ __forceinline__ uint2 ld_stream(const uint2 *p) {
 // (two workgroups per CU).  out[row] = sum over the row (single accumulator, storage order).
 // ABLATE != 0 is instantiated only in the -DSLP_ABLATION build (timing experiments, wrong results): 1 = no x-tile
 // staging, 2 = no entry streaming
-template <int ABLATE, bool NT>
+template <int ABLATE, bool NT, bool NT4 = true>
 __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                            const unsigned short *__restrict__ perm,
                                                            const unsigned char *__restrict__ slen,
@@ -305,7 +305,8 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
             const unsigned int o0 = (offs[s] >> 1) + p, o1 = (offs[s + 1] >> 1) + p, o2 = (offs[s + 2] >> 1) + p,
                                o3 = (offs[s + 3] >> 1) + p;
             const double2 w0 = ld_stream<NT>(v2 + o0), w1 = ld_stream<NT>(v2 + o1), w2 = ld_stream<NT>(v2 + o2), w3 = ld_stream<NT>(v2 + o3);
-            const ushort2 j0 = ld_stream<NT>(c2 + o0), j1 = ld_stream<NT>(c2 + o1), j2 = ld_stream<NT>(c2 + o2), j3 = ld_stream<NT>(c2 + o3);
+            const ushort2 j0 = ld_stream<NT && NT4>(c2 + o0), j1 = ld_stream<NT && NT4>(c2 + o1), j2 = ld_stream<NT && NT4>(c2 + o2),
+                          j3 = ld_stream<NT && NT4>(c2 + o3);
             a0 += w0.x * xt[j0.x];
             a0 += w1.x * xt[j1.x];
             a0 += w2.x * xt[j2.x];
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
         for (; s < n0; ++s) {
             const unsigned int o = (offs[s] >> 1) + p;
             const double2 w = ld_stream<NT>(v2 + o);
-            const ushort2 j = ld_stream<NT>(c2 + o);
+            const ushort2 j = ld_stream<NT && NT4>(c2 + o);
             a0 += w.x * xt[j.x];
             if (s < n1) a1 += w.y * xt[j.y];
         }
@@ -539,7 +540,9 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
 // (two workgroups per CU); NV = 2: 142 KB.  Same single-accumulator, storage-order row sums.
 struct alignas(4) Quad12 { unsigned int x, y, z; };
 
-template <int NV>
+typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
+
+template <int NV, bool NT = false>
 __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                                          const unsigned short *__restrict__ perm,
                                                                          const unsigned char *__restrict__ slen,
@@ -601,6 +604,11 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nr
         const ushort4 r = r_next;
         const unsigned int n0 = nn_next.x, n1 = nn_next.y, n2 = nn_next.z, n3 = nn_next.w;  // n0 >= n1 >= n2 >= n3
         const Quad12 *__restrict__ e4 = reinterpret_cast<const Quad12 *>(ent) + (base_next >> 2);
+        // NT: the cell's entries through a wave-uniform buffer descriptor, 12-byte loads with the non-temporal policy
+        const unsigned long long e4u = (unsigned long long)e4;
+        const void *e4s = (const void *)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(e4u >> 32)) << 32) |
+                                         (unsigned int)__builtin_amdgcn_readfirstlane((int)e4u));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(e4s), 0, 0x7fffffff, 0x00020000);
         __syncthreads();
         if (t + 1 < t_end) prefetch(t + 1);
         double a[NV][4];
@@ -622,7 +630,15 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nr
 #pragma unroll
             for (int i = 0; i < kU; ++i) of[i] = so[(s + i) & (kStripSL - 1)];
 #pragma unroll
-            for (int i = 0; i < kU; ++i) q[i] = e4[(s + i < n0) ? (of[i] >> 2) + p : p];
+            for (int i = 0; i < kU; ++i) {
+                const unsigned int qi = (s + i < n0) ? (of[i] >> 2) + p : p;
+                if (NT) {
+                    const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, qi * 12u, 0, 2);
+                    q[i].x = v.x; q[i].y = v.y; q[i].z = v.z;
+                } else {
+                    q[i] = e4[qi];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < kU; ++i) {
                 if (s + i < n0) {
@@ -872,6 +888,14 @@ bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int varian
     return variant == 2 ? strip_build_c<kQuadC, 4>(a, f, dict) : strip_build_c<kDictC, 2>(a, f, dict);
 }
 
+static int nt_level() {
+    static const int v = [] { const char *e = getenv("SLP_NT_LOADS"); return e ? atoi(e) : SLP_NT_DEFAULT; }();
+    return v;
+}
+static bool nt_quads() {
+    static const int v = [] { const char *e = getenv("SLP_NT_QUADS"); return e ? atoi(e) : 0; }();
+    return v != 0;
+}
 static bool nt_loads() {  // SLP_NT_LOADS=0 / 1: plain / non-temporal entry loads in the LDS-strip kernels
     static const int v = [] { const char *e = getenv("SLP_NT_LOADS"); return e ? atoi(e) : SLP_NT_DEFAULT; }();
     return v != 0;
@@ -899,11 +923,15 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
         return;
     }
     if (f.D > 0) {
-        if (f.rpl == 4)
-            hipLaunchKernelGGL((k_qstrip_spmv<1>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
+        if (f.rpl == 4 && nt_quads())
+            hipLaunchKernelGGL((k_qstrip_spmv<1, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
                                f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
                                (double *)nullptr);
-        else if (nt_loads())
+        else if (f.rpl == 4)
+            hipLaunchKernelGGL((k_qstrip_spmv<1, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
+                               f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
+                               (double *)nullptr);
+        else if (nt_level() == 1)  // 8-byte non-temporal loads measured SLOWER than plain ones (2.33 vs 2.23 ms): explicit only
             hipLaunchKernelGGL((k_dstrip_spmv<1, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
                                f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
                                (double *)nullptr);
@@ -928,7 +956,10 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
     else if (ab == 2) SLP_STRIP_LAUNCH(2);
     else
 #endif
-    if (nt) { constexpr bool NTF = true; SLP_STRIP_LAUNCH(0); }
+    if (nt && nt_level() == 2)
+        hipLaunchKernelGGL((k_strip_spmv<0, true, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
+                           f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out);
+    else if (nt) { constexpr bool NTF = true; SLP_STRIP_LAUNCH(0); }
     else { constexpr bool NTF = false; SLP_STRIP_LAUNCH(0); }
 #undef SLP_STRIP_LAUNCH
     if (f.S > 1)
