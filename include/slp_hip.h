@@ -76,16 +76,16 @@ int slp_matrix_download_rows(slp_matrix *a, int transposed, int64_t row0, int64_
 /* Device-resident benchmark kernels: `reps` back-to-back launches on resident
  * vectors, no host traffic; *ms = average GPU time per launch (HIP events). */
 int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, double *ms);
+/* New device-resident matrix whose row r is scale[r] * (row rows[r] of a): the one-sided stacking [A[up]; -A[lo]] of
+ * ChambollePockPPD.py:74-88 (and any row selection) without a round trip of the CSR through the host.
+ * scale 1 copies, -1 negates exactly. */
+slp_matrix *slp_matrix_gather_rows(slp_matrix *a, int64_t count, const int64_t *rows, const double *scale);
 /* Which kernel serves that orientation: 1 = LDS-tiled strip kernel (k_strip_spmv; long sorted rows,
  * >= 3e7 stored entries), 3 / 2 = the same over a value-dictionary copy (at most 2048 distinct stored values):
  * 3 = k_qstrip_spmv (4096-row blocks, 3-byte entries), 2 = k_dstrip_spmv (2048-row blocks, 4-byte entries;
  * SLP_DICT_VARIANT=1), 4 / 5 = wide strips (k_wstrip_spmv: strips of 131072 columns, x gathered from L2; rows too sparse
  * for the LDS tile over a width far beyond an L2) with value-dictionary / fp64 entries,
  * 0 = row-per-lane-group CSR kernel (k_spmv), -1 = error. */
-/* New device-resident matrix whose row r is scale[r] * (row rows[r] of a): the one-sided stacking [A[up]; -A[lo]] of
- * ChambollePockPPD.py:74-88 (and any row selection) without a round trip of the CSR through the host.
- * scale 1 copies, -1 negates exactly. */
-slp_matrix *slp_matrix_gather_rows(slp_matrix *a, int64_t count, const int64_t *rows, const double *scale);
 int slp_matrix_spmv_kernel(slp_matrix *a, int transposed);
 /* M = gamma_eq A^T A + gamma_ineq I (N x N CSR, sorted rows, exact zeros dropped) formed on the device: replaces
  * `(gamma_eq * a.T * a + gamma_ineq * eye).tocsr()` of ADMM.py:93-101, i.e. scipy's SMMP csr_matmat, with the same
