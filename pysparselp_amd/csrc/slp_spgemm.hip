@@ -130,8 +130,13 @@ static slp_matrix *matrix_normal(slp_matrix *a, double gamma_eq, double gamma_in
         u64 total = 0;
         SLP_HIP(hipMemcpyAsync(&total, off.p + N, sizeof(u64), hipMemcpyDeviceToHost, st));
         SLP_HIP(hipStreamSynchronize(st));
-        SLP_REQUIRE(total < ((u64)1 << 40), "slp_matrix_normal: more than 2^40 products -- M is not sparse at this size (use the "
-                                             "matrix-free conjugate-gradient x-step)");
+        {  // expand-sort-compress holds every product twice (key + value, double-buffered by the sort): 32 bytes each
+            size_t free_b = 0, total_b = 0;
+            SLP_HIP(hipMemGetInfo(&free_b, &total_b));
+            SLP_REQUIRE(total < ((u64)1 << 40) && (double)total * 40.0 < (double)free_b + (double)slp_cached_bytes(),
+                        "slp_matrix_normal: " + std::to_string(total) + " products A[k,i] * A[k,j] do not fit the device -- M is not sparse "
+                        "at this size (use the matrix-free conjugate-gradient x-step, lp_admm(xstep=\"cg\"))");
+        }
         DevBuf<u64> key((size_t)total), key2((size_t)total);
         DevBuf<double> prod((size_t)total), prod2((size_t)total);
         if (N) hipLaunchKernelGGL(k_nm_expand, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, st, N, c.ptr.p, c.idx.p, c.val.p, r.ptr.p, r.idx.p,
