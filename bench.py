@@ -56,9 +56,9 @@ KERNEL_NAMES = {
 }
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this exact workload (tools/profile_c3.sh, tools/summarize_rocprof.py)
 PMC_FILES = {
-    3: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_quad.json"), "slp::k_qstrip_spmv<1>"),
-    2: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_dict.json"), "slp::k_dstrip_spmv<1>"),
-    1: (("r02_c3_pmc_hbm.json", "r01_cp_c3_pmc_hbm.json"), "slp::k_strip_spmv<0>"),
+    3: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_quad.json"), "slp::k_qstrip_spmv<1"),   # kernel-name prefixes: the template
+    2: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_dict.json"), "slp::k_dstrip_spmv<1"),   # argument lists grew between rounds
+    1: (("r02_c3_pmc_hbm.json", "r01_cp_c3_pmc_hbm.json"), "slp::k_strip_spmv<0"),
 }
 
 
@@ -109,9 +109,9 @@ def pmc_traffic(kernel_id, shape):
     for name in names:
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
-            k = json.load(open(path))["kernels"].get(kern)
-            if k:
-                return k["hbm_bytes_per_launch_corrected"], "profiles/" + name
+            for full, k in json.load(open(path))["kernels"].items():
+                if full.startswith(kern):
+                    return k["hbm_bytes_per_launch_corrected"], "profiles/" + name
     return None, None
 
 

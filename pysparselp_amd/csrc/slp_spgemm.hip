@@ -345,37 +345,40 @@ __global__ void k_sf_count(i64 me, i64 mi, const i64 *__restrict__ eptr, const i
 
 __global__ void k_sf_fill(i64 me, i64 mi, i64 n, const i64 *__restrict__ eptr, const i32 *__restrict__ eidx, const double *__restrict__ eval,
                           const i64 *__restrict__ iptr, const i32 *__restrict__ iidx, const double *__restrict__ ival,
-                          const i64 *__restrict__ optr, unsigned int *__restrict__ okey, double *__restrict__ oval) {
+                          const i64 *__restrict__ optr, u64 *__restrict__ okey, double *__restrict__ oval) {
+    // key = (column << 32 | position in the row): a total order, so duplicates of a (row, column) pair keep their storage
+    // order whatever algorithm the segmented sort picks for short segments (its small-segment path is not a stable sort)
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < me + mi; r += (i64)gridDim.x * blockDim.x) {
-        i64 o = optr[r];
+        const i64 o0 = optr[r];
+        i64 o = o0;
         if (r < me) {
-            for (i64 k = eptr[r]; k < eptr[r + 1]; ++k, ++o) { okey[o] = (unsigned int)eidx[k]; oval[o] = eval[k]; }
+            for (i64 k = eptr[r]; k < eptr[r + 1]; ++k, ++o) { okey[o] = ((u64)(unsigned int)eidx[k] << 32) | (u64)(o - o0); oval[o] = eval[k]; }
         } else {
             const i64 i = r - me;
-            for (i64 k = iptr[i]; k < iptr[i + 1]; ++k, ++o) { okey[o] = (unsigned int)iidx[k]; oval[o] = ival[k]; }
-            okey[o] = (unsigned int)(n + i);
+            for (i64 k = iptr[i]; k < iptr[i + 1]; ++k, ++o) { okey[o] = ((u64)(unsigned int)iidx[k] << 32) | (u64)(o - o0); oval[o] = ival[k]; }
+            okey[o] = ((u64)(n + i) << 32) | (u64)(o - o0);
             oval[o] = -1.0;
         }
     }
 }
 
 // unique columns per (sorted) row
-__global__ void k_sf_unique(i64 rows, const i64 *__restrict__ ptr, const unsigned int *__restrict__ key, u64 *__restrict__ len) {
+__global__ void k_sf_unique(i64 rows, const i64 *__restrict__ ptr, const u64 *__restrict__ key, u64 *__restrict__ len) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (i64)gridDim.x * blockDim.x) {
         u64 c = 0;
-        for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) c += (k == ptr[r] || key[k] != key[k - 1]) ? 1 : 0;
+        for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) c += (k == ptr[r] || (key[k] >> 32) != (key[k - 1] >> 32)) ? 1 : 0;
         len[r] = c;
     }
 }
 
-__global__ void k_sf_merge(i64 rows, const i64 *__restrict__ ptr, const unsigned int *__restrict__ key, const double *__restrict__ val,
+__global__ void k_sf_merge(i64 rows, const i64 *__restrict__ ptr, const u64 *__restrict__ key, const double *__restrict__ val,
                            const i64 *__restrict__ optr, i32 *__restrict__ oidx, double *__restrict__ oval) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (i64)gridDim.x * blockDim.x) {
         i64 o = optr[r] - 1;
         for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) {
-            if (k == ptr[r] || key[k] != key[k - 1]) {
+            if (k == ptr[r] || (key[k] >> 32) != (key[k - 1] >> 32)) {
                 ++o;
-                oidx[o] = (i32)key[k];
+                oidx[o] = (i32)(key[k] >> 32);
                 oval[o] = val[k];
             } else {
                 oval[o] = oval[o] + val[k];  // duplicates summed left to right, like COO -> CSR
@@ -405,7 +408,7 @@ slp_matrix *matrix_standard_form(slp_matrix *ae, slp_matrix *ai) {
         SLP_HIP(hipMemcpyAsync(&total, tptr.p + rows, sizeof(i64), hipMemcpyDeviceToHost, st));
         SLP_HIP(hipStreamSynchronize(st));
         SLP_REQUIRE(total < (i64)0x7fffffffll, "standard_form: more than 2^31-1 stored entries");
-        DevBuf<unsigned int> key((size_t)total), key2((size_t)total);
+        DevBuf<u64> key((size_t)total), key2((size_t)total);
         DevBuf<double> val((size_t)total), val2((size_t)total);
         if (rows)
             hipLaunchKernelGGL(k_sf_fill, dim3(g), dim3(kBlock), 0, st, me, mi, n, ae ? ae->a.ptr.p : nullptr, ae ? ae->a.idx.p : nullptr,
@@ -413,13 +416,13 @@ slp_matrix *matrix_standard_form(slp_matrix *ae, slp_matrix *ai) {
         SLP_HIP(hipGetLastError());
         unsigned int bits = 1;
         while (bits < 32 && ((i64)1 << bits) < n + mi) ++bits;
-        if (total) {  // stable sort of every row by column
+        if (total) {  // every row sorted by (column, position in the row)
             size_t bytes = 0;
             SLP_HIP(rocprim::segmented_radix_sort_pairs(nullptr, bytes, key.p, key2.p, val.p, val2.p, (unsigned int)total, (unsigned int)rows,
-                                                        tptr.p, tptr.p + 1, 0u, bits, st));
+                                                        tptr.p, tptr.p + 1, 0u, 32u + bits, st));
             DevBuf<char> tmp(bytes);
             SLP_HIP(rocprim::segmented_radix_sort_pairs(tmp.p, bytes, key.p, key2.p, val.p, val2.p, (unsigned int)total, (unsigned int)rows,
-                                                        tptr.p, tptr.p + 1, 0u, bits, st));
+                                                        tptr.p, tptr.p + 1, 0u, 32u + bits, st));
             SLP_HIP(hipStreamSynchronize(st));
         }
         len.zero();
