@@ -38,12 +38,20 @@ def check_line(d, need_cpu_baseline):
         assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
 
 
-@pytest.mark.parametrize("name", ["r01_bench_admm_c3_final.json", "r01_bench_cp_c3_final.json"])
+@pytest.mark.parametrize("name", ["r01_bench_admm_c3_final.json", "r01_bench_cp_c3_final.json", "r02_bench_admm_c3.json",
+                                  "r02_bench_cp_c3.json"])
 def test_committed_bench_lines(name):
     d = json.loads(open(os.path.join(REPO, "profiles", name)).read().strip().splitlines()[-1])
     check_line(d, need_cpu_baseline=True)
     assert d["n_gpus"] == 1 and d["config"]["n"] == 1_000_000 and d["config"]["m"] == 2_000_000  # BASELINE config 3
     assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic"] > 1e9                # PMC bytes per launch
+    if name.startswith("r02"):  # round 2: admissible fraction, the general path in the same line, an honest CPU baseline
+        r = d["roofline"]
+        assert r["frac"] <= 1.0 and abs(r["traffic"] / r["bytes_per_launch"] - 1.0) < 0.1          # PMC agrees with the bytes moved
+        g = r["general_fp64"]
+        assert 0.5 < g["spmv"]["frac"] <= 1.0 and 0.5 < g["spmv_transposed"]["frac"] <= 1.0
+        assert g["admm_it_per_s"] > 0 and g["chambolle_pock_it_per_s"] > 0
+        assert d["cpu_baseline"]["extrapolated"] is True and d["setup_seconds"] > 0 and d["device_memory"]["csr_released"]
 
 
 @pytest.mark.gpu
