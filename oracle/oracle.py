@@ -207,7 +207,12 @@ def _sorted_rows(indptr, indices, data, shape):
         new[1:] = (r[1:] != r[:-1]) | (j[1:] != j[:-1])
         if not np.all(new):
             starts = np.nonzero(new)[0]
-            v = np.add.reduceat(v, starts)
+            # left to right in storage order like scipy's csr_sum_duplicates (np.add.reduceat is not sequential on
+            # runs of three or more duplicates; np.add.at is)
+            run = np.cumsum(new) - 1
+            summed = np.zeros(starts.size)
+            np.add.at(summed, run, v)
+            v = summed
             r, j = r[starts], j[starts]
     ptr = np.zeros(shape[0] + 1, dtype=np.int64)
     np.add.at(ptr, r + 1, 1)

@@ -95,7 +95,12 @@ def _rows_sorted_by_column(rows, cols, vals, shape):
         first[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
         if not first.all():  # duplicate (row, col) pairs are summed, as COO->CSR does
             starts = np.nonzero(first)[0]
-            vals = np.add.reduceat(vals, starts)
+            # summed left to right in storage order, as scipy's csr_sum_duplicates does (np.add.reduceat is NOT
+            # sequential on runs of three or more; np.add.at is)
+            run = np.cumsum(first) - 1
+            summed = np.zeros(starts.size)
+            np.add.at(summed, run, vals)
+            vals = summed
             rows, cols = rows[starts], cols[starts]
     indptr = np.concatenate(([0], np.cumsum(np.bincount(rows, minlength=shape[0]))))
     return CsrArrays(indptr, cols, vals, shape)

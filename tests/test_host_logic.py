@@ -187,3 +187,27 @@ def test_one_sided_row_plan_matches_the_reference_stacking():
     assert bb.tolist() == [5.0, 6.0, 1.0, 2.0, 3.0, 1.0, 2.0]
     with pytest.raises(ValueError):
         one_sided_rows(3, 0, np.array([-1.0, -np.inf, -1.0]), np.full(3, np.inf))
+
+
+def test_standard_form_sums_duplicate_entries_like_scipy():
+    """Rows with three or more entries in one column: scipy (the arithmetic under the reference's hstack / vstack / tocsr,
+    tools.py:88-127) sums them left to right in storage order -- np.add.reduceat does not.  Both restatements (the host
+    layer's and the oracle's) must match scipy bit for bit; the device transform is compared with them in
+    tests/test_gpu_spgemm.py."""
+    import scipy.sparse
+
+    from oracle import oracle
+
+    rng = np.random.RandomState(1)
+    for _ in range(200):
+        n, mi = int(rng.randint(1, 4)), int(rng.randint(1, 6))
+        lens = rng.randint(0, 9, size=mi)
+        ptr = np.concatenate(([0], np.cumsum(lens)))
+        a = scipy.sparse.csr_matrix((rng.randn(ptr[-1]), rng.randint(0, n, size=ptr[-1]).astype(np.int32), ptr), shape=(mi, n))
+        ref = scipy.sparse.hstack((a, -scipy.sparse.eye(mi, mi))).tocsr()
+        args = (np.zeros(n), None, None, a, None, None, np.zeros(n), np.ones(n), np.zeros(n))
+        got = tools.convert_to_standard_form_with_bounds(*args)[1]
+        orc = oracle.convert_to_standard_form_with_bounds(args[0], None, None, oracle.as_csr(a), *args[4:])[1]
+        for m in (got, orc):
+            assert np.array_equal(ref.indptr, m.indptr) and np.array_equal(ref.indices, m.indices)
+            assert np.array_equal(ref.data, m.data)
