@@ -542,7 +542,9 @@ struct alignas(4) Quad12 { unsigned int x, y, z; };
 
 typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
 
-template <int NV, bool NT = false>
+// ABL != 0 exists only in the -DSLP_ABLATION build (tools/ablate_quads.py; WRONG results): 1 = no value-table lookup,
+// 2 = no LDS gathers at all, 3 = no entry loads (synthetic entries from registers)
+template <int NV, bool NT = false, int ABL = 0>
 __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                                          const unsigned short *__restrict__ perm,
                                                                          const unsigned char *__restrict__ slen,
@@ -614,12 +616,12 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nr
         double a[NV][4];
 #pragma unroll
         for (int v = 0; v < NV; ++v) { a[v][0] = acc[v][r.x]; a[v][1] = acc[v][r.y]; a[v][2] = acc[v][r.z]; a[v][3] = acc[v][r.w]; }
-#define SLP_QSTRIP_TERM(h, e24)                                     \
-    {                                                               \
-        const double w = dv[(e24) & 0xfffu];                        \
-        const unsigned int j = ((e24) >> 12) & 0xfffu;              \
-        a[0][h] += w * xt[0][j];                                    \
-        if (NV == 2) a[NV - 1][h] += w * xt[NV - 1][j];             \
+#define SLP_QSTRIP_TERM(h, e24)                                                                  \
+    {                                                                                            \
+        const double w = (ABL == 1 || ABL == 2) ? (double)((e24) & 0xfffu) : dv[(e24) & 0xfffu]; \
+        const unsigned int j = ((e24) >> 12) & 0xfffu;                                           \
+        a[0][h] += w * (ABL == 2 ? (double)j : xt[0][j]);                                        \
+        if (NV == 2) a[NV - 1][h] += w * xt[NV - 1][j];                                          \
     }
         constexpr int kU = NV == 1 ? kQuadU1 : kQuadU2;
         const unsigned int n0w = (unsigned int)__builtin_amdgcn_readfirstlane((int)n0);  // sorted: the wave's largest count
@@ -632,7 +634,10 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nr
 #pragma unroll
             for (int i = 0; i < kU; ++i) {
                 const unsigned int qi = (s + i < n0) ? (of[i] >> 2) + p : p;
-                if (NT) {
+                if (ABL == 3) {
+                    q[i].x = qi * 2654435761u; q[i].y = q[i].x ^ (qi << 7); q[i].z = q[i].y + 0x9e3779b9u;
+                    q[i].x &= 0xff7ff7ffu; q[i].y &= 0xf7ff7ff7u; q[i].z &= 0x7ff7ff7fu;  // ids < 2048, columns < 3968
+                } else if (NT) {
                     const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, qi * 12u, 0, 2);
                     q[i].x = v.x; q[i].y = v.y; q[i].z = v.z;
                 } else {
@@ -923,6 +928,18 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
         return;
     }
     if (f.D > 0) {
+#ifdef SLP_ABLATION
+        if (f.rpl == 4 && getenv("SLP_QSTRIP_ABLATE") && atoi(getenv("SLP_QSTRIP_ABLATE")) > 0) {
+            const int ab = atoi(getenv("SLP_QSTRIP_ABLATE"));
+#define SLP_QABL(A)                                                                                                              \
+    hipLaunchKernelGGL((k_qstrip_spmv<1, false, A>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, \
+                       f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out, (double *)nullptr)
+            if (ab == 1) SLP_QABL(1);
+            else if (ab == 2) SLP_QABL(2);
+            else SLP_QABL(3);
+#undef SLP_QABL
+        } else
+#endif
         if (f.rpl == 4 && nt_quads())
             hipLaunchKernelGGL((k_qstrip_spmv<1, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
                                f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
