@@ -10,8 +10,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SLP_LIB_VARIANT=ablation: the -DSLP_ABLATION build of `make -C pysparselp_amd/csrc ablation` (tools/ablate_strip.py only)
-LIB_PATH = os.path.join(_HERE, "libslp_hip_ablation.so" if os.environ.get("SLP_LIB_VARIANT") == "ablation" else "libslp_hip.so")
+# SLP_LIB_VARIANT=<name>: libslp_hip_<name>.so -- the -DSLP_ABLATION build (`make -C pysparselp_amd/csrc ablation`, timing
+# experiments with wrong results) or a kernel-lab build (`make variant NAME=... EXTRA=...`); never set in production
+_VARIANT = os.environ.get("SLP_LIB_VARIANT")
+LIB_PATH = os.path.join(_HERE, f"libslp_hip_{_VARIANT}.so" if _VARIANT else "libslp_hip.so")
 
 ORDER_AUTO, ORDER_SEQUENTIAL, ORDER_TREE = 0, 1, 2
 

@@ -43,10 +43,20 @@ constexpr int kDictHash = 16384; // slots of the detection hash set
 constexpr unsigned long long kDictEmpty = ~0ull;
 constexpr int kQuadC = 3968;     // quad variant: 4 rows per lane (4096-row blocks), 31 KB of x, 12-bit column + 12-bit value id
 constexpr int kQuadR = 4 * 1024;
-constexpr int kQuadU1 = 4, kQuadU2 = 6;  // 12-byte quad loads in flight per lane (64 VGPRs at two workgroups per CU: 6 would spill)
+#ifndef SLP_QUAD_G
+#define SLP_QUAD_G 2
+#endif
+#ifndef SLP_QUAD_U1
+#define SLP_QUAD_U1 3  // 12-byte quad loads in flight per lane: 3 measured best with the branch-free slot body (1.92 ms; 4: 1.98, 2: 2.38)
+#endif
+constexpr int kQuadG = SLP_QUAD_G;       // rows of a lane's quad whose LDS gathers are issued together
+constexpr int kQuadU1 = SLP_QUAD_U1, kQuadU2 = 6;  // 12-byte quad loads in flight per lane (64 VGPRs at two workgroups per CU: 6 would spill)
 constexpr int kWideC = 131072;   // wide strips: 1 MB of x per strip, gathered from L2 (no LDS tile): rows too sparse for the LDS strips
 constexpr int kWideColShift = 11; // wide dictionary entry: value id in the low 11 bits, column inside the strip above
-constexpr int kDictU1 = 8, kDictU2 = 8;  // entry-pair loads in flight per lane (one / two right-hand sides)
+#ifndef SLP_DICT_U1
+#define SLP_DICT_U1 8
+#endif
+constexpr int kDictU1 = SLP_DICT_U1, kDictU2 = 8;  // entry-pair loads in flight per lane (one / two right-hand sides)
 constexpr int kStripT = 1024;    // threads per workgroup
 constexpr int kStripR = 2048;    // rows per block (two per thread)
 constexpr int kStripSL = 256;
@@ -487,6 +497,8 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
         if (t + 1 < t_end) prefetch(t + 1);
         double a0 = acc[0][r.x], a1 = acc[0][r.y], b0 = 0.0, b1 = 0.0;
         if (NV == 2) { b0 = acc[NV - 1][r.x]; b1 = acc[NV - 1][r.y]; }
+        // (A branch-free form of this step -- all four gathers issued together, selects instead of branches, as in
+        // k_qstrip_spmv -- measured SLOWER here: 2.43 against 2.23 ms for A^T y at config 3.)
 #define SLP_DSTRIP_STEP(q, live1)                                                   \
     {                                                                               \
         const double w0 = dv[(q).x & 0xffffu];                                      \
@@ -616,13 +628,6 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nr
         double a[NV][4];
 #pragma unroll
         for (int v = 0; v < NV; ++v) { a[v][0] = acc[v][r.x]; a[v][1] = acc[v][r.y]; a[v][2] = acc[v][r.z]; a[v][3] = acc[v][r.w]; }
-#define SLP_QSTRIP_TERM(h, e24)                                                                  \
-    {                                                                                            \
-        const double w = (ABL == 1 || ABL == 2) ? (double)((e24) & 0xfffu) : dv[(e24) & 0xfffu]; \
-        const unsigned int j = ((e24) >> 12) & 0xfffu;                                           \
-        a[0][h] += w * (ABL == 2 ? (double)j : xt[0][j]);                                        \
-        if (NV == 2) a[NV - 1][h] += w * xt[NV - 1][j];                                          \
-    }
         constexpr int kU = NV == 1 ? kQuadU1 : kQuadU2;
         const unsigned int n0w = (unsigned int)__builtin_amdgcn_readfirstlane((int)n0);  // sorted: the wave's largest count
         const unsigned int *__restrict__ so = soff + cell * kStripSL;
@@ -644,17 +649,39 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nr
                     q[i] = e4[qi];
                 }
             }
+            // Branch-free slot body: all eight LDS gathers of a slot (value table and x-tile for the lane's four rows) are
+            // issued back to back -- every address is valid, pad entries are (id 0, column 0) -- and only the accumulation is
+            // predicated (a select).  With a branch per term the compiler waits for each term's two gathers before it issues
+            // the next pair (s_waitcnt lgkmcnt(0) after every term): the LDS latency was paid once per entry.
 #pragma unroll
             for (int i = 0; i < kU; ++i) {
-                if (s + i < n0) {
-                    SLP_QSTRIP_TERM(0, q[i].x)
-                    if (s + i < n1) SLP_QSTRIP_TERM(1, (q[i].x >> 24) | (q[i].y << 8))
-                    if (s + i < n2) SLP_QSTRIP_TERM(2, (q[i].y >> 16) | (q[i].z << 16))
-                    if (s + i < n3) SLP_QSTRIP_TERM(3, q[i].z >> 8)
+                if (s + i < n0w) {  // wave-uniform: slots beyond the wave's longest row are skipped as a whole
+                    const unsigned int e[4] = {q[i].x, (q[i].x >> 24) | (q[i].y << 8), (q[i].y >> 16) | (q[i].z << 16), q[i].z >> 8};
+                    const bool live[4] = {s + i < n0, s + i < n1, s + i < n2, s + i < n3};
+                    // two rows at a time: four gathers in flight (eight spill registers at the 64-VGPR budget)
+#pragma unroll
+                    for (int g = 0; g < 4; g += kQuadG) {
+                        double w[kQuadG], xv[NV][kQuadG];
+#pragma unroll
+                        for (int h = 0; h < kQuadG; ++h) {
+                            w[h] = (ABL == 1 || ABL == 2) ? (double)(e[g + h] & 0xfffu) : dv[e[g + h] & 0xfffu];
+                            const unsigned int j = (e[g + h] >> 12) & 0xfffu;
+                            xv[0][h] = ABL == 2 ? (double)j : xt[0][j];
+                            if (NV == 2) xv[NV - 1][h] = xt[NV - 1][j];
+                        }
+#pragma unroll
+                        for (int h = 0; h < kQuadG; ++h) {
+                            const double t0 = a[0][g + h] + w[h] * xv[0][h];
+                            a[0][g + h] = live[g + h] ? t0 : a[0][g + h];
+                            if (NV == 2) {
+                                const double t1 = a[NV - 1][g + h] + w[h] * xv[NV - 1][h];
+                                a[NV - 1][g + h] = live[g + h] ? t1 : a[NV - 1][g + h];
+                            }
+                        }
+                    }
                 }
             }
         }
-#undef SLP_QSTRIP_TERM
 #pragma unroll
         for (int v = 0; v < NV; ++v) { acc[v][r.x] = a[v][0]; acc[v][r.y] = a[v][1]; acc[v][r.z] = a[v][2]; acc[v][r.w] = a[v][3]; }
         __syncthreads();
