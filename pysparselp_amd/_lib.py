@@ -87,6 +87,8 @@ _SIGNATURES = {
     "slp_admm_cg_create_on_mixed": (c_vp, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_blocks_create": (c_vp, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl]),
     "slp_blocks_create_on": (c_vp, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl]),
+    "slp_blocks_group_link": (c_int, [c_vp, c_int]),
+    "slp_blocks_group_iterate": (c_int, [c_vp, c_int, c_i64]),
     "slp_blocks_destroy": (None, [c_vp]),
     "slp_blocks_set_cg": (c_int, [c_vp, c_dbl, c_int]),
     "slp_blocks_iterate": (c_int, [c_vp, c_i64]),

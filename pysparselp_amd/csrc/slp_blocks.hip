@@ -346,7 +346,9 @@ static void blk_cg(slp_blocks *s, Apply apply, i64 len = -1, double *sol = nullp
     }
 }
 
-static void rb_iteration(slp_blocks *s) {
+// One block's share of an iteration up to the exchange: its projection (matrix-free CG, no exchange inside), the
+// over-relaxed x, the slack update and the consensus summand acc_j = used_j ? x_j + lambda_j / gamma : 0.
+static void rb_project(slp_blocks *s) {
     hipStream_t st = ctx().stream;
     const i64 n = s->N, m = s->m, me = s->m_eq;
     const int gn = grid_for(n, kBlock), gm = grid_for(m, kBlock);
@@ -372,9 +374,6 @@ static void rb_iteration(slp_blocks *s) {
                            s->gamma, s->x.p, s->acc.p);
         hipLaunchKernelGGL(k_rb_slack, dim3(gm), dim3(kBlock), 0, st, m, (i64)0, s->w.p, s->zero_m.p, s->slo.p, s->shi.p, s->alpha,
                            1.0 - s->alpha, s->gamma, s->xs.p, s->xps.p, s->lams.p);
-        if (s->distributed) comm_allreduce_dev(s->acc.p, n, 0);
-        hipLaunchKernelGGL(k_rb_consensus, dim3(gn), dim3(kBlock), 0, st, n, s->used.p, s->copies.p, s->acc.p, s->c.p, s->lb.p, s->ub.p,
-                           s->x.p, s->gamma, s->xp.p, s->lam.p);
         SLP_HIP(hipGetLastError());
         return;
     }
@@ -393,10 +392,25 @@ static void rb_iteration(slp_blocks *s) {
     if (m > me)
         hipLaunchKernelGGL(k_rb_slack, dim3(grid_for(m - me, kBlock)), dim3(kBlock), 0, st, m, me, s->vs.p, s->nu.p, s->slo.p, s->shi.p,
                            s->alpha, 1.0 - s->alpha, s->gamma, s->xs.p, s->xps.p, s->lams.p);
-    if (s->distributed) comm_allreduce_dev(s->acc.p, n, 0);  // the consensus sum: the only exchange of an iteration
-    hipLaunchKernelGGL(k_rb_consensus, dim3(gn), dim3(kBlock), 0, st, n, s->used.p, s->copies.p, s->acc.p, s->c.p, s->lb.p, s->ub.p, s->x.p,
-                       s->gamma, s->xp.p, s->lam.p);
     SLP_HIP(hipGetLastError());
+}
+
+// ... and after it: xp = clamp((sum of the summands over every block of every rank - c / gamma) / copies), this block's lambda
+static void rb_consensus(slp_blocks *s, const double *acc_total) {
+    const i64 n = s->N;
+    hipLaunchKernelGGL(k_rb_consensus, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, s->used.p, s->copies.p, acc_total, s->c.p,
+                       s->lb.p, s->ub.p, s->x.p, s->gamma, s->xp.p, s->lam.p);
+    SLP_HIP(hipGetLastError());
+}
+
+static void rb_iteration(slp_blocks *s) {
+    rb_project(s);
+    if (s->distributed) comm_allreduce_dev(s->acc.p, s->N, 0);  // the consensus sum: the only exchange of an iteration
+    rb_consensus(s, s->acc.p);
+}
+
+__global__ void k_rb_accumulate(i64 n, const double *__restrict__ a, double *__restrict__ total) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) total[j] = total[j] + a[j];
 }
 
 static void blk_iteration(slp_blocks *s) {
@@ -531,6 +545,46 @@ int slp_blocks_iterate(slp_blocks *s, int64_t k) {
     SLP_API_INT({
         SLP_REQUIRE(s && k >= 0, "slp_blocks_iterate: bad arguments");
         for (i64 it = 0; it < k; ++it) blk_iteration(s);
+    })
+}
+
+// ---- several row blocks on one rank (ADMMBlocks.py's `blocks` metadata at scale) ---------------------------------------
+// Every block is its own slp_blocks over its own row-block matrix (slp_blocks_create_on): own copy of the variables it
+// uses, own multipliers, own projection.  One iteration of the group: every block's projection, the summands added in block
+// order, ONE all-reduce of n doubles for the whole group, the consensus update in every block.
+int slp_blocks_group_link(slp_blocks **blocks, int count) {
+    SLP_API_INT({
+        SLP_REQUIRE(blocks && count >= 1, "slp_blocks_group_link: bad arguments");
+        for (int g = 0; g < count; ++g) {
+            SLP_REQUIRE(blocks[g] && blocks[g]->row_block, "slp_blocks_group_link: blocks must come from slp_blocks_create_on");
+            SLP_REQUIRE(blocks[g]->N == blocks[0]->N && blocks[g]->gamma == blocks[0]->gamma, "slp_blocks_group_link: blocks differ in n / gamma");
+        }
+        // copies_j = number of blocks (of all ranks) that use variable j: each block holds its own count summed over the
+        // ranks (slp_blocks_create_on); the group total goes into every block
+        const i64 n = blocks[0]->N;
+        DevBuf<double> total((size_t)n);
+        total.zero();
+        for (int g = 0; g < count; ++g)
+            hipLaunchKernelGGL(k_rb_accumulate, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, blocks[g]->copies.p, total.p);
+        SLP_HIP(hipGetLastError());
+        for (int g = 0; g < count; ++g) blocks[g]->copies.copy_from(total);
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+    })
+}
+
+int slp_blocks_group_iterate(slp_blocks **blocks, int count, int64_t k) {
+    SLP_API_INT({
+        SLP_REQUIRE(blocks && count >= 1 && k >= 0, "slp_blocks_group_iterate: bad arguments");
+        slp_blocks *s0 = blocks[0];
+        const i64 n = s0->N;
+        for (i64 it = 0; it < k; ++it) {
+            for (int g = 0; g < count; ++g) rb_project(blocks[g]);
+            for (int g = 1; g < count; ++g)  // fixed order: deterministic sums
+                hipLaunchKernelGGL(k_rb_accumulate, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, blocks[g]->acc.p, s0->acc.p);
+            SLP_HIP(hipGetLastError());
+            if (s0->distributed) comm_allreduce_dev(s0->acc.p, n, 0);
+            for (int g = 0; g < count; ++g) rb_consensus(blocks[g], s0->acc.p);
+        }
     })
 }
 

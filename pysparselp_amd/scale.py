@@ -180,3 +180,55 @@ class DeviceBlocks:
 
     def describe(self):
         return "block-splitting ADMM (ADMMBlocks.py), one block per rank, matrix-free per-block projections (CG), gamma=0.7, alpha=1.95"
+
+
+class DeviceBlocksGroup:
+    """Block-splitting ADMM with SEVERAL row blocks on this rank (the ``blocks`` metadata of the reference,
+    ADMMBlocks.py:93-95,178-243, at scale): block g = rows ``cuts[g] .. cuts[g + 1]`` of the DeviceMatrix ``a`` (cut on the
+    device, ``slp_matrix_gather_rows``), each with its own copy of the variables it uses, its own multipliers and its own
+    matrix-free projection; one all-reduce of n doubles per iteration for the whole group (``slp_blocks_group_iterate``).
+    All rows are inequalities ``b_lower <= a_i x <= b_upper`` (equality rows: give ``m_eq`` leading rows of block 0)."""
+
+    def __init__(self, a, cuts, b_upper, c, lb, ub, gamma=0.7, b_lower=None, m_eq=0, cg_tol=1e-13, cg_max_steps=500):
+        import ctypes
+
+        self._l = _lib.lib()
+        self.n = a.shape[1]
+        self.c = _lib.f64(c)
+        cuts = [int(v) for v in cuts]
+        assert cuts[0] == 0 and cuts[-1] == a.shape[0] and all(x <= y for x, y in zip(cuts, cuts[1:]))
+        assert 0 <= m_eq <= cuts[1]
+        b_upper = _lib.f64(b_upper)
+        b_lower = None if b_lower is None else _lib.f64(b_lower)
+        self.blocks, self._mats = [], []
+        for g, (r0, r1) in enumerate(zip(cuts, cuts[1:])):
+            mat = a.gather_rows(np.arange(r0, r1, dtype=np.int64))
+            self._mats.append(mat)
+            self.blocks.append(DeviceBlocks(mat, b_upper[r0:r1], c, lb, ub, gamma=gamma, m_eq=m_eq if g == 0 else 0,
+                                            b_lower=None if b_lower is None else b_lower[r0:r1], cg_tol=cg_tol, cg_max_steps=cg_max_steps))
+        self._handles = (ctypes.c_void_p * len(self.blocks))(*[blk._h for blk in self.blocks])
+        _lib.check(self._l.slp_blocks_group_link(self._handles, len(self.blocks)))
+
+    def close(self):
+        for blk in getattr(self, "blocks", []):
+            blk.close()
+        for mat in getattr(self, "_mats", []):
+            mat.close()
+        self.blocks, self._mats = [], []
+
+    __del__ = close
+
+    def iterate(self, k):
+        _lib.check(self._l.slp_blocks_group_iterate(self._handles, len(self.blocks), int(k)))
+
+    def x(self):
+        return self.blocks[0].x()
+
+    def objective(self):
+        return float(self.c.dot(self.x()))
+
+    def cg_steps(self):
+        return sum(blk.cg_steps() for blk in self.blocks)
+
+    def describe(self):
+        return f"block-splitting ADMM (ADMMBlocks.py), {len(self.blocks)} row blocks on this rank, matrix-free per-block projections (CG)"

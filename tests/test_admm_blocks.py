@@ -140,3 +140,34 @@ def test_gpu_row_block_solver_matches_oracle(monkeypatch, min_nnz, m_eq):
         assert np.max(np.abs(sol.x() - x) / (1 + np.abs(x))) < 1e-9
         sol.close()
     a.close()
+
+
+@pytest.mark.gpu
+def test_several_row_blocks_on_one_rank_match_the_reference_block_decomposition():
+    """DeviceBlocksGroup: three uneven row blocks of a device-resident LP, each its own copy of the variables; against the
+    oracle's restatement of lp_admm_block_decomposition (sparse LU per block) with the same row ranges as blocks."""
+    from oracle import oracle
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceBlocks, DeviceBlocksGroup
+
+    n, m = 800, 1500
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, 0.01, seed=9)
+    s = a.download()
+    cuts = [0, 400, 1100, 1500]
+    grp = DeviceBlocksGroup(a, cuts, b, c, lb, ub)
+    grp.iterate(40)
+    x_grp = grp.x()
+    assert grp.cg_steps() > 0
+    grp.close()
+    x_ref = oracle.lp_admm_block_decomposition(c, None, None, s, None, b, lb, ub, nb_iter=39, nb_iter_plot=10 ** 9, blocks_eq=[],
+                                               blocks_ineq=[(lo, hi - 1) for lo, hi in zip(cuts, cuts[1:])])
+    assert np.max(np.abs(x_grp - x_ref) / (1 + np.abs(x_ref))) < 1e-8
+    # a group of one block is the single-block solver
+    one = DeviceBlocksGroup(a, [0, m], b, c, lb, ub)
+    one.iterate(10)
+    single = DeviceBlocks(a, b, c, lb, ub)
+    single.iterate(10)
+    assert np.array_equal(one.x(), single.x())
+    one.close()
+    single.close()
+    a.close()
