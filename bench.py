@@ -76,6 +76,7 @@ def parse():
     p.add_argument("--eq-frac", type=float, default=0.0,
                    help="fraction of the constraint rows turned into equalities a_i x = a_i x_feasible (randomLP.py:62-68); "
                         "the default all-inequality LP is the primary workload")
+    p.add_argument("--blocks-per-rank", type=int, default=1, help="admm_blocks: row blocks on every rank (DeviceBlocksGroup)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-general", action="store_true", help="skip the general (fp64 strip entries) block")
     p.add_argument("--keep-csr", dest="release_csr", action="store_false",
@@ -263,13 +264,13 @@ def main():
         m_eq_local = max(0, min(rows, m_eq_global - r0))
         if m_eq_local:
             b[:m_eq_local] = a.matvec(xf)[:m_eq_local]
-    solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local)
+    solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local, blocks_per_rank=args.blocks_per_rank)
     _lib.check(lib.slp_synchronize())
     t_gen = time.perf_counter() - t_gen
     # Steady state keeps only what the iteration reads: when both orientations run on strip copies, the two CSR copies
     # (48 GB at config 3) are dropped and the cached temporaries of the setup returned to the driver.
     mem = {"in_use_after_setup_gb": device_memory_in_use(lib)}
-    released = args.release_csr and a.spmv_kernel(False) >= 1 and a.spmv_kernel(True) >= 1
+    released = args.release_csr and args.blocks_per_rank == 1 and a.spmv_kernel(False) >= 1 and a.spmv_kernel(True) >= 1
     if released:
         a.release_csr()
     _lib.check(lib.slp_trim())

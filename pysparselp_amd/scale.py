@@ -117,7 +117,7 @@ class DeviceCP:
         return "diagonally preconditioned Chambolle-Pock, alpha=1, theta=1"
 
 
-def make_solver(method, a, b_upper, c, lb, ub, m_eq=0):
+def make_solver(method, a, b_upper, c, lb, ub, m_eq=0, blocks_per_rank=1):
     """``b_upper[:m_eq]`` are equality right-hand sides (the first ``m_eq`` rows), the rest upper bounds."""
     if method == "chambolle_pock_ppd":
         return DeviceCP(a, b_upper, c, lb, ub, m_eq=m_eq)
@@ -126,6 +126,10 @@ def make_solver(method, a, b_upper, c, lb, ub, m_eq=0):
 
         return DeviceADMM(a, b_upper, c, lb, ub, m_eq=m_eq)
     if method == "admm_blocks":
+        if blocks_per_rank > 1:
+            rows = a.shape[0]
+            cuts = [rows * g // blocks_per_rank for g in range(blocks_per_rank + 1)]
+            return DeviceBlocksGroup(a, cuts, b_upper, c, lb, ub, m_eq=m_eq)
         return DeviceBlocks(a, b_upper, c, lb, ub, m_eq=m_eq)
     raise ValueError(method)
 
@@ -229,6 +233,9 @@ class DeviceBlocksGroup:
 
     def cg_steps(self):
         return sum(blk.cg_steps() for blk in self.blocks)
+
+    def matrix_passes_per_iteration(self):
+        return None
 
     def describe(self):
         return f"block-splitting ADMM (ADMMBlocks.py), {len(self.blocks)} row blocks on this rank, matrix-free per-block projections (CG)"
