@@ -172,6 +172,8 @@ void launch_spmv(const CsrDev &a, const double *x, double *y, int order) {
     SLP_HIP(hipGetLastError());
 }
 
+bool comm_active();  // slp_comm.hip
+
 const StripJds *fast_format(slp_matrix *m, bool transposed) {
     if (transposed) build_transpose(m);
     const CsrDev &a = transposed ? m->at : m->a;
@@ -183,10 +185,16 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
         if (m->format_policy == 2) return nullptr;  // CSR kernels only
         // few distinct stored values (rounded coefficients, +-1 patterns): 4-byte entries, values looked up in LDS
         // quads (4096-row blocks, 3-byte entries) when that still leaves enough row blocks to fill the chip without
-        // splitting strips (a split changes the association of the row sums); else pairs.  SLP_DICT_VARIANT=1|2 forces.
+        // splitting strips -- a split changes the association of the row sums, and on one GPU every product is the
+        // sequential CSR sum bit for bit -- else pairs.  Measured at config 3 for A^T (245 quad blocks): quads with the
+        // strips split over two workgroups 1.92 ms, pairs unsplit 2.18 ms, quads unsplit (half the chip) 3.02 ms.  With the
+        // rows partitioned over several GPUs the partial sums are re-associated by the all-reduce anyway: quads always
+        // (10-13 % faster per iteration on the row blocks of 2 / 4 / 8 ranks, tools/variant_rule.py).
+        // SLP_DICT_VARIANT=1|2 forces a geometry.
         const char *ev = getenv("SLP_DICT_VARIANT");
-        int variant = (a.nrow + 4095) / 4096 >= 384 ? 2 : 1;
+        int variant = ((a.nrow + 4095) / 4096 >= 384 || comm_active()) ? 2 : 1;
         if (ev && (ev[0] == '1' || ev[0] == '2')) variant = ev[0] - '0';
+        else if (variant == 2 && !strip_wanted(a, 2) && strip_wanted(a, 1)) variant = 1;  // too sparse for the narrower quad strips
         const bool dict = strip_wanted(a, variant) && matrix_dictionary(m);
         if (dict) strip_build(a, f, &m->vdict, variant);
         else if (strip_wanted(a, 0)) strip_build(a, f, nullptr, 0);

@@ -556,8 +556,11 @@ typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
 
 // ABL != 0 exists only in the -DSLP_ABLATION build (tools/ablate_quads.py; WRONG results): 1 = no value-table lookup,
 // 2 = no LDS gathers at all, 3 = no entry loads (synthetic entries from registers)
+#ifndef SLP_QUAD_WAVES
+#define SLP_QUAD_WAVES 8  // waves per SIMD the single-vector quad kernel is compiled for (8: two workgroups per CU, 64 VGPRs)
+#endif
 template <int NV, bool NT = false, int ABL = 0>
-__global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_qstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
+__global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                                          const unsigned short *__restrict__ perm,
                                                                          const unsigned char *__restrict__ slen,
                                                                          const unsigned int *__restrict__ soff,
