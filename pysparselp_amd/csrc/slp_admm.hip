@@ -691,6 +691,7 @@ static void admm_finish_create(slp_admm *s, const int64_t *m_indptr, const int32
     s->lanes_rows = lanes_for(s->a->a, s->order);
     s->lanes_cols = lanes_for(s->a->at, s->order);
     if (m_indptr) {
+        Phase ph("gs_plan (host level schedule)");
         gs_plan(s->plan, N, m_indptr, m_indices, m_data);
     } else {
         // M = gamma_eq A^T A + gamma_ineq I formed on the device (slp_spgemm.hip, SMMP accumulation order); the
@@ -704,6 +705,7 @@ static void admm_finish_create(slp_admm *s, const int64_t *m_indptr, const int32
             mm->a.ptr.download(mp.data(), mp.size());
             mm->a.idx.download(mj.data(), mj.size());
             mm->a.val.download(mx.data(), mx.size());
+            Phase ph("gs_plan (host level schedule)");
             gs_plan(s->plan, N, mp.data(), mj.data(), mx.data());
         } catch (...) { delete mm; throw; }
         delete mm;
@@ -759,6 +761,7 @@ slp_admm *slp_admm_create_lp(int64_t n, int64_t m_eq, const int64_t *eq_indptr, 
         SLP_REQUIRE(in_indptr, "slp_admm_create_lp: the inequality block is required (the reference's standard form is undefined "
                                "without it, tools.py:92)");
         SLP_REQUIRE(m_eq == 0 || (eq_indptr && b_eq), "slp_admm_create_lp: NULL equality block");
+        Phase ph("slp_admm_create_lp (total)");
         hipStream_t st = ctx().stream;
         auto *s = new slp_admm();
         slp_matrix *ae = nullptr, *ai = nullptr, *ae2 = nullptr, *ai2 = nullptr, *a2 = nullptr;
