@@ -98,10 +98,6 @@ def spmv_bytes(nnz, rows, cols):
     return 12 * nnz + 8 * (rows + 1) + 8 * cols + 8 * rows
 
 
-def cp_iter_bytes(nnz, m, n):
-    return 24 * nnz + 8 * (m + 1) + 8 * (n + 1) + 8 * (8 * n + 5 * m)
-
-
 def pmc_traffic(kernel_id, shape):
     """(HBM bytes per launch from the committed rocprofv3 PMC summary of this workload, its path) or (None, None)."""
     if kernel_id not in PMC_FILES or shape != (1_000_000, 2_000_000, 1e-3):
