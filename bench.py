@@ -37,6 +37,9 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# multi-process GPU work on this platform: the host driver only supports dmabuf IPC (RCCL's intra-node transport needs it);
+# must be in the environment before the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # the HIP library first: bench never needs torch on one GPU
 from pysparselp_amd import _lib  # noqa: E402

@@ -213,6 +213,7 @@ def init_comm_from_env(rank=None, world=None):
     global _host_transport
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL's intra-node transport needs on this platform
     lib = _lib.lib()
     if os.environ.get("SLP_COMM_TRANSPORT") == "host":
         _host_transport = HostTcpAllreduce(rank, world)
