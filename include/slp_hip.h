@@ -289,8 +289,10 @@ slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lo
 /* Several row blocks on one rank (the `blocks` metadata of ADMMBlocks.py at scale): each block its own slp_blocks from
  * slp_blocks_create_on over its own row-block matrix (same n, same gamma; under slp_comm_init every rank creates the
  * same number of blocks).  slp_blocks_group_link once after creating them (the per-variable copy counts become the
- * group's), then slp_blocks_group_iterate: every block's projection, ONE all-reduce of n doubles for the group, the
- * consensus update in every block.  slp_blocks_get_xp of any member returns the consensus variable. */
+ * group's), then slp_blocks_group_iterate: every block's projection -- under slp_comm_init each block's consensus summand
+ * is all-reduced on a second stream while the next block's projection computes (count all-reduces of n doubles per
+ * iteration, all but the last overlapped) -- and the consensus update in every block.  slp_blocks_get_xp of any member
+ * returns the consensus variable. */
 int slp_blocks_group_link(slp_blocks **blocks, int count);
 int slp_blocks_group_iterate(slp_blocks **blocks, int count, int64_t k);
 void slp_blocks_destroy(slp_blocks *s);

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(kBlock) void k_blk_energy(i64 P, const i32 *__restr
 // S nu = A (A^T nu) + nu  on inequality rows.  The only exchange is the consensus sum over the ranks (n doubles).
 bool comm_active();
 void comm_allreduce_dev(double *buf, i64 count, int op);
+void comm_allreduce_dev_async(double *buf, i64 count, int op);
+void comm_join();
 
 // v = xp - lambda / gamma  (original part)
 __global__ void k_rb_v(i64 n, const double *__restrict__ xp, const double *__restrict__ lam, double gamma, double *__restrict__ v) {
@@ -550,8 +552,10 @@ int slp_blocks_iterate(slp_blocks *s, int64_t k) {
 
 // ---- several row blocks on one rank (ADMMBlocks.py's `blocks` metadata at scale) ---------------------------------------
 // Every block is its own slp_blocks over its own row-block matrix (slp_blocks_create_on): own copy of the variables it
-// uses, own multipliers, own projection.  One iteration of the group: every block's projection, the summands added in block
-// order, ONE all-reduce of n doubles for the whole group, the consensus update in every block.
+// uses, own multipliers, own projection.  One iteration of the group: every block's projection; with the rows partitioned
+// over several ranks each block's summand is all-reduced on a second stream WHILE the next block's projection computes
+// (asynchronous block updates overlapped with the exchange: G all-reduces of n doubles, all but the last hidden); the
+// reduced summands added in block order; the consensus update in every block.
 int slp_blocks_group_link(slp_blocks **blocks, int count) {
     SLP_API_INT({
         SLP_REQUIRE(blocks && count >= 1, "slp_blocks_group_link: bad arguments");
@@ -578,11 +582,19 @@ int slp_blocks_group_iterate(slp_blocks **blocks, int count, int64_t k) {
         slp_blocks *s0 = blocks[0];
         const i64 n = s0->N;
         for (i64 it = 0; it < k; ++it) {
-            for (int g = 0; g < count; ++g) rb_project(blocks[g]);
+            // Asynchronous block updates: as soon as a block's summand exists its all-reduce starts on the second stream and
+            // travels over xGMI while the NEXT block's projection computes; only the last block's exchange is exposed.
+            // (One rank, or one block: a single all-reduce of the sum, as before.)
+            const bool overlap = s0->distributed && count > 1;
+            for (int g = 0; g < count; ++g) {
+                rb_project(blocks[g]);
+                if (overlap) comm_allreduce_dev_async(blocks[g]->acc.p, n, 0);
+            }
+            if (overlap) comm_join();
             for (int g = 1; g < count; ++g)  // fixed order: deterministic sums
                 hipLaunchKernelGGL(k_rb_accumulate, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, blocks[g]->acc.p, s0->acc.p);
             SLP_HIP(hipGetLastError());
-            if (s0->distributed) comm_allreduce_dev(s0->acc.p, n, 0);
+            if (s0->distributed && !overlap) comm_allreduce_dev(s0->acc.p, n, 0);
             for (int g = 0; g < count; ++g) rb_consensus(blocks[g], s0->acc.p);
         }
     })

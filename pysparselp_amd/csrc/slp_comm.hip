@@ -12,7 +12,10 @@
 // over the fully connected node; it is issued on the library's compute stream,
 // in order with the kernels around it -- every all-reduce's result is consumed
 // by the very next kernel of the iteration, so there is no rank-local pass to
-// overlap it with.
+// overlap it with.  The exception is the block-splitting
+// ADMM with several blocks per rank: a block's consensus summand is all-reduced
+// on a second stream while the next block's projection computes
+// (comm_allreduce_dev_async / comm_join).
 //
 // Transport 2 (tests): a host callback (slp_comm_init_host).  The device buffer
 // is copied to the host, the callback reduces it in place across the ranks --
@@ -45,7 +48,19 @@ static struct {
     int nranks = 1, rank = 0;
     long long collectives = 0;  // all-reduces issued since slp_comm_init* (slp_comm_collectives)
     DevBuf<double> scratch;
+    // asynchronous all-reduces (block groups): a second stream, ordered against the compute stream by events
+    hipStream_t side = nullptr;
+    hipEvent_t ready[8] = {}, done = nullptr;
+    unsigned next_ready = 0;
+    bool pending = false;
 } g;
+
+static void side_stream() {
+    if (g.side) return;
+    SLP_HIP(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
+    for (auto &e : g.ready) SLP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    SLP_HIP(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+}
 
 static void load_rccl() {
     if (g.lib) return;
@@ -99,6 +114,33 @@ void comm_allreduce_dev(double *buf, i64 count, int op) {
     check(g.all_reduce(buf, buf, (size_t)count, ncclFloat64, op == 1 ? ncclMax : ncclSum, g.comm, st), "ncclAllReduce");
 }
 
+// The same all-reduce, but on the library's second stream: it starts once everything enqueued so far on the compute stream
+// has finished and runs beside whatever the compute stream is given next (the projection of the next block of a group);
+// comm_join() makes the compute stream wait for every asynchronous all-reduce issued so far.  The host transport (tests)
+// has no asynchronous form: it reduces at once.
+void comm_allreduce_dev_async(double *buf, i64 count, int op) {
+    SLP_REQUIRE(g.active, "slp_comm_init has not been called");
+    if (count <= 0) return;
+    if (g.host_fn) {
+        comm_allreduce_dev(buf, count, op);
+        return;
+    }
+    ++g.collectives;
+    side_stream();
+    hipEvent_t ev = g.ready[g.next_ready++ % 8];
+    SLP_HIP(hipEventRecord(ev, ctx().stream));
+    SLP_HIP(hipStreamWaitEvent(g.side, ev, 0));
+    check(g.all_reduce(buf, buf, (size_t)count, ncclFloat64, op == 1 ? ncclMax : ncclSum, g.comm, g.side), "ncclAllReduce");
+    g.pending = true;
+}
+
+void comm_join() {
+    if (!g.pending) return;
+    SLP_HIP(hipEventRecord(g.done, g.side));
+    SLP_HIP(hipStreamWaitEvent(ctx().stream, g.done, 0));
+    g.pending = false;
+}
+
 }  // namespace slp
 
 using namespace slp;
@@ -150,6 +192,7 @@ int slp_comm_init_host(int nranks, int rank, slp_host_allreduce_fn fn, void *use
 int slp_comm_finalize(void) {
     SLP_API_INT({
         if (g.active) {
+            if (g.side) SLP_HIP(hipStreamSynchronize(g.side));
             SLP_HIP(hipStreamSynchronize(ctx().stream));
             g.scratch.release();
             if (g.comm) check(g.comm_destroy(g.comm), "ncclCommDestroy");

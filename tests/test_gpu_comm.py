@@ -22,7 +22,7 @@ os.environ["SLP_FORCE_DISTRIBUTED"] = "1"
 os.environ["SLP_STRIP_MIN_NNZ"] = %(min_nnz)r
 from pysparselp_amd import _lib
 from pysparselp_amd.problems import random_lp_on_device
-from pysparselp_amd.scale import DeviceBlocks, DeviceCP
+from pysparselp_amd.scale import DeviceBlocks, DeviceBlocksGroup, DeviceCP
 from pysparselp_amd.admm_cg import DeviceADMM
 lib = _lib.lib(0)
 n, m, p = 30000, 40000, 0.001
@@ -31,9 +31,12 @@ def run():
     a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=3)
     cp = DeviceCP(a, b, c, lb, ub); cp.iterate(30); x_cp = cp.x(); cp.close()
     blk = DeviceBlocks(a, b, c, lb, ub, cg_max_steps=40); blk.iterate(4); x_blk = blk.x(); e_blk = blk.report()[0]; blk.close()
+    # three row blocks on this rank: under the communicator every block's summand is all-reduced on the second stream while
+    # the next block's projection computes (asynchronous block updates)
+    grp = DeviceBlocksGroup(a, [0, 15000, 27000, m], b, c, lb, ub, cg_max_steps=40); grp.iterate(4); x_grp = grp.x(); grp.close()
     admm = DeviceADMM(a, b, c, lb, ub); admm.iterate(15); x_admm = admm.x(n); rep = admm.report(); admm.close()
     a.close()
-    return x_cp, x_admm, rep, x_blk, e_blk
+    return x_cp, x_admm, rep, x_blk, e_blk, x_grp
 
 plain = run()                                   # no communicator yet: single-GPU code path
 uid = ctypes.create_string_buffer(128)
@@ -51,6 +54,7 @@ assert np.max(np.abs(plain[1] - part[1]) / (1 + np.abs(plain[1]))) < 1e-12
 assert np.allclose(plain[2], part[2], rtol=1e-10)
 assert np.max(np.abs(plain[3] - part[3]) / (1 + np.abs(plain[3]))) < 1e-12   # block-splitting ADMM, consensus all-reduce
 assert abs(plain[4] - part[4]) <= 1e-10 * (1 + abs(plain[4]))
+assert np.array_equal(plain[5], part[5])                                     # one rank: the per-block all-reduces are identities
 print("COMM-OK")
 """
 
@@ -109,6 +113,11 @@ blk = DeviceBlocks(a, b, c, lb, ub, cg_max_steps=30)
 got = per_iteration(blk, 1, 3)
 assert got == [(n, 0)] * 3, got                           # block splitting: ONE consensus all-reduce, none inside the block CG
 blk.close()
+from pysparselp_amd.scale import DeviceBlocksGroup
+grp = DeviceBlocksGroup(a, [0, 10000, 25000, m], b, c, lb, ub, cg_max_steps=30)
+got = per_iteration(grp, 1, 3)
+assert got == [(n, 0)] * 9, got                           # three blocks on the rank: one (overlapped) all-reduce per block
+grp.close()
 a.close()
 _lib.check(lib.slp_comm_finalize())
 print("RECORD-OK")
