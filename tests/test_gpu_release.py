@@ -51,3 +51,39 @@ def test_release_needs_strip_copies_in_both_orientations():
     with pytest.raises(_lib.SlpError, match="only copy"):
         a.release_csr()
     a.close()
+
+
+def test_matrix_guards_raise_clear_errors():
+    """bad CSR input is an error at the boundary, not an out-of-bounds device access; a matrix that was
+    row-normalised in place is not scaled twice; derived copies are not pulled from under a live solver."""
+    import scipy.sparse
+
+    from pysparselp_amd import _lib
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.device import DeviceMatrix
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    l = _lib.lib()
+    indptr = np.array([0, 2, 4], dtype=np.int64)
+    data = np.ones(4)
+    for bad_idx, what in ((np.array([0, 5, 1, 2], dtype=np.int32), "out of range"), (np.array([0, -1, 1, 2], dtype=np.int32), "out of range")):
+        h = l.slp_matrix_create(2, 3, _lib.ptr(indptr), _lib.ptr(bad_idx), _lib.ptr(data))
+        assert not h and what in _lib.last_error()
+    bad_ptr = np.array([0, 3, 2], dtype=np.int64)
+    h = l.slp_matrix_create(2, 3, _lib.ptr(bad_ptr), _lib.ptr(np.zeros(2, dtype=np.int32)), _lib.ptr(np.ones(2)))
+    assert not h and "non-decreasing" in _lib.last_error()
+
+    a, xf, c, lb, ub, b = random_lp_on_device(2000, 3000, 0.01, seed=2)   # CSR kernels, no dictionary strips: scaling in place
+    cp = DeviceCP(a, b, c, lb, ub)
+    with pytest.raises(_lib.SlpError, match="still alive"):
+        a.set_format(1)                       # would free copies the live solver points into
+    with pytest.raises(_lib.SlpError, match="still alive"):
+        DeviceADMM(a, b, c, lb, ub)           # in-place row normalisation under a live solver
+    cp.close()
+    s1 = DeviceADMM(a, b, c, lb, ub)
+    s1.iterate(3)
+    s1.close()
+    with pytest.raises(_lib.SlpError, match="already row-normalised"):
+        DeviceADMM(a, b, c, lb, ub)           # the matrix now holds scaled values: scaling again would solve another LP
+    a.close()
