@@ -497,8 +497,9 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
         if (t + 1 < t_end) prefetch(t + 1);
         double a0 = acc[0][r.x], a1 = acc[0][r.y], b0 = 0.0, b1 = 0.0;
         if (NV == 2) { b0 = acc[NV - 1][r.x]; b1 = acc[NV - 1][r.y]; }
-        // (A branch-free form of this step -- all four gathers issued together, selects instead of branches, as in
-        // k_qstrip_spmv -- measured SLOWER here: 2.43 against 2.23 ms for A^T y at config 3.)
+        // (Measured SLOWER here, A^T y at config 3, 2.16-2.23 ms as written: a branch-free form of this step -- all four
+        // gathers issued together, selects instead of branches, as in k_qstrip_spmv -- 2.43 ms; row 0 by select under a
+        // wave-uniform guard, row 1 by branch 2.28; 6 / 10 / 12 pair loads in flight instead of 8: 2.38 / 2.53 / 3.04.)
 #define SLP_DSTRIP_STEP(q, live1)                                                   \
     {                                                                               \
         const double w0 = dv[(q).x & 0xffffu];                                      \
