@@ -223,8 +223,13 @@ int slp_admm_bench(slp_admm *s, int64_t k, double *ms);
  * problem of ADMM.py:76-91 (any mix of equalities and inequalities).
  * slp_admm_cg_create_on: all-inequality LP  A_ineq x <= b_upper  whose matrix is
  * already resident; row normalisation and the slack standard form
- * [A' -I] (tools.py:272-290, :88-127) are applied ON THE DEVICE, scaling the
- * matrix values in place (a_ineq is modified and must outlive the solver).
+ * [A' -I] (tools.py:272-290, :88-127) are applied ON THE DEVICE.  When the
+ * matrix runs on value-dictionary strips the two row scalings are kept as a
+ * vector and the matrix is left untouched (any number of solvers may share it);
+ * otherwise its values are scaled IN PLACE, once: a second ADMM set-up on the
+ * same matrix, or one while another solver created on it is alive, fails with
+ * an error instead of silently solving another problem.  a_ineq must outlive
+ * the solver.
  * With slp_comm_init active the rows (and their slack variables) are this
  * rank's block; the n original variables are replicated. */
 typedef struct slp_admm_cg slp_admm_cg;
