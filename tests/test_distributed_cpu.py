@@ -263,3 +263,46 @@ def test_row_partitioned_solvers_match_single_process_oracle():
     for r in range(world):
         assert np.max(np.abs(results[r]["blocks_x"] - x_ref) / (1 + np.abs(x_ref))) < 1e-9
     assert np.array_equal(results[0]["blocks_x"], results[1]["blocks_x"])
+
+
+def _tcp_rank(rank, world, port, q):
+    import ctypes
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from pysparselp_amd.parallel import HostTcpAllreduce
+
+    t = HostTcpAllreduce(rank, world)
+    buf = np.arange(5, dtype=np.float64) * (rank + 1) + 0.25 * rank
+    big = np.full(300_000, float(rank + 1))                      # larger than a socket buffer: no deadlock in the exchange
+    out = []
+    for arr, op in ((buf.copy(), 0), (buf.copy(), 1), (big, 0)):
+        rc = t._allreduce(arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), arr.size, op, None)
+        assert rc == 0
+        out.append(arr)
+    t.close()
+    q.put((rank, out))
+
+
+@pytest.mark.timeout(120)
+def test_host_tcp_transport_reduces_identically_on_every_rank():
+    """parallel.HostTcpAllreduce (the transport behind SLP_COMM_TRANSPORT=host): rank-ordered sums through rank 0, the same
+    bits on every rank, sum and max, buffers larger than a socket buffer."""
+    import multiprocessing as mp
+
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tcp_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    base = np.arange(5, dtype=np.float64)
+    want_sum = sum(base * (r + 1) + 0.25 * r for r in range(world))
+    want_max = np.maximum.reduce([base * (r + 1) + 0.25 * r for r in range(world)])
+    for r in range(world):
+        assert np.array_equal(res[r][0], want_sum) and np.array_equal(res[r][1], want_max)
+        assert np.array_equal(res[r][2], np.full(300_000, 6.0))
