@@ -80,6 +80,7 @@ def parse():
                    help="fraction of the constraint rows turned into equalities a_i x = a_i x_feasible (randomLP.py:62-68); "
                         "the default all-inequality LP is the primary workload")
     p.add_argument("--blocks-per-rank", type=int, default=1, help="admm_blocks: row blocks on every rank (DeviceBlocksGroup)")
+    p.add_argument("--jacobi", action="store_true", help="admm_blocks: Jacobi-preconditioned conjugate gradients (slp_blocks_set_precond)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-general", action="store_true", help="skip the general (fp64 strip entries) block")
     p.add_argument("--keep-csr", dest="release_csr", action="store_false",
@@ -263,7 +264,7 @@ def main():
         m_eq_local = max(0, min(rows, m_eq_global - r0))
         if m_eq_local:
             b[:m_eq_local] = a.matvec(xf)[:m_eq_local]
-    solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local, blocks_per_rank=args.blocks_per_rank)
+    solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local, blocks_per_rank=args.blocks_per_rank, jacobi=args.jacobi)
     _lib.check(lib.slp_synchronize())
     t_gen = time.perf_counter() - t_gen
     # Steady state keeps only what the iteration reads: when both orientations run on strip copies, the two CSR copies
@@ -345,6 +346,8 @@ def main():
                 "n": args.n, "m": args.m, "density": args.density, "seed": args.seed, "nnz": nnz_total, "eq_frac": args.eq_frac,
                 "method": args.method, "matrix_passes_per_iteration": passes,
                 "collectives_per_iteration": (coll / args.steps) if distributed else 0,
+                **({"cg_steps_per_iteration": (solver.cg_steps() - cg0) / args.steps, "jacobi": bool(args.jacobi)}
+                   if args.method == "admm_blocks" else {}),
             },
             "roofline": roofline,
             "objective_after_run": obj,

@@ -302,6 +302,10 @@ int slp_blocks_group_link(slp_blocks **blocks, int count);
 int slp_blocks_group_iterate(slp_blocks **blocks, int count, int64_t k);
 void slp_blocks_destroy(slp_blocks *s);
 int slp_blocks_set_cg(slp_blocks *s, double tol, int max_steps);
+/* Jacobi (diagonal) preconditioner for the per-block conjugate gradients of a solver from slp_blocks_create_on
+ * (1 = on).  Same projection up to the CG tolerance; measured: no fewer steps on the benchmark LPs, whose systems have an
+ * essentially constant diagonal -- an option for badly scaled constraint matrices. */
+int slp_blocks_set_precond(slp_blocks *s, int jacobi);
 int slp_blocks_iterate(slp_blocks *s, int64_t k);
 /* out[0] = the augmented-Lagrangian energy of ADMMBlocks.py:246-253, out[1] = CG steps taken so far. */
 int slp_blocks_report(slp_blocks *s, double out[2]);

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "slp_blocks_group_iterate": (c_int, [c_vp, c_int, c_i64]),
     "slp_blocks_destroy": (None, [c_vp]),
     "slp_blocks_set_cg": (c_int, [c_vp, c_dbl, c_int]),
+    "slp_blocks_set_precond": (c_int, [c_vp, c_int]),
     "slp_blocks_iterate": (c_int, [c_vp, c_i64]),
     "slp_blocks_report": (c_int, [c_vp, c_vp]),
     "slp_blocks_cg_steps": (c_i64, [c_vp]),

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void k_blk_dot(i64 n, const double *__restr
 // scal[slot] = sum of the partials; then the CG scalars that depend on it:
 //   mode 1 (slot = PQ): alpha = rs / pq            (0 when the residual is already 0)
 //   mode 2 (slot = RSNEW): beta = rsnew / rs ; rs = rsnew
-enum { B_RS = 0, B_PQ = 1, B_RSNEW = 2, B_ALPHA = 3, B_BETA = 4, B_RHS2 = 5, B_COUNT = 8 };
+enum { B_RS = 0, B_PQ = 1, B_RSNEW = 2, B_ALPHA = 3, B_BETA = 4, B_RHS2 = 5, B_RR = 6, B_COUNT = 8 };
 __global__ __launch_bounds__(kBlock) void k_blk_finish(int nparts, const double *__restrict__ part, double *__restrict__ scal, int slot,
                                                        int mode) {
     __shared__ double lds[kBlock / kWave];
@@ -77,6 +77,22 @@ __global__ void k_blk_step(i64 m, const double *__restrict__ scal, const double 
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
         nu[i] = nu[i] + alpha * dir[i];
         r[i] = r[i] - alpha * q[i];
+    }
+}
+
+// Jacobi preconditioner (slp_blocks_set_precond): z = r / diag(S)
+__global__ void k_blk_precond(i64 m, const double *__restrict__ dinv, const double *__restrict__ r, double *__restrict__ z) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) z[i] = dinv[i] * r[i];
+}
+
+// 1 / diag(S): S = I + A^T A over the columns (rows of the transposed copy: 1 + sum a_ij^2), or A A^T (+ I on inequality
+// rows) over the rows
+__global__ void k_blk_diag(i64 rows, i64 first_identity, const i64 *__restrict__ ptr, const double *__restrict__ val, double base,
+                           double *__restrict__ dinv) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (i64)gridDim.x * blockDim.x) {
+        double s = (r >= first_identity) ? base : 0.0;
+        for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) s += val[k] * val[k];
+        dinv[r] = s > 0.0 ? 1.0 / s : 1.0;
     }
 }
 
@@ -303,6 +319,8 @@ struct slp_blocks {
     DevBuf<double> copies, acc, vs, xs, xps, lams, slo, shi;
     bool primal = false;      // projection solved in the primal form (I + A^T A), see k_rb_resid0_primal
     DevBuf<double> xsol, zero_m;
+    bool precond = false;     // Jacobi-preconditioned CG (slp_blocks_set_precond); dinv = 1 / diag(S), z = preconditioned residual
+    DevBuf<double> dinv, z;
 };
 
 namespace slp {
@@ -328,17 +346,32 @@ static void blk_cg(slp_blocks *s, Apply apply, i64 len = -1, double *sol = nullp
     if (!sol) sol = s->nu.p;
     const int gm = grid_for(m, kBlock);
     blk_dot(s, m, s->rhs.p, s->rhs.p, B_RHS2, 0);
-    blk_dot(s, m, s->r.p, s->r.p, B_RS, 0);
+    const bool pc = s->precond && s->dinv.n >= (size_t)m;
+    if (pc) {  // z = D^-1 r ; dir = z ; rs := r.z ; the stopping test keeps |r|^2 in its own slot
+        hipLaunchKernelGGL(k_blk_precond, dim3(gm), dim3(kBlock), 0, st, m, s->dinv.p, s->r.p, s->z.p);
+        SLP_HIP(hipMemcpyAsync(s->dir.p, s->z.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st));
+        blk_dot(s, m, s->r.p, s->z.p, B_RS, 0);
+        blk_dot(s, m, s->r.p, s->r.p, B_RR, 0);
+    } else {
+        blk_dot(s, m, s->r.p, s->r.p, B_RS, 0);
+    }
     double h[B_COUNT];
     for (int it = 0; it < s->max_cg;) {
         s->scal.download(h, B_COUNT);  // one 64-byte read every `check_every` steps
-        if (!(h[B_RS] > s->tol * s->tol * h[B_RHS2])) break;
+        if (!(h[pc ? B_RR : B_RS] > s->tol * s->tol * h[B_RHS2])) break;
         auto step = [&]() {
             apply(s->dir.p, s->q.p);
             blk_dot(s, m, s->dir.p, s->q.p, B_PQ, 1);
             hipLaunchKernelGGL(k_blk_step, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->dir.p, s->q.p, sol, s->r.p);
-            blk_dot(s, m, s->r.p, s->r.p, B_RSNEW, 2);
-            hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->r.p, s->dir.p);
+            if (pc) {
+                hipLaunchKernelGGL(k_blk_precond, dim3(gm), dim3(kBlock), 0, st, m, s->dinv.p, s->r.p, s->z.p);
+                blk_dot(s, m, s->r.p, s->z.p, B_RSNEW, 2);
+                blk_dot(s, m, s->r.p, s->r.p, B_RR, 0);
+                hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->z.p, s->dir.p);
+            } else {
+                blk_dot(s, m, s->r.p, s->r.p, B_RSNEW, 2);
+                hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->r.p, s->dir.p);
+            }
         };
         const int chunk = std::min(s->check_every, s->max_cg - it);
         if (s->a->a.nnz <= 20000000) s->cg_graph.run(chunk, s->check_every, step);  // all kernel arguments are fixed pointers
@@ -540,6 +573,25 @@ int slp_blocks_set_cg(slp_blocks *s, double tol, int max_steps) {
         SLP_REQUIRE(s && tol > 0.0 && max_steps > 0, "slp_blocks_set_cg: bad arguments");
         s->tol = tol;
         s->max_cg = max_steps;
+    })
+}
+
+int slp_blocks_set_precond(slp_blocks *s, int jacobi) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && s->row_block, "slp_blocks_set_precond: a solver from slp_blocks_create_on is required");
+        s->precond = jacobi != 0;
+        s->cg_graph.reset();
+        if (!s->precond) return 0;
+        const i64 len = s->primal ? s->N : s->m;
+        require_csr(s->a, "slp_blocks_set_precond");
+        s->dinv.alloc((size_t)len);
+        s->z.alloc((size_t)len);
+        const CsrDev &c = s->primal ? s->a->at : s->a->a;  // primal: 1 + column norms^2; dual: row norms^2 (+ 1 on inequality rows)
+        if (len)
+            hipLaunchKernelGGL(k_blk_diag, dim3(grid_for(len, kBlock)), dim3(kBlock), 0, ctx().stream, len, s->primal ? (i64)0 : s->m_eq,
+                               c.ptr.p, c.val.p, 1.0, s->dinv.p);
+        SLP_HIP(hipGetLastError());
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
     })
 }
 

@@ -117,7 +117,7 @@ class DeviceCP:
         return "diagonally preconditioned Chambolle-Pock, alpha=1, theta=1"
 
 
-def make_solver(method, a, b_upper, c, lb, ub, m_eq=0, blocks_per_rank=1):
+def make_solver(method, a, b_upper, c, lb, ub, m_eq=0, blocks_per_rank=1, jacobi=False):
     """``b_upper[:m_eq]`` are equality right-hand sides (the first ``m_eq`` rows), the rest upper bounds."""
     if method == "chambolle_pock_ppd":
         return DeviceCP(a, b_upper, c, lb, ub, m_eq=m_eq)
@@ -130,7 +130,7 @@ def make_solver(method, a, b_upper, c, lb, ub, m_eq=0, blocks_per_rank=1):
             rows = a.shape[0]
             cuts = [rows * g // blocks_per_rank for g in range(blocks_per_rank + 1)]
             return DeviceBlocksGroup(a, cuts, b_upper, c, lb, ub, m_eq=m_eq)
-        return DeviceBlocks(a, b_upper, c, lb, ub, m_eq=m_eq)
+        return DeviceBlocks(a, b_upper, c, lb, ub, m_eq=m_eq, jacobi=jacobi)
     raise ValueError(method)
 
 
@@ -140,7 +140,7 @@ class DeviceBlocks:
     ``b_lower <= a_i x <= b_upper``.  Per-block projections by conjugate gradients, no exchange inside them; one
     all-reduce of n doubles per iteration for the consensus."""
 
-    def __init__(self, a, b_upper, c, lb, ub, gamma=0.7, m_eq=0, b_lower=None, cg_tol=1e-13, cg_max_steps=500):
+    def __init__(self, a, b_upper, c, lb, ub, gamma=0.7, m_eq=0, b_lower=None, cg_tol=1e-13, cg_max_steps=500, jacobi=False):
         self._l = _lib.lib()
         self.a = a
         self.n = a.shape[1]
@@ -151,6 +151,8 @@ class DeviceBlocks:
             a._h, int(m_eq), None if b_lower is None else _lib.ptr(b_lower), _lib.ptr(b_upper), _lib.ptr(self.c), _lib.ptr(lb),
             _lib.ptr(ub), float(gamma)))
         _lib.check(self._l.slp_blocks_set_cg(self._h, float(cg_tol), int(cg_max_steps)))
+        if jacobi:
+            _lib.check(self._l.slp_blocks_set_precond(self._h, 1))
 
     def close(self):
         if getattr(self, "_h", None):

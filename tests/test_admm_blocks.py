@@ -133,6 +133,11 @@ def test_gpu_row_block_solver_matches_oracle(monkeypatch, min_nnz, m_eq):
     assert 30 < sol.cg_steps() < 30 * 500
     sol.close()
     assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-8
+    # Jacobi-preconditioned conjugate gradients: the same projection (to the CG tolerance), hence the same iterates
+    sol = DeviceBlocks(a, b, c, lb, ub, m_eq=m_eq, b_lower=bl, jacobi=True)
+    sol.iterate(30)
+    assert np.max(np.abs(sol.x() - x) / (1 + np.abs(x))) < 1e-9 and 30 < sol.cg_steps() < 30 * 500
+    sol.close()
     if m_eq == 0:  # the two forms of the projection give the same iterates
         monkeypatch.setenv("SLP_BLOCKS_PRIMAL", "0")
         sol = DeviceBlocks(a, b, c, lb, ub, m_eq=0, b_lower=bl)
