@@ -154,6 +154,11 @@ slp_gs *slp_gs_create(int64_t n, const int64_t *indptr, const int32_t *indices,
                       const double *data);
 void slp_gs_destroy(slp_gs *g);
 int64_t slp_gs_num_levels(const slp_gs *g);
+/* Which sweep the plan chose: 0 one launch per dependency level, 1 one workgroup for the whole (small) system, 2 runs of
+ * narrow levels in one workgroup with a register ring (x gathered from memory), 3 the same with the entries classed at plan
+ * time (products with values that are final formed chip-wide beforehand, recent results read from an LDS ring).  All four give
+ * the sequential sweep's x bit for bit.  SLP_GS_PIPELINED=0/1 and SLP_GS_WINDOW=0 override the choice (tests, timing). */
+int slp_gs_sweep_kind(const slp_gs *g);
 /* x[n] is updated in place (host buffer), maxiter sweeps, relaxation w;
  * lower/upper may hold -inf/+inf. */
 int slp_gs_solve(slp_gs *g, const double *b, const double *lower, const double *upper,

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "slp_gs_create": (c_vp, [c_i64, c_vp, c_vp, c_vp]),
     "slp_gs_destroy": (None, [c_vp]),
     "slp_gs_num_levels": (c_i64, [c_vp]),
+    "slp_gs_sweep_kind": (c_int, [c_vp]),
     "slp_gs_solve": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_dbl]),
     "slp_admm_create": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_admm_create_lp": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl,

@@ -120,8 +120,11 @@ constexpr int kGsEntries = 4;  // entries of a row per lane
 constexpr int kGsMaxSeg = 16;  // lanes per row at most (longer rows: the per-level kernels are used instead)
 constexpr int kGsRing = 3;
 
-struct GsStep { int first, count, maxseg, barrier; };  // lane slots [first, first + count), chain rounds, barrier after the step
-// lane slot: row id, row position in level order, seg | lanes << 8 | entries of this lane << 16 | idle << 24
+// lane slots [first, first + count), chain rounds, barrier: bit 0 = barrier after the step, bit 1 = the step has entries of class
+// "far" (windowed kernel)
+struct GsStep { int first, count, maxseg, barrier; };
+// lane slot: row id, row position in level order, seg | lanes << 8 | entries of this lane << 16 | idle << 24, and where the
+// windowed kernel keeps the row's new x in its LDS ring (-1: nowhere)
 struct alignas(16) GsSlot { i32 row; i32 t; int info; int pad; };
 // the lane's entries, stored per lane slot so that a step streams them with three 16-byte loads per lane
 struct alignas(16) GsEnt { i32 idx[kGsEntries]; double val[kGsEntries]; };
@@ -198,7 +201,116 @@ __global__ __launch_bounds__(1024) void k_gs_sweep_pipelined(int nsteps, const G
             }
             x[g.sl.row] = v;
         }
-        if (sd.barrier) __syncthreads();  // last step of a level: the next level reads these x
+        if (sd.barrier & 1) __syncthreads();  // last step of a level: the next level reads these x
+    };
+    load_slot(st[0], 0);
+    load_slot(st[1], 1);
+    load_data(st[0]);
+    for (int s = 0; s < nsteps; s += kGsRing) {
+#pragma unroll
+        for (int j = 0; j < kGsRing; ++j)
+            if (s + j < nsteps) process(st[j], s + j, st[(j + 1) % kGsRing], st[(j + 2) % kGsRing]);
+    }
+}
+
+// ---- the windowed form of the single-workgroup sweep ---------------------------------------------------------------------
+// k_gs_sweep_pipelined is bound by ONE compute unit's vector-memory path: every lane slot gathers kGsEntries values of x at
+// random addresses, one 64-byte request per lane, 4096 requests per step.  Here no x gather is left on that path.  Each entry
+// of a lane slot is classed when the plan is built, by where the value it reads comes from:
+//   static  the source row is final before this kernel starts (an earlier segment) or is not touched before the reader's own
+//           step (the row itself and rows of later levels): x[source] * value is formed by k_gs_pack_terms, chip-wide, just
+//           before the kernel -- the product is rounded once wherever it is formed, and the sum keeps its order;
+//   near    the source row is updated by this kernel in one of the last kGsWinLevels - 1 levels: its new x is read from an LDS
+//           ring of kGsWinLevels levels (each row writes its result to x and to the ring);
+//   far     updated by this kernel longer ago: a gather from x, as before (none on grid problems; steps without any skip it).
+// What streams per lane slot is 16 B of slot record, 16 B of entry codes and 32 B of terms, all contiguous.
+constexpr int kGsWinLevels = 4;
+constexpr int kGsWide = 4096;        // rows of a level that fit one ring slot
+constexpr unsigned kGsNear = 1u << 30, kGsStatic = 2u << 30;
+struct alignas(16) GsCode { unsigned c[kGsEntries]; };  // class << 30 | (near: ring index; far: row id)
+struct alignas(16) GsDyn { double v[kGsEntries]; };     // static: x[source] * value; near / far: value
+
+__global__ void k_gs_pack_terms(i64 first, i64 count, const GsEnt *__restrict__ ents, const GsCode *__restrict__ codes,
+                                const double *__restrict__ x, GsDyn *__restrict__ dyn) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (i64)gridDim.x * blockDim.x) {
+        const GsEnt en = ents[first + k];
+        const GsCode cd = codes[first + k];
+        GsDyn d;
+#pragma unroll
+        for (int e = 0; e < kGsEntries; ++e) d.v[e] = (cd.c[e] >> 30) == 2 ? x[en.idx[e]] * en.val[e] : en.val[e];
+        dyn[first + k] = d;
+    }
+}
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(1024) void k_gs_sweep_windowed(int nsteps, const GsStep *__restrict__ steps, const GsSlot *__restrict__ slots,
+                                                            const GsCode *__restrict__ codes, const GsDyn *__restrict__ dyn,
+                                                            const double *__restrict__ invd, const GsRow *__restrict__ packed,
+                                                            double *__restrict__ x, double w) {
+    __shared__ double win[kGsWinLevels * kGsWide];
+    struct Stage {
+        GsSlot sl;
+        int live;
+        GsCode cd;
+        GsDyn dv;
+        GsRow rw;
+        double invd;
+    };
+    Stage st[kGsRing];
+    const int tid = threadIdx.x;
+    auto load_slot = [&](Stage &g, int s) {
+        const int sc = s < nsteps ? s : nsteps - 1;
+        const GsStep sd = steps[sc];
+        g.live = (s < nsteps && tid < sd.count) ? 1 : 0;
+        const i64 i = (i64)sd.first + (tid < sd.count ? tid : 0);
+        g.sl = slots[i];
+        g.cd = codes[i];
+        g.dv = dyn[i];
+    };
+    auto load_data = [&](Stage &g) {
+        g.rw = packed[g.sl.t];
+        g.invd = invd[g.sl.t];
+    };
+    auto process = [&](const Stage &g, int s, Stage &g2, Stage &g3) {
+        const GsStep sd = steps[s];
+        double term[kGsEntries];
+#pragma unroll
+        for (int e = 0; e < kGsEntries; ++e) term[e] = win[(g.cd.c[e] >> 30) == 1 ? (g.cd.c[e] & (kGsWinLevels * kGsWide - 1)) : 0];
+        if (sd.barrier & 2) {  // uniform over the workgroup
+#pragma unroll
+            for (int e = 0; e < kGsEntries; ++e)
+                if ((g.cd.c[e] >> 30) == 0) term[e] = __hip_atomic_load(&x[g.cd.c[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        load_data(g2);
+        load_slot(g3, s + 2);
+#pragma unroll
+        for (int e = 0; e < kGsEntries; ++e) term[e] = (g.cd.c[e] >> 30) == 2 ? g.dv.v[e] : term[e] * g.dv.v[e];
+        const int seg = (!g.live || (g.sl.info >> 24)) ? -1 : (g.sl.info & 0xff);
+        const int nlane = (g.sl.info >> 8) & 0xff, len = (g.sl.info >> 16) & 0xff;
+        double v = 0.0, carry = 0.0;
+        for (int r = 0; r < sd.maxseg; ++r) {
+            if (seg == r) {
+                v = carry;
+#pragma unroll
+                for (int e = 0; e < kGsEntries; ++e)
+                    if (e < len) v += term[e];
+            }
+            const double up = __shfl_up(v, 1);
+            if (seg == r + 1) carry = up;
+        }
+        if (seg >= 0 && seg == nlane - 1) {
+            if (BOUNDED) {
+                v = w * (g.rw.b - v) * g.invd + g.rw.xi;
+                if (v < g.rw.lo) v = g.rw.lo;
+                else if (v > g.rw.hi) v = g.rw.hi;
+            } else {
+                const double nv = (g.rw.b - v + g.rw.lo * g.rw.xi) * g.invd;
+                v = w * nv + (1 - w) * g.rw.xi;
+            }
+            x[g.sl.row] = v;
+            if (g.sl.pad >= 0) win[g.sl.pad] = v;
+        }
+        if (sd.barrier & 1) __syncthreads();
     };
     load_slot(st[0], 0);
     load_slot(st[1], 1);
@@ -232,11 +344,15 @@ struct GsPlan {
     std::vector<i64> lptr;   // level pointer on the host (launch sizes)
     bool one_block = false;
     bool pipelined = false;  // runs of narrow levels go through the single-workgroup kernel with the register ring
-    struct Segment { bool launch; i64 first, count; };  // launch: level `first` with k_gs_level; else steps [first, first + count)
+    bool windowed = false;   // ... and those runs use k_gs_sweep_windowed (entry classes, LDS ring) instead of k_gs_sweep_pipelined
+    // launch: level `first` with k_gs_level; else steps [first, first + count) = lane slots [slot_first, slot_first + slot_count)
+    struct Segment { bool launch; i64 first, count, slot_first, slot_count; };
     std::vector<Segment> segments;
     DevBuf<GsStep> steps;
     DevBuf<GsSlot> slots;
     DevBuf<GsEnt> ents;               // per lane slot
+    DevBuf<GsCode> codes;             // per lane slot: the classes of its entries (windowed kernel)
+    mutable DevBuf<GsDyn> dyn;        // per lane slot: the terms, refreshed before every run of a segment (k_gs_pack_terms)
     mutable DevBuf<GsRow> packed;     // per row position, refreshed before every sweep
 };
 
@@ -318,9 +434,20 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         std::vector<GsSlot> slots;
         std::vector<GsPlan::Segment> segs;
         std::vector<GsEnt> ents;
-        const GsSlot idle = {0, 0, 1 << 24, 0};
+        std::vector<GsCode> codes;
+        const GsSlot idle = {0, 0, 1 << 24, -1};
         GsEnt noent;
-        for (int e = 0; e < kGsEntries; ++e) { noent.idx[e] = 0; noent.val[e] = 0.0; }
+        GsCode nocode;
+        for (int e = 0; e < kGsEntries; ++e) { noent.idx[e] = 0; noent.val[e] = 0.0; nocode.c[e] = kGsStatic; }
+        // windowed kernel: position of every row in level order, and the first level of the run of narrow levels being built
+        const char *ew = getenv("SLP_GS_WINDOW");
+        const bool window = !(ew && ew[0] == '0') && n < ((i64)1 << 30);
+        std::vector<i32> pos;
+        if (window) {
+            pos.resize((size_t)n);
+            for (i64 t = 0; t < n; ++t) pos[(size_t)rows[(size_t)t]] = (i32)t;
+        }
+        i64 seg_first_level = 0;
         std::vector<i64> kpos((size_t)n + 1, 0);  // level-ordered entry offset of every row position
         for (i64 t = 0; t < n; ++t) kpos[(size_t)t + 1] = kpos[(size_t)t] + (indptr[rows[(size_t)t] + 1] - indptr[rows[(size_t)t]]);
         i64 narrow_levels = 0;
@@ -331,27 +458,33 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                 if (kpos[(size_t)t + 1] - kpos[(size_t)t] > (i64)kGsMaxSeg * kGsEntries) launch = true;  // a very long row
             if (launch) {
                 GsPlan::Segment sg;
-                sg.launch = true; sg.first = l; sg.count = 1;
+                sg.launch = true; sg.first = l; sg.count = 1; sg.slot_first = 0; sg.slot_count = 0;
                 segs.push_back(sg);
                 continue;
             }
             ++narrow_levels;
+            if (segs.empty() || segs.back().launch) seg_first_level = l;
             const size_t step0 = st.size();
+            const size_t slot0 = slots.size();
             size_t first = slots.size();
             int maxseg = 1;
+            bool has_far = false;
             auto close_step = [&](bool barrier) {
                 GsStep sd;
-                sd.first = (int)first; sd.count = (int)(slots.size() - first); sd.maxseg = maxseg; sd.barrier = barrier ? 1 : 0;
+                sd.first = (int)first; sd.count = (int)(slots.size() - first); sd.maxseg = maxseg;
+                sd.barrier = (barrier ? 1 : 0) | (has_far ? 2 : 0);
                 st.push_back(sd);
                 first = slots.size();
                 maxseg = 1;
+                has_far = false;
             };
+            const bool fits_ring = end - beg <= kGsWide;  // this level's results go to the LDS ring
             for (i64 t = beg; t < end; ++t) {
                 const i64 len = kpos[(size_t)t + 1] - kpos[(size_t)t];
                 const int nl = (int)std::max<i64>(1, (len + kGsEntries - 1) / kGsEntries);
                 size_t used = slots.size() - first;
                 if ((used & 63) + (size_t)nl > 64) {  // a row's lanes stay inside one wave
-                    while ((slots.size() - first) & 63) { slots.push_back(idle); ents.push_back(noent); }
+                    while ((slots.size() - first) & 63) { slots.push_back(idle); ents.push_back(noent); codes.push_back(nocode); }
                     used = slots.size() - first;
                 }
                 if (used + (size_t)nl > 1024) close_step(false);  // next step of the same level: no barrier in between
@@ -359,22 +492,40 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                     const i64 left = len - (i64)j * kGsEntries;
                     const int cnt = (int)std::max<i64>(0, std::min<i64>(kGsEntries, left));
                     GsSlot sl;
-                    sl.row = rows[(size_t)t]; sl.t = (i32)t; sl.pad = 0;
+                    sl.row = rows[(size_t)t]; sl.t = (i32)t;
+                    sl.pad = (window && fits_ring) ? (int)((l % kGsWinLevels) * kGsWide + (t - beg)) : -1;
                     sl.info = j | (nl << 8) | (cnt << 16);
                     slots.push_back(sl);
                     GsEnt en = noent;
+                    GsCode cd = nocode;
                     const i64 src = indptr[rows[(size_t)t]] + (i64)j * kGsEntries;  // the row's entries in storage order
-                    for (int e = 0; e < cnt; ++e) { en.idx[e] = indices[src + e]; en.val[e] = data[src + e]; }
+                    for (int e = 0; e < cnt; ++e) {
+                        en.idx[e] = indices[src + e];
+                        en.val[e] = data[src + e];
+                        if (!window) continue;
+                        const i64 js = indices[src + e], lj = level[(size_t)js];
+                        if (lj < seg_first_level || lj >= l) {
+                            cd.c[e] = kGsStatic;  // final before this run starts, or not touched before this row's step
+                        } else if (lj > l - kGsWinLevels && g.lptr[(size_t)lj + 1] - g.lptr[(size_t)lj] <= kGsWide) {
+                            cd.c[e] = kGsNear | (unsigned)((lj % kGsWinLevels) * kGsWide + (pos[(size_t)js] - g.lptr[(size_t)lj]));
+                        } else {
+                            cd.c[e] = (unsigned)js;
+                            has_far = true;
+                        }
+                    }
                     ents.push_back(en);
+                    codes.push_back(cd);
                 }
                 maxseg = std::max(maxseg, nl);
             }
             close_step(true);
             if (!segs.empty() && !segs.back().launch) {
                 segs.back().count += (i64)(st.size() - step0);
+                segs.back().slot_count += (i64)(slots.size() - slot0);
             } else {
                 GsPlan::Segment sg;
                 sg.launch = false; sg.first = (i64)step0; sg.count = (i64)(st.size() - step0);
+                sg.slot_first = (i64)slot0; sg.slot_count = (i64)(slots.size() - slot0);
                 segs.push_back(sg);
             }
         }
@@ -386,6 +537,11 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             g.ents.upload(ents.data(), ents.size());
             g.packed.alloc((size_t)n);
             g.segments = segs;
+            g.windowed = window;
+            if (window) {
+                g.codes.upload(codes.data(), codes.size());
+                g.dyn.alloc(codes.size());
+            }
         }
     }
 }
@@ -427,6 +583,15 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
             for (const GsPlan::Segment &sg : g.segments) {
                 if (sg.launch) {
                     level_launch(sg.first);
+                } else if (g.windowed) {
+                    hipLaunchKernelGGL(k_gs_pack_terms, dim3(grid_for(sg.slot_count, kBlock)), dim3(kBlock), 0, st, sg.slot_first,
+                                       sg.slot_count, g.ents.p, g.codes.p, x, g.dyn.p);
+                    if (bounded)
+                        hipLaunchKernelGGL(k_gs_sweep_windowed<true>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
+                                           g.slots.p, g.codes.p, g.dyn.p, g.invd.p, g.packed.p, x, w);
+                    else
+                        hipLaunchKernelGGL(k_gs_sweep_windowed<false>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
+                                           g.slots.p, g.codes.p, g.dyn.p, g.invd.p, g.packed.p, x, w);
                 } else if (bounded) {
                     hipLaunchKernelGGL(k_gs_sweep_pipelined<true>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
                                        g.slots.p, g.ents.p, g.invd.p, g.packed.p, x, w);
@@ -672,6 +837,11 @@ slp_gs *slp_gs_create(int64_t n, const int64_t *indptr, const int32_t *indices, 
 void slp_gs_destroy(slp_gs *g) { delete g; }
 
 int64_t slp_gs_num_levels(const slp_gs *g) { return g ? g->plan.nlevels : -1; }
+
+int slp_gs_sweep_kind(const slp_gs *g) {
+    if (!g) return -1;
+    return g->plan.one_block ? 1 : (g->plan.pipelined ? (g->plan.windowed ? 3 : 2) : 0);
+}
 
 int slp_gs_solve(slp_gs *g, const double *b, const double *lower, const double *upper, double *x, int maxiter, double w) {
     SLP_API_INT({

@@ -1,7 +1,8 @@
-"""The single-workgroup, software-pipelined Gauss-Seidel sweep (k_gs_sweep_pipelined: register ring of
-prefetched rows, a row's accumulator handed from lane to lane) against the oracle's sequential sweep,
-bit for bit.  The library picks it for systems with many narrow dependency levels; SLP_GS_PIPELINED=1
-forces it here on every size.  -m gpu."""
+"""The single-workgroup, software-pipelined Gauss-Seidel sweeps (register ring of prefetched rows, a row's
+accumulator handed from lane to lane; k_gs_sweep_windowed: entries classed at plan time, recent results from an
+LDS ring, products with final values formed beforehand; k_gs_sweep_pipelined: every x gathered from memory)
+against the oracle's sequential sweep, bit for bit.  The library picks them for systems with many narrow
+dependency levels; SLP_GS_PIPELINED=1 forces them here on every size, SLP_GS_WINDOW=0 selects the second.  -m gpu."""
 import numpy as np
 import pytest
 import scipy.sparse
@@ -14,11 +15,14 @@ pytestmark = pytest.mark.gpu
 CASES = ["sc50a", "sc105", "potts8", "potts50", "random0", "random1", "random2"]
 
 
-@pytest.fixture()
-def pipelined(monkeypatch):
+@pytest.fixture(params=["window", "gather"])
+def pipelined(monkeypatch, request):
     monkeypatch.setenv("SLP_GS_PIPELINED", "1")
-    yield
+    if request.param == "gather":
+        monkeypatch.setenv("SLP_GS_WINDOW", "0")
+    yield 3 if request.param == "window" else 2
     monkeypatch.delenv("SLP_GS_PIPELINED", raising=False)
+    monkeypatch.delenv("SLP_GS_WINDOW", raising=False)
 
 
 @pytest.mark.parametrize("n,density", [(1, 1.0), (700, 0.004), (700, 0.03), (700, 0.25), (5000, 0.0008), (40000, 0.00005), (3000, 0.4)])
@@ -41,8 +45,11 @@ def test_sweep_random_against_oracle(pipelined, n, density):
     xo = x0.copy()
     oracle.BoundedGaussSeidel(m).solve(rhs, lo, hi, xo, maxiter=2, w=1.1)
     xg = x0.copy()
-    boundedGaussSeidelClass(m).solve(rhs, lo, hi, xg, maxiter=2, w=1.1)
+    gs = boundedGaussSeidelClass(m)
+    gs.solve(rhs, lo, hi, xg, maxiter=2, w=1.1)
     assert np.array_equal(xg, xo)
+    if np.diff(m.indptr).max() <= 64:  # (a level with a longer row goes to the per-level kernel)
+        assert gs.sweep_kind == pipelined
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -69,6 +76,45 @@ def test_potts_grid_takes_the_pipelined_sweep_by_default():
     x = lp_admm(*args, nb_iter=12, nb_iter_plot=5)
     xo = oracle.lp_admm(*args, nb_iter=12, nb_iter_plot=5)
     assert np.array_equal(x, xo)
+
+
+def test_band_and_grid_systems_pick_the_windowed_sweep(monkeypatch):
+    """Without overrides: a 5-point grid (every dependency one level back: LDS ring only) and a band matrix with offsets up to
+    37 (dependencies up to 37 levels back: ring, plus gathers for the ones older than three levels) take the windowed kernel;
+    three sweeps, w = 1, against the oracle; the gather form gives the same bits."""
+    from pysparselp_amd.gaussSiedel import boundedGaussSeidelClass
+
+    rng = np.random.RandomState(11)
+    s = 300
+    n = s * s
+    ii = np.arange(n)
+    rows = np.concatenate([ii[:-1], ii[1:], ii[:-s], ii[s:]])
+    cols = np.concatenate([ii[1:], ii[:-1], ii[s:], ii[:-s]])
+    grid = scipy.sparse.coo_matrix((rng.randn(rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    nb = 30000
+    offs = [-37, -5, -1, 1, 2, 9, 37]
+    band = scipy.sparse.diags([rng.randn(nb - abs(o)) for o in offs], offs, shape=(nb, nb), format="csr")
+    for m0 in (grid, band):
+        m = (m0 + scipy.sparse.diags(np.abs(m0).sum(axis=1).A1 + 1.0)).tocsr()
+        m.sort_indices()
+        k = m.shape[0]
+        rhs, x0 = rng.randn(k), rng.randn(k)
+        lo = np.where(rng.rand(k) < 0.3, -np.inf, -rng.rand(k))
+        hi = np.where(rng.rand(k) < 0.3, np.inf, rng.rand(k))
+        xo = x0.copy()
+        oracle.BoundedGaussSeidel(m).solve(rhs, lo, hi, xo, maxiter=3, w=1.0)
+        out = []
+        for window in (None, "0"):
+            if window is None:
+                monkeypatch.delenv("SLP_GS_WINDOW", raising=False)
+            else:
+                monkeypatch.setenv("SLP_GS_WINDOW", window)
+            gs = boundedGaussSeidelClass(m)
+            assert gs.sweep_kind == (3 if window is None else 2)
+            xg = x0.copy()
+            gs.solve(rhs, lo, hi, xg, maxiter=3, w=1.0)
+            out.append(xg)
+        assert np.array_equal(out[0], xo) and np.array_equal(out[1], xo)
 
 
 def test_randomised_systems_all_sweep_variants():

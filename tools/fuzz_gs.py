@@ -1,5 +1,6 @@
 """Randomised cross-check of the Gauss-Seidel sweeps (per-level launches, single-workgroup kernel, pipelined
-single-workgroup kernel with mixed wide / narrow segments) against the oracle's sequential sweep, bit for bit.
+single-workgroup kernel with mixed wide / narrow segments, with and without the LDS window) against the oracle's
+sequential sweep, bit for bit.
 python tools/fuzz_gs.py [--cases 120] [--seed 0]"""
 import argparse
 import os
@@ -51,6 +52,7 @@ def run(cases, seed, verbose=False):
 
     rng = np.random.RandomState(seed)
     saved = os.environ.get("SLP_GS_PIPELINED")
+    saved_w = os.environ.get("SLP_GS_WINDOW")
     tally = {}
     for case in range(cases):
         kind, m = random_system(rng)
@@ -60,6 +62,10 @@ def run(cases, seed, verbose=False):
             os.environ.pop("SLP_GS_PIPELINED", None)
         else:
             os.environ["SLP_GS_PIPELINED"] = force
+        if rng.rand() < 0.35:
+            os.environ["SLP_GS_WINDOW"] = "0"
+        else:
+            os.environ.pop("SLP_GS_WINDOW", None)
         rhs = rng.randn(n)
         lo = np.where(rng.rand(n) < 0.3, -np.inf, -rng.rand(n))
         hi = np.where(rng.rand(n) < 0.3, np.inf, rng.rand(n))
@@ -71,15 +77,16 @@ def run(cases, seed, verbose=False):
         g = boundedGaussSeidelClass(m)
         g.solve(rhs, lo, hi, xg, maxiter=sweeps, w=w)
         if verbose:
-            print("case", case, kind, n, m.nnz, "levels", g.num_levels, "pipelined", force, flush=True)
-        tally[(kind, force)] = tally.get((kind, force), 0) + 1
+            print("case", case, kind, n, m.nnz, "levels", g.num_levels, "pipelined", force, "sweep kind", g.sweep_kind, flush=True)
+        tally[(kind, force, g.sweep_kind)] = tally.get((kind, force, g.sweep_kind), 0) + 1
         if not np.array_equal(xg, xo):
-            raise AssertionError(f"Gauss-Seidel mismatch: case {case} {kind} n={n} nnz={m.nnz} pipelined={force} "
+            raise AssertionError(f"Gauss-Seidel mismatch: case {case} {kind} n={n} nnz={m.nnz} pipelined={force} kind={g.sweep_kind} "
                                  f"max diff {np.max(np.abs(xg - xo))}")
-    if saved is None:
-        os.environ.pop("SLP_GS_PIPELINED", None)
-    else:
-        os.environ["SLP_GS_PIPELINED"] = saved
+    for name, old in (("SLP_GS_PIPELINED", saved), ("SLP_GS_WINDOW", saved_w)):
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
     return tally
 
 
@@ -90,7 +97,7 @@ def main():
     p.add_argument("--verbose", action="store_true")
     args = p.parse_args()
     tally = run(args.cases, args.seed, args.verbose)
-    print("ok:", args.cases, "cases", {f"{k[0]}/{k[1]}": v for k, v in sorted(tally.items())})
+    print("ok:", args.cases, "cases", {f"{k[0]}/{k[1]}/kind{k[2]}": v for k, v in sorted(tally.items())})
 
 
 if __name__ == "__main__":
