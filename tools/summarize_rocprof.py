@@ -47,11 +47,12 @@ def pmc(fetch_path, write_path):
 
 
 def db_stats(path):
-    """rocprofv3's default output is a rocpd SQLite file; `top_kernels` is its --stats summary (durations in ns)."""
+    """rocprofv3's default output is a rocpd SQLite file; `top_kernels` is its --stats summary.  The view reports MICROSECONDS
+    (k_strip_spmv at C3: 3536 = 3.5 ms, matching the HIP-event timing in bench.py)."""
     import sqlite3
 
     w = csv.writer(sys.stdout)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+    w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
     cur = sqlite3.connect(path).cursor()
     for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 25"):
         w.writerow([short(name)[:90], calls, int(total), int(avg), round(pct, 3)])
