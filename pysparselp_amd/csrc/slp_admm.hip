@@ -214,111 +214,199 @@ __global__ __launch_bounds__(1024) void k_gs_sweep_pipelined(int nsteps, const G
 }
 
 // ---- the windowed form of the single-workgroup sweep ---------------------------------------------------------------------
-// k_gs_sweep_pipelined is bound by ONE compute unit's vector-memory path: every lane slot gathers kGsEntries values of x at
-// random addresses, one 64-byte request per lane, 4096 requests per step.  Here no x gather is left on that path.  Each entry
-// of a lane slot is classed when the plan is built, by where the value it reads comes from:
-//   static  the source row is final before this kernel starts (an earlier segment) or is not touched before the reader's own
-//           step (the row itself and rows of later levels): x[source] * value is formed by k_gs_pack_terms, chip-wide, just
-//           before the kernel -- the product is rounded once wherever it is formed, and the sum keeps its order;
-//   near    the source row is updated by this kernel in one of the last kGsWinLevels - 1 levels: its new x is read from an LDS
-//           ring of kGsWinLevels levels (each row writes its result to x and to the ring);
-//   far     updated by this kernel longer ago: a gather from x, as before (none on grid problems; steps without any skip it).
-// What streams per lane slot is 16 B of slot record, 16 B of entry codes and 32 B of terms, all contiguous.
+// k_gs_sweep_pipelined is bound by the instruction issue of ONE compute unit (PMC on the Potts 256^2 system: the four SIMDs
+// issue in 85 % of the cycles): every wave runs every step whether it has lanes in it or not, every entry costs a 64-byte
+// gather request plus predication, and the chain runs the step's longest row in every wave.  Here:
+//  * the unit of work is a WAVE SLOT (64 lane slots).  A level's wave slots are dealt to the 16 waves; each wave walks its own
+//    list of headers (GsStepW: where its 64 lane slots are, chain rounds, barrier after it, has "far" entries) and a wave
+//    with nothing to do in a level only joins the level's barrier;
+//  * each entry of a lane slot is classed when the plan is built, by where the value it reads comes from:
+//      static  the source row is final before this kernel starts (an earlier segment) or is not touched before the reader's
+//              own step (the row itself and rows of later levels): x[source] * value is formed by k_gs_pack_terms, chip-wide,
+//              just before the kernel -- the product is rounded once wherever it is formed, and the sum keeps its order;
+//      near    the source row is updated by this kernel in one of the last kGsWinLevels - 1 levels: its new x is read from an
+//              LDS ring of kGsWinLevels levels (each row writes its result to x and to the ring);
+//      far     updated by this kernel longer ago: a gather from x (none on grid problems; wave slots without any skip it);
+//    the body has no class test: a term is ring[code] * dyn, where static entries and the padding of short lanes point at a
+//    ring cell that holds 1.0 (y * 1.0 == y bit for bit) and padding terms are -0.0 (v + -0.0 == v bit for bit);
+//  * nothing that is waited for was issued less than two wave slots earlier: headers and lane records are fetched 4 ahead,
+//    terms 2 ahead, the row record (last lane of a row only) 2 ahead.  Headers are read with vector loads (an s_load would
+//    share lgkmcnt with the LDS reads); the accumulator goes from lane to lane by DPP (wave_shr:1), not the LDS crossbar.
+// Streams: 8 B per wave slot, 16 B + 32 B per lane slot (GsLane + position, GsDyn), 40 B per row (GsRowW).
+// One compute unit reads 60 (HBM) / 110 (MALL) / 150 (L2) GB/s (tools/lab/one_cu_stream.cpp): with the loads out of the way
+// of the arithmetic (a build without them runs the Potts 256^2 sweep 9 x faster) the bytes ARE the time.
 constexpr int kGsWinLevels = 4;
 constexpr int kGsWide = 4096;        // rows of a level that fit one ring slot
-constexpr unsigned kGsNear = 1u << 30, kGsStatic = 2u << 30;
-struct alignas(16) GsCode { unsigned c[kGsEntries]; };  // class << 30 | (near: ring index; far: row id)
-struct alignas(16) GsDyn { double v[kGsEntries]; };     // static: x[source] * value; near / far: value
+constexpr int kGsWaves = 16;
+constexpr int kGsOne = kGsWinLevels * kGsWide;  // the ring cell that holds 1.0
+static_assert(kGsOne < 0xffff, "ring indices are 16 bits");
+// code: ring index of the value to multiply with (kGsOne: none).  info: lane of the row | last lane of a row << 4 |
+// entries of this lane << 5 | mask of far entries << 8.  ldsw: where the row's new x goes in the ring (0xffff: nowhere).
+// The row position of a lane slot (both the result it writes and its GsRowW record are addressed by it) is kept in an array
+// of its own, read 4 wave slots ahead like the lane record: as a member of the record, the compiler moves it out of the loaded
+// tuple right behind the load, which waits for it.  Results go to `xpos` in position order (coalesced; k_gs_unpack scatters
+// them to x after the kernel), row records are read in position order (a stream: in row order every 40-byte record would
+// cost a 128-byte line).
+struct alignas(4) GsLane { unsigned short code[kGsEntries]; unsigned short info, ldsw; };
+struct alignas(16) GsDyn { double v[kGsEntries]; };     // static: x[source] * value; near / far: value; padding: -0.0
+struct alignas(8) GsRowW { double b, lo, hi, xi, invd; };  // per row position
+struct alignas(8) GsStepW { int first; unsigned meta; };  // meta: active | chain rounds << 1 | barrier << 6 | has far << 7
 
-__global__ void k_gs_pack_terms(i64 first, i64 count, const GsEnt *__restrict__ ents, const GsCode *__restrict__ codes,
+__global__ void k_gs_pack_terms(i64 first, i64 count, const GsEnt *__restrict__ ents, const GsLane *__restrict__ lanes,
                                 const double *__restrict__ x, GsDyn *__restrict__ dyn) {
     for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (i64)gridDim.x * blockDim.x) {
         const GsEnt en = ents[first + k];
-        const GsCode cd = codes[first + k];
+        const GsLane la = lanes[first + k];
+        const int cnt = (la.info >> 5) & 7, far = la.info >> 8;
         GsDyn d;
 #pragma unroll
-        for (int e = 0; e < kGsEntries; ++e) d.v[e] = (cd.c[e] >> 30) == 2 ? x[en.idx[e]] * en.val[e] : en.val[e];
+        for (int e = 0; e < kGsEntries; ++e) {
+            const bool fixed = la.code[e] == kGsOne && !((far >> e) & 1);
+            d.v[e] = e >= cnt ? -0.0 : (fixed ? x[en.idx[e]] * en.val[e] : en.val[e]);
+        }
         dyn[first + k] = d;
     }
 }
 
 template <bool BOUNDED>
-__global__ __launch_bounds__(1024) void k_gs_sweep_windowed(int nsteps, const GsStep *__restrict__ steps, const GsSlot *__restrict__ slots,
-                                                            const GsCode *__restrict__ codes, const GsDyn *__restrict__ dyn,
-                                                            const double *__restrict__ invd, const GsRow *__restrict__ packed,
-                                                            double *__restrict__ x, double w) {
-    __shared__ double win[kGsWinLevels * kGsWide];
-    struct Stage {
-        GsSlot sl;
-        int live;
-        GsCode cd;
-        GsDyn dv;
-        GsRow rw;
-        double invd;
-    };
-    Stage st[kGsRing];
-    const int tid = threadIdx.x;
-    auto load_slot = [&](Stage &g, int s) {
-        const int sc = s < nsteps ? s : nsteps - 1;
-        const GsStep sd = steps[sc];
-        g.live = (s < nsteps && tid < sd.count) ? 1 : 0;
-        const i64 i = (i64)sd.first + (tid < sd.count ? tid : 0);
-        g.sl = slots[i];
-        g.cd = codes[i];
-        g.dv = dyn[i];
-    };
-    auto load_data = [&](Stage &g) {
-        g.rw = packed[g.sl.t];
-        g.invd = invd[g.sl.t];
-    };
-    auto process = [&](const Stage &g, int s, Stage &g2, Stage &g3) {
-        const GsStep sd = steps[s];
+__global__ void k_gs_pack_rows(i64 n, const i32 *__restrict__ rows, const double *__restrict__ b, const double *__restrict__ lo,
+                               const double *__restrict__ hi, const double *__restrict__ x, const double *__restrict__ invd,
+                               GsRowW *__restrict__ out) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i32 i = rows[t];
+        GsRowW r;
+        r.b = b[i];
+        r.lo = BOUNDED ? lo[i] : lo[t];  // unbounded: the level-ordered diagonal
+        r.hi = BOUNDED ? hi[i] : 0.0;
+        r.xi = x[i];
+        r.invd = invd[t];
+        out[t] = r;
+    }
+}
+
+// x[row] = the result the windowed kernel left at the row's position
+__global__ void k_gs_unpack(i64 first, i64 count, const i32 *__restrict__ rows, const double *__restrict__ xpos, double *__restrict__ x) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (i64)gridDim.x * blockDim.x) x[rows[first + k]] = xpos[first + k];
+}
+
+__device__ __forceinline__ double gs_lane_up(double v) {  // lane i receives lane i - 1's v (lane 0 keeps its own)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// The loop body has no memory instruction under a branch: with loads or stores on some paths only, the compiler can no longer
+// count what is in flight (s_waitcnt vmcnt) and falls back to waiting for everything, which undoes the prefetch.  So every
+// lane loads its row record, every lane stores (lanes that do not finish a row: to a scratch cell), and a wave that has no
+// wave slot in a level repeats the level's first one (same inputs, same results, same addresses: harmless).  FAR = false is
+// the instantiation for plans without far entries.
+template <bool BOUNDED, bool FAR>
+__global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *__restrict__ hoff, const GsStepW *__restrict__ hdr,
+                                                                    const GsLane *__restrict__ lanes, const i32 *__restrict__ lane_row,
+                                                                    const GsDyn *__restrict__ dyn, const GsEnt *__restrict__ ents,
+                                                                    const GsRowW *__restrict__ rowsw, double *__restrict__ x,
+                                                                    double *__restrict__ scratch, double w) {
+    // (lane_row holds row POSITIONS, x is the position-ordered result buffer, far entries name positions)
+    __shared__ double win[kGsOne + 1 + 64];  // the ring, the cell that holds 1.0, one scratch cell per lane
+    constexpr int RA = 6, RB = 3, RC = 2;  // ring sizes: headers + lane records (4 ahead), terms (2 ahead), row records (2 ahead)
+    GsStepW rec[RA];
+    GsLane la[RA];
+    i32 lrow[RA];
+    GsDyn dv[RB];
+    GsRowW rw[RC];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int h0 = hoff[wave], nsteps = hoff[wave + 1] - h0;  // this wave's headers
+    const GsStepW *steps = hdr + h0;
+    double *const spill = scratch + threadIdx.x;
+    if (threadIdx.x == 0) win[kGsOne] = 1.0;
+    __syncthreads();
+    int vzero;  // a zero the compiler cannot see through: keeps the header loads on the vector path
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    auto load_rec = [&](int j, int s) { rec[j] = steps[(s < nsteps ? s : nsteps - 1) + vzero]; };
+    auto slot_of = [&](int j) { return (size_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[j].first) + (unsigned)lane; };
+    auto issue_a = [&](int j) { la[j] = lanes[slot_of(j)]; lrow[j] = lane_row[slot_of(j)]; };
+    auto issue_b = [&](int jb, int j) { dv[jb] = dyn[slot_of(j)]; };
+    auto issue_c = [&](int jc, int j) { rw[jc] = rowsw[lrow[j]]; };
+    auto process = [&](int s, int j, int jb, int jc) {
+        const unsigned meta = __builtin_amdgcn_readfirstlane(rec[j].meta);
+        const size_t slot = slot_of(j);
+        const size_t slot_a = slot_of((j + 4) % RA), slot_b = slot_of((j + 2) % RA);
+        // (the scheduler must not issue the load into rec[j] above the reads of its old value: the two would then be live
+        // together, in two registers, and the copy between them lands right behind the load and waits for it)
+        __builtin_amdgcn_sched_barrier(0);
+        load_rec(j, s + RA);                                  // the header of wave slot s has been read out
+#if !defined(SLP_GS_ABLATE) || SLP_GS_ABLATE != 1
+        la[(j + 4) % RA] = lanes[slot_a];
+        lrow[(j + 4) % RA] = lane_row[slot_a];
+        dv[(jb + 2) % RB] = dyn[slot_b];
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        const GsLane me = la[j];
+        double xv[kGsEntries];
+#pragma unroll
+        for (int e = 0; e < kGsEntries; ++e) xv[e] = win[me.code[e]];
+#if defined(SLP_GS_ABLATE) && SLP_GS_ABLATE == 4
+        for (int e = 0; e < kGsEntries; ++e) xv[e] = 1.0 + me.code[e];
+#endif
+        if (FAR) {
+            if (meta & 128u) {  // uniform over the wave
+                const GsEnt en = ents[slot];
+#pragma unroll
+                for (int e = 0; e < kGsEntries; ++e)
+                    if ((me.info >> (8 + e)) & 1) xv[e] = __hip_atomic_load(&x[en.idx[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         double term[kGsEntries];
 #pragma unroll
-        for (int e = 0; e < kGsEntries; ++e) term[e] = win[(g.cd.c[e] >> 30) == 1 ? (g.cd.c[e] & (kGsWinLevels * kGsWide - 1)) : 0];
-        if (sd.barrier & 2) {  // uniform over the workgroup
-#pragma unroll
-            for (int e = 0; e < kGsEntries; ++e)
-                if ((g.cd.c[e] >> 30) == 0) term[e] = __hip_atomic_load(&x[g.cd.c[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        load_data(g2);
-        load_slot(g3, s + 2);
-#pragma unroll
-        for (int e = 0; e < kGsEntries; ++e) term[e] = (g.cd.c[e] >> 30) == 2 ? g.dv.v[e] : term[e] * g.dv.v[e];
-        const int seg = (!g.live || (g.sl.info >> 24)) ? -1 : (g.sl.info & 0xff);
-        const int nlane = (g.sl.info >> 8) & 0xff, len = (g.sl.info >> 16) & 0xff;
+        for (int e = 0; e < kGsEntries; ++e) term[e] = xv[e] * dv[jb].v[e];
+#if defined(SLP_GS_ABLATE) && SLP_GS_ABLATE == 3
+        const int seg = me.info & 15, rounds = 1;
+#else
+        const int seg = me.info & 15, rounds = (int)((meta >> 1) & 31u);
+#endif
         double v = 0.0, carry = 0.0;
-        for (int r = 0; r < sd.maxseg; ++r) {
+        for (int r = 0; r < rounds; ++r) {
             if (seg == r) {
                 v = carry;
 #pragma unroll
-                for (int e = 0; e < kGsEntries; ++e)
-                    if (e < len) v += term[e];
+                for (int e = 0; e < kGsEntries; ++e) v += term[e];
             }
-            const double up = __shfl_up(v, 1);
+            const double up = gs_lane_up(v);
             if (seg == r + 1) carry = up;
         }
-        if (seg >= 0 && seg == nlane - 1) {
+        {
+            const GsRowW r = rw[jc];
             if (BOUNDED) {
-                v = w * (g.rw.b - v) * g.invd + g.rw.xi;
-                if (v < g.rw.lo) v = g.rw.lo;
-                else if (v > g.rw.hi) v = g.rw.hi;
+                v = w * (r.b - v) * r.invd + r.xi;
+                v = v < r.lo ? r.lo : (v > r.hi ? r.hi : v);
             } else {
-                const double nv = (g.rw.b - v + g.rw.lo * g.rw.xi) * g.invd;
-                v = w * nv + (1 - w) * g.rw.xi;
+                const double nv = (r.b - v + r.lo * r.xi) * r.invd;
+                v = w * nv + (1 - w) * r.xi;
             }
-            x[g.sl.row] = v;
-            if (g.sl.pad >= 0) win[g.sl.pad] = v;
+            const bool last = me.info & 16;
+            *(last ? x + lrow[j] : spill) = v;
+            win[last && me.ldsw != 0xffff ? (int)me.ldsw : kGsOne + 1 + lane] = v;
         }
-        if (sd.barrier & 1) __syncthreads();
+#if !defined(SLP_GS_ABLATE) || SLP_GS_ABLATE != 1
+        issue_c(jc, (j + 2) % RA);                            // rw[jc] is free again
+#endif
+#if !defined(SLP_GS_ABLATE) || SLP_GS_ABLATE != 2
+        if (meta & 64u) __syncthreads();                      // the wave's last wave slot of a level: the next level reads these x
+#endif
     };
-    load_slot(st[0], 0);
-    load_slot(st[1], 1);
-    load_data(st[0]);
-    for (int s = 0; s < nsteps; s += kGsRing) {
 #pragma unroll
-        for (int j = 0; j < kGsRing; ++j)
-            if (s + j < nsteps) process(st[j], s + j, st[(j + 1) % kGsRing], st[(j + 2) % kGsRing]);
+    for (int j = 0; j < RA; ++j) load_rec(j, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_a(j);
+    issue_b(0, 0);
+    issue_b(1, 1);
+    issue_c(0, 0);
+    issue_c(1, 1);
+    for (int s = 0; s < nsteps; s += RA) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) process(s + j, j, j % RB, j % RC);  // (the plan pads every wave's list to a multiple of RA)
     }
 }
 
@@ -344,15 +432,22 @@ struct GsPlan {
     std::vector<i64> lptr;   // level pointer on the host (launch sizes)
     bool one_block = false;
     bool pipelined = false;  // runs of narrow levels go through the single-workgroup kernel with the register ring
+    bool has_far = false;    // (windowed) some entry reads a row updated by the same kernel more than kGsWinLevels - 1 levels before
     bool windowed = false;   // ... and those runs use k_gs_sweep_windowed (entry classes, LDS ring) instead of k_gs_sweep_pipelined
     // launch: level `first` with k_gs_level; else steps [first, first + count) = lane slots [slot_first, slot_first + slot_count)
-    struct Segment { bool launch; i64 first, count, slot_first, slot_count; };
+    struct Segment { bool launch; i64 first, count, slot_first, slot_count, level_first, level_count, hoff; };
     std::vector<Segment> segments;
     DevBuf<GsStep> steps;
     DevBuf<GsSlot> slots;
     DevBuf<GsEnt> ents;               // per lane slot
-    DevBuf<GsCode> codes;             // per lane slot: the classes of its entries (windowed kernel)
+    DevBuf<GsLane> lanes;             // windowed kernel: per lane slot, the classes of its entries and the lane's place in its row
+    DevBuf<i32> lane_row;             // ... and its row
+    DevBuf<GsStepW> stepsw;           // ... the wave-slot headers, per segment and per wave
+    DevBuf<int> hoffs;                // ... and kGsWaves + 1 offsets into them per segment
     mutable DevBuf<GsDyn> dyn;        // per lane slot: the terms, refreshed before every run of a segment (k_gs_pack_terms)
+    mutable DevBuf<GsRowW> rowsw;     // per row position, refreshed before every sweep (k_gs_pack_rows)
+    mutable DevBuf<double> scratch;   // where lanes that do not finish a row store
+    mutable DevBuf<double> xpos;      // the windowed kernel's results, by row position
     mutable DevBuf<GsRow> packed;     // per row position, refreshed before every sweep
 };
 
@@ -434,11 +529,16 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         std::vector<GsSlot> slots;
         std::vector<GsPlan::Segment> segs;
         std::vector<GsEnt> ents;
-        std::vector<GsCode> codes;
+        std::vector<GsLane> lanes;
+        std::vector<i32> lane_row;  // (windowed kernel) the row of every lane slot, 0 for idle ones
         const GsSlot idle = {0, 0, 1 << 24, -1};
         GsEnt noent;
-        GsCode nocode;
-        for (int e = 0; e < kGsEntries; ++e) { noent.idx[e] = 0; noent.val[e] = 0.0; nocode.c[e] = kGsStatic; }
+        GsLane nolane;
+        for (int e = 0; e < kGsEntries; ++e) { noent.idx[e] = 0; noent.val[e] = 0.0; nolane.code[e] = (unsigned short)kGsOne; }
+        nolane.info = 0;  // no entries, not the last lane of a row
+        nolane.ldsw = 0xffff;
+
+        std::vector<i64> lvs0((size_t)g.nlevels, 0), lvs1((size_t)g.nlevels, 0);  // lane slots of every narrow level
         // windowed kernel: position of every row in level order, and the first level of the run of narrow levels being built
         const char *ew = getenv("SLP_GS_WINDOW");
         const bool window = !(ew && ew[0] == '0') && n < ((i64)1 << 30);
@@ -459,6 +559,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             if (launch) {
                 GsPlan::Segment sg;
                 sg.launch = true; sg.first = l; sg.count = 1; sg.slot_first = 0; sg.slot_count = 0;
+                sg.level_first = l; sg.level_count = 1; sg.hoff = 0;
                 segs.push_back(sg);
                 continue;
             }
@@ -470,6 +571,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             int maxseg = 1;
             bool has_far = false;
             auto close_step = [&](bool barrier) {
+                while (window && ((slots.size() - first) & 63)) { slots.push_back(idle); ents.push_back(noent); lanes.push_back(nolane); lane_row.push_back(0); }
                 GsStep sd;
                 sd.first = (int)first; sd.count = (int)(slots.size() - first); sd.maxseg = maxseg;
                 sd.barrier = (barrier ? 1 : 0) | (has_far ? 2 : 0);
@@ -484,7 +586,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                 const int nl = (int)std::max<i64>(1, (len + kGsEntries - 1) / kGsEntries);
                 size_t used = slots.size() - first;
                 if ((used & 63) + (size_t)nl > 64) {  // a row's lanes stay inside one wave
-                    while ((slots.size() - first) & 63) { slots.push_back(idle); ents.push_back(noent); codes.push_back(nocode); }
+                    while ((slots.size() - first) & 63) { slots.push_back(idle); ents.push_back(noent); lanes.push_back(nolane); lane_row.push_back(0); }
                     used = slots.size() - first;
                 }
                 if (used + (size_t)nl > 1024) close_step(false);  // next step of the same level: no barrier in between
@@ -497,7 +599,10 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                     sl.info = j | (nl << 8) | (cnt << 16);
                     slots.push_back(sl);
                     GsEnt en = noent;
-                    GsCode cd = nocode;
+                    GsLane cd = nolane;
+                    cd.info = (unsigned short)(j | (j == nl - 1 ? 16 : 0) | (cnt << 5));
+                    cd.ldsw = (unsigned short)(sl.pad >= 0 ? sl.pad : 0xffff);
+                    lane_row.push_back((i32)t);
                     const i64 src = indptr[rows[(size_t)t]] + (i64)j * kGsEntries;  // the row's entries in storage order
                     for (int e = 0; e < cnt; ++e) {
                         en.idx[e] = indices[src + e];
@@ -505,27 +610,33 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                         if (!window) continue;
                         const i64 js = indices[src + e], lj = level[(size_t)js];
                         if (lj < seg_first_level || lj >= l) {
-                            cd.c[e] = kGsStatic;  // final before this run starts, or not touched before this row's step
+                            cd.code[e] = (unsigned short)kGsOne;  // static: final before this run starts, or not touched before this row's step
                         } else if (lj > l - kGsWinLevels && g.lptr[(size_t)lj + 1] - g.lptr[(size_t)lj] <= kGsWide) {
-                            cd.c[e] = kGsNear | (unsigned)((lj % kGsWinLevels) * kGsWide + (pos[(size_t)js] - g.lptr[(size_t)lj]));
+                            cd.code[e] = (unsigned short)((lj % kGsWinLevels) * kGsWide + (pos[(size_t)js] - g.lptr[(size_t)lj]));  // near
                         } else {
-                            cd.c[e] = (unsigned)js;
+                            cd.code[e] = (unsigned short)kGsOne;  // far: gathered from the results; the position is read from the entry record
+                            cd.info |= (unsigned short)(1 << (8 + e));
+                            en.idx[e] = pos[(size_t)js];
                             has_far = true;
                         }
                     }
                     ents.push_back(en);
-                    codes.push_back(cd);
+                    lanes.push_back(cd);
                 }
                 maxseg = std::max(maxseg, nl);
             }
             close_step(true);
+            lvs0[(size_t)l] = (i64)slot0;
+            lvs1[(size_t)l] = (i64)slots.size();
             if (!segs.empty() && !segs.back().launch) {
                 segs.back().count += (i64)(st.size() - step0);
                 segs.back().slot_count += (i64)(slots.size() - slot0);
+                segs.back().level_count += 1;
             } else {
                 GsPlan::Segment sg;
                 sg.launch = false; sg.first = (i64)step0; sg.count = (i64)(st.size() - step0);
                 sg.slot_first = (i64)slot0; sg.slot_count = (i64)(slots.size() - slot0);
+                sg.level_first = l; sg.level_count = 1; sg.hoff = 0;
                 segs.push_back(sg);
             }
         }
@@ -539,8 +650,56 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             g.segments = segs;
             g.windowed = window;
             if (window) {
-                g.codes.upload(codes.data(), codes.size());
-                g.dyn.alloc(codes.size());
+                // wave-slot headers: a level's wave slots dealt to the waves in turn; a wave without one in a level repeats the
+                // level's first wave slot (see k_gs_sweep_windowed); a wave's last header of a level carries the barrier
+                std::vector<GsStepW> hd;
+                std::vector<int> hoffs;
+                for (GsPlan::Segment &sg : segs) {
+                    if (sg.launch) continue;
+                    std::vector<std::vector<GsStepW>> per((size_t)kGsWaves);
+                    for (i64 l = sg.level_first; l < sg.level_first + sg.level_count; ++l) {
+                        const i64 nw = (lvs1[(size_t)l] - lvs0[(size_t)l]) / 64;
+                        for (i64 q = 0; q < nw; ++q) {
+                            const size_t q0 = (size_t)(lvs0[(size_t)l] + 64 * q);
+                            unsigned rounds = 1, far = 0;
+                            for (size_t k = q0; k < q0 + 64; ++k) {
+                                rounds = std::max(rounds, (unsigned)(lanes[k].info & 15) + 1u);
+                                far |= (unsigned)(lanes[k].info >> 8);
+                            }
+                            GsStepW h;
+                            h.first = (int)q0;
+                            h.meta = 1u | (rounds << 1) | (far ? 128u : 0u);
+                            if (far) g.has_far = true;
+                            per[(size_t)(q % kGsWaves)].push_back(h);
+                        }
+                        for (int wv = 0; wv < kGsWaves; ++wv) {
+                            if ((i64)wv >= nw) per[(size_t)wv].push_back(per[0].back());  // nothing left for this wave: it repeats wave 0's
+                            per[(size_t)wv].back().meta |= 64u;
+                        }
+                    }
+                    sg.hoff = (i64)hoffs.size();
+                    for (int wv = 0; wv < kGsWaves; ++wv) {
+                        // the kernel's loop is unrolled by 6 without a remainder: pad with repeats of the wave's last wave slot
+                        // (after the last barrier; same inputs, same results), without the barrier flag
+                        while (per[(size_t)wv].size() % 6) {
+                            GsStepW h = per[(size_t)wv].back();
+                            h.meta &= ~64u;
+                            per[(size_t)wv].push_back(h);
+                        }
+                        hoffs.push_back((int)hd.size());
+                        hd.insert(hd.end(), per[(size_t)wv].begin(), per[(size_t)wv].end());
+                    }
+                    hoffs.push_back((int)hd.size());
+                }
+                g.segments = segs;
+                g.stepsw.upload(hd.data(), hd.size());
+                g.hoffs.upload(hoffs.data(), hoffs.size());
+                g.lanes.upload(lanes.data(), lanes.size());
+                g.lane_row.upload(lane_row.data(), lane_row.size());
+                g.dyn.alloc(lanes.size());
+                g.rowsw.alloc((size_t)n);
+                g.scratch.alloc((size_t)64 * kGsWaves);
+                g.xpos.alloc((size_t)n);
             }
         }
     }
@@ -576,7 +735,13 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
     if (g.pipelined) {
         for (int s = 0; s < sweeps; ++s) {
             // right-hand side, bounds and own x of every row, in level order (x[row] only changes in the row's own step)
-            if (bounded)
+            if (g.windowed && bounded)
+                hipLaunchKernelGGL(k_gs_pack_rows<true>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.invd.p,
+                                   g.rowsw.p);
+            else if (g.windowed)
+                hipLaunchKernelGGL(k_gs_pack_rows<false>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.invd.p,
+                                   g.rowsw.p);
+            else if (bounded)
                 hipLaunchKernelGGL(k_gs_pack<true>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.packed.p);
             else
                 hipLaunchKernelGGL(k_gs_pack<false>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.packed.p);
@@ -585,13 +750,17 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
                     level_launch(sg.first);
                 } else if (g.windowed) {
                     hipLaunchKernelGGL(k_gs_pack_terms, dim3(grid_for(sg.slot_count, kBlock)), dim3(kBlock), 0, st, sg.slot_first,
-                                       sg.slot_count, g.ents.p, g.codes.p, x, g.dyn.p);
-                    if (bounded)
-                        hipLaunchKernelGGL(k_gs_sweep_windowed<true>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
-                                           g.slots.p, g.codes.p, g.dyn.p, g.invd.p, g.packed.p, x, w);
-                    else
-                        hipLaunchKernelGGL(k_gs_sweep_windowed<false>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
-                                           g.slots.p, g.codes.p, g.dyn.p, g.invd.p, g.packed.p, x, w);
+                                       sg.slot_count, g.ents.p, g.lanes.p, x, g.dyn.p);
+                    auto run = [&](auto kernel) {
+                        hipLaunchKernelGGL(kernel, dim3(1), dim3(64 * kGsWaves), 0, st, g.hoffs.p + sg.hoff, g.stepsw.p, g.lanes.p,
+                                           g.lane_row.p, g.dyn.p, g.ents.p, g.rowsw.p, g.xpos.p, g.scratch.p, w);
+                        const i64 t0 = g.lptr[(size_t)sg.level_first], t1 = g.lptr[(size_t)(sg.level_first + sg.level_count)];
+                        hipLaunchKernelGGL(k_gs_unpack, dim3(grid_for(t1 - t0, kBlock)), dim3(kBlock), 0, st, t0, t1 - t0, g.rows.p, g.xpos.p, x);
+                    };
+                    if (bounded && g.has_far) run(k_gs_sweep_windowed<true, true>);
+                    else if (bounded) run(k_gs_sweep_windowed<true, false>);
+                    else if (g.has_far) run(k_gs_sweep_windowed<false, true>);
+                    else run(k_gs_sweep_windowed<false, false>);
                 } else if (bounded) {
                     hipLaunchKernelGGL(k_gs_sweep_pipelined<true>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
                                        g.slots.p, g.ents.p, g.invd.p, g.packed.p, x, w);
