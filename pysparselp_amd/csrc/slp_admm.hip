@@ -475,6 +475,34 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         }
         maxlev = std::max(maxlev, lv);
     }
+    // Rows that nothing waits for -- no coupled row of higher index, in either direction of the pattern -- need not sit at the
+    // earliest level their inputs allow: when there are many (the slack unknowns of lp_admm's normal matrix: each is coupled
+    // only with the variables of its own constraint, all of lower index) they are moved to one level of their own behind all
+    // others, which is wide and therefore swept by the chip-wide per-level kernel instead of the single-workgroup one.  Every
+    // row still sees exactly the values the sequential sweep gives it (its lower neighbours updated, no higher neighbour
+    // exists), two such rows are never coupled, so x does not change by a bit.  SLP_GS_SINKS=0 keeps the earliest levels.
+    {
+        const char *es = getenv("SLP_GS_SINKS");
+        std::vector<char> coupled_up((size_t)n, 0);
+        for (i64 i = 0; i < n; ++i)
+            for (i64 k = indptr[i]; k < indptr[i + 1]; ++k) {
+                const i32 j = indices[k];
+                if (j != i) coupled_up[(size_t)std::min<i64>(i, j)] = 1;
+            }
+        i64 sinks = 0;
+        for (i64 i = 0; i < n; ++i) sinks += (!coupled_up[(size_t)i] && level[(size_t)i] > 0) ? 1 : 0;
+        if (sinks > 4096 && !(es && es[0] == '0')) {
+            for (i64 i = 0; i < n; ++i)
+                if (!coupled_up[(size_t)i] && level[(size_t)i] > 0) level[(size_t)i] = maxlev + 1;
+            // renumber: levels that held nothing else are gone
+            std::vector<i32> remap((size_t)maxlev + 2, 0);
+            for (i64 i = 0; i < n; ++i) remap[(size_t)level[(size_t)i]] = 1;
+            i32 next_level = 0;
+            for (size_t l = 0; l < remap.size(); ++l) remap[l] = remap[l] ? next_level++ : -1;
+            for (i64 i = 0; i < n; ++i) level[(size_t)i] = remap[(size_t)level[(size_t)i]];
+            maxlev = next_level - 1;
+        }
+    }
     g.nlevels = n ? (i64)maxlev + 1 : 0;
     g.lptr.assign((size_t)g.nlevels + 1, 0);
     for (i64 i = 0; i < n; ++i) g.lptr[(size_t)level[(size_t)i] + 1]++;
