@@ -66,6 +66,10 @@ def run(cases, seed, verbose=False):
             os.environ["SLP_GS_WINDOW"] = "0"
         else:
             os.environ.pop("SLP_GS_WINDOW", None)
+        if rng.rand() < 0.3:
+            os.environ["SLP_GS_SINKS"] = "0"  # earliest levels for every row (no last level of rows nothing waits for)
+        else:
+            os.environ.pop("SLP_GS_SINKS", None)
         rhs = rng.randn(n)
         lo = np.where(rng.rand(n) < 0.3, -np.inf, -rng.rand(n))
         hi = np.where(rng.rand(n) < 0.3, np.inf, rng.rand(n))
@@ -82,6 +86,7 @@ def run(cases, seed, verbose=False):
         if not np.array_equal(xg, xo):
             raise AssertionError(f"Gauss-Seidel mismatch: case {case} {kind} n={n} nnz={m.nnz} pipelined={force} kind={g.sweep_kind} "
                                  f"max diff {np.max(np.abs(xg - xo))}")
+    os.environ.pop("SLP_GS_SINKS", None)
     for name, old in (("SLP_GS_PIPELINED", saved), ("SLP_GS_WINDOW", saved_w)):
         if old is None:
             os.environ.pop(name, None)
