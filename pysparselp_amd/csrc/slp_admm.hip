@@ -435,7 +435,7 @@ struct GsPlan {
     bool has_far = false;    // (windowed) some entry reads a row updated by the same kernel more than kGsWinLevels - 1 levels before
     bool windowed = false;   // ... and those runs use k_gs_sweep_windowed (entry classes, LDS ring) instead of k_gs_sweep_pipelined
     // launch: level `first` with k_gs_level; else steps [first, first + count) = lane slots [slot_first, slot_first + slot_count)
-    struct Segment { bool launch; i64 first, count, slot_first, slot_count, level_first, level_count, hoff; };
+    struct Segment { bool launch; i64 first, count, slot_first, slot_count, level_first, level_count, hoff; int waves; };
     std::vector<Segment> segments;
     DevBuf<GsStep> steps;
     DevBuf<GsSlot> slots;
@@ -443,7 +443,7 @@ struct GsPlan {
     DevBuf<GsLane> lanes;             // windowed kernel: per lane slot, the classes of its entries and the lane's place in its row
     DevBuf<i32> lane_row;             // ... and its row
     DevBuf<GsStepW> stepsw;           // ... the wave-slot headers, per segment and per wave
-    DevBuf<int> hoffs;                // ... and kGsWaves + 1 offsets into them per segment
+    DevBuf<int> hoffs;                // ... and (waves of the segment) + 1 offsets into them per segment
     mutable DevBuf<GsDyn> dyn;        // per lane slot: the terms, refreshed before every run of a segment (k_gs_pack_terms)
     mutable DevBuf<GsRowW> rowsw;     // per row position, refreshed before every sweep (k_gs_pack_rows)
     mutable DevBuf<double> scratch;   // where lanes that do not finish a row store
@@ -587,7 +587,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             if (launch) {
                 GsPlan::Segment sg;
                 sg.launch = true; sg.first = l; sg.count = 1; sg.slot_first = 0; sg.slot_count = 0;
-                sg.level_first = l; sg.level_count = 1; sg.hoff = 0;
+                sg.level_first = l; sg.level_count = 1; sg.hoff = 0; sg.waves = 0;
                 segs.push_back(sg);
                 continue;
             }
@@ -664,7 +664,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                 GsPlan::Segment sg;
                 sg.launch = false; sg.first = (i64)step0; sg.count = (i64)(st.size() - step0);
                 sg.slot_first = (i64)slot0; sg.slot_count = (i64)(slots.size() - slot0);
-                sg.level_first = l; sg.level_count = 1; sg.hoff = 0;
+                sg.level_first = l; sg.level_count = 1; sg.hoff = 0; sg.waves = 0;
                 segs.push_back(sg);
             }
         }
@@ -684,7 +684,14 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                 std::vector<int> hoffs;
                 for (GsPlan::Segment &sg : segs) {
                     if (sg.launch) continue;
-                    std::vector<std::vector<GsStepW>> per((size_t)kGsWaves);
+                    // as many waves as the widest level of the run has wave slots (at most kGsWaves): a wave with nothing of its
+                    // own in a level repeats another's wave slot, and those repeats take issue cycles from the waves on its SIMD
+                    i64 widest = 1;
+                    for (i64 l = sg.level_first; l < sg.level_first + sg.level_count; ++l)
+                        widest = std::max(widest, (lvs1[(size_t)l] - lvs0[(size_t)l]) / 64);
+                    const int waves = (int)std::min<i64>(kGsWaves, widest);
+                    sg.waves = waves;
+                    std::vector<std::vector<GsStepW>> per((size_t)waves);
                     for (i64 l = sg.level_first; l < sg.level_first + sg.level_count; ++l) {
                         const i64 nw = (lvs1[(size_t)l] - lvs0[(size_t)l]) / 64;
                         for (i64 q = 0; q < nw; ++q) {
@@ -698,15 +705,15 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                             h.first = (int)q0;
                             h.meta = 1u | (rounds << 1) | (far ? 128u : 0u);
                             if (far) g.has_far = true;
-                            per[(size_t)(q % kGsWaves)].push_back(h);
+                            per[(size_t)(q % waves)].push_back(h);
                         }
-                        for (int wv = 0; wv < kGsWaves; ++wv) {
+                        for (int wv = 0; wv < waves; ++wv) {
                             if ((i64)wv >= nw) per[(size_t)wv].push_back(per[0].back());  // nothing left for this wave: it repeats wave 0's
                             per[(size_t)wv].back().meta |= 64u;
                         }
                     }
                     sg.hoff = (i64)hoffs.size();
-                    for (int wv = 0; wv < kGsWaves; ++wv) {
+                    for (int wv = 0; wv < waves; ++wv) {
                         // the kernel's loop is unrolled by 6 without a remainder: pad with repeats of the wave's last wave slot
                         // (after the last barrier; same inputs, same results), without the barrier flag
                         while (per[(size_t)wv].size() % 6) {
@@ -780,7 +787,7 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
                     hipLaunchKernelGGL(k_gs_pack_terms, dim3(grid_for(sg.slot_count, kBlock)), dim3(kBlock), 0, st, sg.slot_first,
                                        sg.slot_count, g.ents.p, g.lanes.p, x, g.dyn.p);
                     auto run = [&](auto kernel) {
-                        hipLaunchKernelGGL(kernel, dim3(1), dim3(64 * kGsWaves), 0, st, g.hoffs.p + sg.hoff, g.stepsw.p, g.lanes.p,
+                        hipLaunchKernelGGL(kernel, dim3(1), dim3(64 * sg.waves), 0, st, g.hoffs.p + sg.hoff, g.stepsw.p, g.lanes.p,
                                            g.lane_row.p, g.dyn.p, g.ents.p, g.rowsw.p, g.xpos.p, g.scratch.p, w);
                         const i64 t0 = g.lptr[(size_t)sg.level_first], t1 = g.lptr[(size_t)(sg.level_first + sg.level_count)];
                         hipLaunchKernelGGL(k_gs_unpack, dim3(grid_for(t1 - t0, kBlock)), dim3(kBlock), 0, st, t0, t1 - t0, g.rows.p, g.xpos.p, x);
