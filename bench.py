@@ -145,7 +145,8 @@ def cpu_baseline(args, method):
     """Oracle (port of the reference algorithm, 1 thread) on a bounded sample: the first m/10 rows of the same LP with all n
     columns (>= 1/10 of the stored entries; per-entry cost on a CPU depends on the size of the gathered vector, which is the
     full one here).  Only iterations are timed (timestamps taken by the oracle's per-iteration hook); the rate is scaled by
-    the row ratio -- an extrapolation, validated once at full size by tools/cpu_full_c3.py (profiles/r02_cpu_full_c3.json)."""
+    the row ratio -- an extrapolation, validated at full size for both methods by tools/cpu_full_c3.py
+    (profiles/r03_cpu_full_c3.json)."""
     from oracle import oracle
 
     rows = args.cpu_sample_rows or max(1, args.m // 10)
@@ -182,12 +183,15 @@ def cpu_baseline(args, method):
         "sample_setup_seconds": setup_s,
         "host_cores_present": os.cpu_count(),
     }
-    full = os.path.join(REPO, "profiles", "r02_cpu_full_c3.json")
-    if os.path.exists(full):
+    for name in ("r03_cpu_full_c3.json", "r02_cpu_full_c3.json"):  # (r02: Chambolle-Pock only)
+        full = os.path.join(REPO, "profiles", name)
         try:
-            out["full_size_validation"] = {"source": "profiles/r02_cpu_full_c3.json", **json.load(open(full)).get(method, {})}
+            rec = json.load(open(full)).get(method)
         except Exception:  # the validation record is optional evidence, never a reason to lose the bench line
-            pass
+            rec = None
+        if rec:
+            out["full_size_validation"] = {"source": "profiles/" + name, **rec}
+            break
     return out
 
 
@@ -314,6 +318,7 @@ def main():
             "frac": ax["frac"],
             "traffic": ax["traffic"],
             "traffic_source": ax["traffic_source"],
+            "traffic_measured_in_this_run": False,  # a committed rocprofv3 PMC summary of this command, not a counter of this run
             "definition": "achieved = bytes the kernel has to move per launch (the matrix copy it streams + x read once + y "
                           "written once) / HIP-event time per launch on the library's stream; traffic = rocprofv3 PMC "
                           "(FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of the same kernel on the same workload",

@@ -48,15 +48,35 @@ def _lib():
         lib.orc_normal_matrix.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, dbl, dbl, vp, vp, vp]
         lib.orc_normal_matrix.restype = i64
         lib.orc_row_scale_l2.argtypes = [i64, vp, vp, vp]
+        lib.orc_csc_rmatvec.argtypes = [i64, vp, vp, vp, vp, vp]
+        lib.orc_scale_rows_reversed.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.orc_stack_standard_form.argtypes = [i64, i64, i64] + [vp] * 9
+        lib.orc_sort_rows.argtypes = [i64, vp, vp, vp]
+        lib.orc_sort_rows.restype = i64
+        lib.orc_set_threads.argtypes = [ctypes.c_int]
+        lib.orc_get_threads.restype = ctypes.c_int
         for f in (lib.orc_csr_matvec, lib.orc_csr_rmatvec, lib.orc_bounded_gauss_seidel,
-                  lib.orc_csr_to_csc, lib.orc_row_scale_l2):
+                  lib.orc_csr_to_csc, lib.orc_row_scale_l2, lib.orc_csc_rmatvec, lib.orc_scale_rows_reversed,
+                  lib.orc_stack_standard_form, lib.orc_set_threads):
             f.restype = None
+        lib.orc_set_threads(int(os.environ.get("ORACLE_THREADS", "1")))
         _LIB = lib
     return _LIB
 
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def set_threads(n):
+    """Threads for the loops over independent rows / columns (default 1, or ``ORACLE_THREADS``): results do not depend on
+    it -- no sum is split or reordered (slp_oracle.c) -- only the wall time of the full-size parity runs does.  The
+    timed ``cpu_baseline`` of bench.py keeps 1: the reference is single-threaded."""
+    _lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return int(_lib().orc_get_threads())
 
 
 def _f64(a):
@@ -67,6 +87,7 @@ class Csr:
     """Raw CSR triple (int64 indptr, int32 indices, float64 data) + shape."""
 
     def __init__(self, indptr, indices, data, shape):
+        self._csc = None  # CSC arrays, built on first use by rmatvec when several threads are asked for
         self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         self.indices = np.ascontiguousarray(indices, dtype=np.int32)
         self.data = _f64(data)
@@ -113,6 +134,13 @@ def rmatvec(a, y):
     y = _f64(y)
     assert y.size == a.shape[0]
     out = np.empty(a.shape[1])
+    if get_threads() > 1 and a.nnz > 1_000_000:
+        # columns are independent: the same chain of additions per column from the (stable) CSC arrays
+        if a._csc is None:
+            a._csc = to_csc(a)
+        cptr, crow, cdata = a._csc
+        _lib().orc_csc_rmatvec(a.shape[1], _p(cptr), _p(crow), _p(cdata), _p(y), _p(out))
+        return out
     _lib().orc_csr_rmatvec(a.shape[0], a.shape[1], _p(a.indptr), _p(a.indices), _p(a.data), _p(y), _p(out))
     return out
 
@@ -180,16 +208,16 @@ def precondition_constraints(a, b, b2=None):
     a = as_csr(a)
     inv_s = np.empty(a.shape[0])
     _lib().orc_row_scale_l2(a.shape[0], _p(a.indptr), _p(a.data), _p(inv_s))
-    rows = np.repeat(np.arange(a.shape[0]), np.diff(a.indptr))
-    scaled = inv_s[rows] * a.data
-    # reverse every row segment: position p in row r maps to start+end-1-p
-    pos = np.arange(a.nnz)
-    rev = a.indptr[rows] + a.indptr[rows + 1] - 1 - pos
-    a_p = Csr(a.indptr.copy(), a.indices[rev], scaled[rev], a.shape)
-    keep = a_p.data != 0  # SMMP drops entries whose value is exactly 0
-    if not np.all(keep):
-        counts = np.bincount(rows[keep], minlength=a.shape[0])
-        a_p = Csr(np.concatenate(([0], np.cumsum(counts))), a_p.indices[keep], a_p.data[keep], a.shape)
+    # scaled, every row reversed, exact zeros dropped (SMMP): slp_oracle.c orc_scale_rows_reversed
+    counts = np.empty(a.shape[0], dtype=np.int64)
+    args = (a.shape[0], _p(a.indptr), _p(a.indices), _p(a.data), _p(inv_s))
+    _lib().orc_scale_rows_reversed(*args, _p(counts), None, None, None)
+    ptr = np.zeros(a.shape[0] + 1, dtype=np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    ind = np.empty(int(ptr[-1]), dtype=np.int32)
+    dat = np.empty(int(ptr[-1]))
+    _lib().orc_scale_rows_reversed(*args, None, _p(ptr), _p(ind), _p(dat))
+    a_p = Csr(ptr, ind, dat, a.shape)
     bp = inv_s * _f64(b) if b is not None else None
     if b2 is None:
         return a_p, bp
@@ -198,25 +226,25 @@ def precondition_constraints(a, b, b2=None):
 
 def _sorted_rows(indptr, indices, data, shape):
     """COO->CSR as scipy does it for hstack/vstack results: columns sorted
-    inside every row, duplicates summed in that order."""
-    rows = np.repeat(np.arange(shape[0]), np.diff(indptr))
-    order = np.lexsort((indices, rows))  # stable: by row, then column
-    r, j, v = rows[order], indices[order], data[order]
-    if r.size:
-        new = np.ones(r.size, dtype=bool)
-        new[1:] = (r[1:] != r[:-1]) | (j[1:] != j[:-1])
-        if not np.all(new):
-            starts = np.nonzero(new)[0]
-            # left to right in storage order like scipy's csr_sum_duplicates (np.add.reduceat is not sequential on
-            # runs of three or more duplicates; np.add.at is)
-            run = np.cumsum(new) - 1
-            summed = np.zeros(starts.size)
-            np.add.at(summed, run, v)
-            v = summed
-            r, j = r[starts], j[starts]
+    inside every row (stable), duplicates summed in that order.  ``indices`` / ``data`` are sorted in place."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    dups = _lib().orc_sort_rows(shape[0], _p(indptr), _p(indices), _p(data))
+    if dups == 0:
+        return Csr(indptr, indices, data, shape)
+    r = np.repeat(np.arange(shape[0]), np.diff(indptr))
+    j, v = indices, data
+    new = np.ones(r.size, dtype=bool)
+    new[1:] = (r[1:] != r[:-1]) | (j[1:] != j[:-1])
+    starts = np.nonzero(new)[0]
+    # left to right in storage order like scipy's csr_sum_duplicates (np.add.reduceat is not sequential on
+    # runs of three or more duplicates; np.add.at is)
+    run = np.cumsum(new) - 1
+    summed = np.zeros(starts.size)
+    np.add.at(summed, run, v)
+    r, j = r[starts], j[starts]
     ptr = np.zeros(shape[0] + 1, dtype=np.int64)
     np.add.at(ptr, r + 1, 1)
-    return Csr(np.cumsum(ptr), j, v, shape)
+    return Csr(np.cumsum(ptr), j, summed, shape)
 
 
 def convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0):
@@ -227,27 +255,22 @@ def convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper,
     if a_ineq is None:
         raise UnboundLocalError("a_eq2 (reference fails the same way when a_ineq is None)")
     ni, n = a_ineq.shape
-    ci = np.diff(a_ineq.indptr)
-    rows_i = np.repeat(np.arange(ni), ci)
-    # rows [Ai, -I]: append one (n+i, -1) entry per row, then sort each row
-    ind_i = np.concatenate((a_ineq.indices, (n + np.arange(ni)).astype(np.int32)))
-    dat_i = np.concatenate((a_ineq.data, -np.ones(ni)))
-    row_i = np.concatenate((rows_i, np.arange(ni)))
+    # rows [Ai, -I]: one (n+i, -1) entry appended to every row, then every row sorted (slp_oracle.c)
+    me = 0 if a_eq is None else a_eq.shape[0]
+    lens = np.diff(a_ineq.indptr) + 1
     if a_eq is not None:
-        me = a_eq.shape[0]
-        rows_e = np.repeat(np.arange(me), np.diff(a_eq.indptr))
-        rows = np.concatenate((rows_e, me + row_i))
-        ind = np.concatenate((a_eq.indices, ind_i))
-        dat = np.concatenate((a_eq.data, dat_i))
+        lens = np.concatenate((np.diff(a_eq.indptr), lens))
         b2 = np.hstack((_f64(beq), np.zeros(ni)))
     else:
-        me = 0
-        rows, ind, dat = row_i, ind_i, dat_i
         b2 = np.zeros(ni)
-    order = np.argsort(rows, kind="stable")
-    counts = np.bincount(rows, minlength=me + ni)
-    ptr = np.concatenate(([0], np.cumsum(counts)))
-    a2 = _sorted_rows(ptr, ind[order], dat[order], (me + ni, n + ni))
+    ptr = np.zeros(me + ni + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ind = np.empty(int(ptr[-1]), dtype=np.int32)
+    dat = np.empty(int(ptr[-1]))
+    e = a_eq if a_eq is not None else Csr(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), (0, n))
+    _lib().orc_stack_standard_form(me, ni, n, _p(e.indptr), _p(e.indices), _p(e.data), _p(a_ineq.indptr), _p(a_ineq.indices),
+                                   _p(a_ineq.data), _p(ptr), _p(ind), _p(dat))
+    a2 = _sorted_rows(ptr, ind, dat, (me + ni, n + ni))
     if b_lower is None:
         b_lower = np.full(ni, -np.inf)
     if b_upper is None:
@@ -290,19 +313,25 @@ def one_sided(a_ineq, b_lower, b_upper):
 # --------------------------------------------------------------------------
 def cp_setup(a_eq, a_ineq, alpha=1):
     """Diagonal preconditioners T, Sigma_eq, Sigma_ineq (ChambollePockPPD.py:122-179)."""
+    def powered(a, p):
+        cp = Csr(a.indptr, a.indices, np.abs(a.data) ** p, a.shape)
+        if get_threads() > 1 and a.nnz > 1_000_000:  # the CSC arrays of |A|^p are those of A with the same map applied
+            if a._csc is None:
+                a._csc = to_csc(a)
+            cp._csc = (a._csc[0], a._csc[1], np.abs(a._csc[2]) ** p)
+        return cp
+
     tmp = 0
     for a in (a_eq, a_ineq):
         if a is not None:
-            cp = Csr(a.indptr, a.indices, np.abs(a.data) ** (2 - alpha), a.shape)
-            tmp = tmp + rmatvec(cp, np.ones(a.shape[0]))  # :134,144 column sums, row order
+            tmp = tmp + rmatvec(powered(a, 2 - alpha), np.ones(a.shape[0]))  # :134,144 column sums, row order
     tmp[tmp == 0] = 1  # :152
     diag_t = 1 / tmp
 
     def sigma(a):
         if a is None:
             return None
-        cp = Csr(a.indptr, a.indices, np.abs(a.data) ** alpha, a.shape)
-        s = matvec(cp, np.ones(a.shape[1]))  # :161,172
+        s = matvec(Csr(a.indptr, a.indices, np.abs(a.data) ** alpha, a.shape), np.ones(a.shape[1]))  # :161,172
         s[s == 0] = 1
         return 1 / s
 

@@ -26,9 +26,19 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 typedef int64_t i64;
 typedef int32_t i32;
+
+/* Threads for the loops whose iterations are independent of each other (rows of a CSR product, columns of a CSC
+ * product, rows of a setup transform).  1 by default -- the reference is single-threaded end to end and the timed
+ * cpu_baseline keeps 1.  More threads never change a result: no sum is split or reordered, a thread owns whole rows
+ * (or whole columns) and walks them in the order stated per function.  Used by the full-size parity tests
+ * (tests/test_gpu_c3_full.py), where one thread would take minutes per iteration. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
 
 /* y = A x, A in CSR.  scipy csr_matvec: for each row, sum = y[i] (zero on
  * entry for `A * x`), then sum += data[k] * x[indices[k]] in storage order.
@@ -37,6 +47,7 @@ typedef int32_t i32;
 void orc_csr_matvec(i64 nrow, const i64 *indptr, const i32 *indices,
                     const double *data, const double *x, double *y)
 {
+#pragma omp parallel for num_threads(g_threads) if (g_threads > 1) schedule(dynamic, 256)
     for (i64 i = 0; i < nrow; ++i) {
         double sum = 0.0;
         for (i64 k = indptr[i]; k < indptr[i + 1]; ++k)
@@ -61,6 +72,21 @@ void orc_csr_rmatvec(i64 nrow, i64 ncol, const i64 *indptr, const i32 *indices,
         const double yi = y[i];
         for (i64 k = indptr[i]; k < indptr[i + 1]; ++k)
             out[indices[k]] += data[k] * yi;
+    }
+}
+
+/* The same `y * A` from the CSC arrays of A as orc_csr_to_csc builds them (stable: rows increasing inside every
+ * column, ties in storage order): out[j] = ((0 + t_1) + t_2) + ... over the column's entries -- exactly the chain
+ * of additions orc_csr_rmatvec performs on out[j], so the two agree bit for bit (tests/test_oracle_golden.py).
+ * Columns are independent: this is the form the multi-threaded runs use. */
+void orc_csc_rmatvec(i64 ncol, const i64 *cptr, const i32 *crow, const double *cdata, const double *y, double *out)
+{
+#pragma omp parallel for num_threads(g_threads) if (g_threads > 1) schedule(dynamic, 256)
+    for (i64 j = 0; j < ncol; ++j) {
+        double sum = 0.0;
+        for (i64 p = cptr[j]; p < cptr[j + 1]; ++p)
+            sum += cdata[p] * y[crow[p]];
+        out[j] = sum;
     }
 }
 
@@ -92,25 +118,80 @@ void orc_bounded_gauss_seidel(i64 n, const i64 *indptr, const i32 *indices,
 }
 
 /* Stable CSR -> CSC conversion (scipy csr_tocsc: counting sort by column,
- * rows visited in order, so every column lists its rows increasingly). */
+ * rows visited in order, so every column lists its rows increasingly).
+ * With several threads: thread t owns a contiguous range of rows, counts its entries per column, and is handed, for
+ * every column, the slots right behind those of the threads before it -- the same placement as the one-thread loop. */
 void orc_csr_to_csc(i64 nrow, i64 ncol, const i64 *indptr, const i32 *indices,
                     const double *data, i64 *cptr, i32 *crow, double *cdata)
 {
     const i64 nnz = indptr[nrow];
-    memset(cptr, 0, (size_t)(ncol + 1) * sizeof(i64));
-    for (i64 k = 0; k < nnz; ++k)
-        cptr[indices[k] + 1]++;
+    const int T = (g_threads > 1 && nnz > 100000) ? g_threads : 1;
+    if (T == 1) {
+        memset(cptr, 0, (size_t)(ncol + 1) * sizeof(i64));
+        for (i64 k = 0; k < nnz; ++k)
+            cptr[indices[k] + 1]++;
+        for (i64 j = 0; j < ncol; ++j)
+            cptr[j + 1] += cptr[j];
+        i64 *next = (i64 *)malloc((size_t)(ncol + 1) * sizeof(i64));
+        memcpy(next, cptr, (size_t)(ncol + 1) * sizeof(i64));
+        for (i64 i = 0; i < nrow; ++i)
+            for (i64 k = indptr[i]; k < indptr[i + 1]; ++k) {
+                const i64 p = next[indices[k]]++;
+                crow[p] = (i32)i;
+                cdata[p] = data[k];
+            }
+        free(next);
+        return;
+    }
+    i64 *hist = (i64 *)calloc((size_t)T * (size_t)ncol, sizeof(i64));
+    i64 *row0 = (i64 *)malloc((size_t)(T + 1) * sizeof(i64));
+    for (int t = 0; t <= T; ++t) { /* row ranges of about equal entry counts */
+        const i64 want = nnz / T * t;
+        i64 lo = 0, hi = nrow;
+        while (lo < hi) {
+            const i64 mid = (lo + hi) / 2;
+            if (indptr[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        row0[t] = (t == T) ? nrow : lo;
+    }
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        i64 *h = hist + (size_t)t * (size_t)ncol;
+        for (i64 k = indptr[row0[t]]; k < indptr[row0[t + 1]]; ++k)
+            h[indices[k]]++;
+    }
+    cptr[0] = 0;
+#pragma omp parallel for num_threads(T) schedule(static)
+    for (i64 j = 0; j < ncol; ++j) {
+        i64 tot = 0;
+        for (int t = 0; t < T; ++t) tot += hist[(size_t)t * (size_t)ncol + j];
+        cptr[j + 1] = tot;
+    }
     for (i64 j = 0; j < ncol; ++j)
         cptr[j + 1] += cptr[j];
-    i64 *next = (i64 *)malloc((size_t)(ncol + 1) * sizeof(i64));
-    memcpy(next, cptr, (size_t)(ncol + 1) * sizeof(i64));
-    for (i64 i = 0; i < nrow; ++i)
-        for (i64 k = indptr[i]; k < indptr[i + 1]; ++k) {
-            const i64 p = next[indices[k]]++;
-            crow[p] = (i32)i;
-            cdata[p] = data[k];
+#pragma omp parallel for num_threads(T) schedule(static)
+    for (i64 j = 0; j < ncol; ++j) {
+        i64 at = cptr[j];
+        for (int t = 0; t < T; ++t) {
+            const i64 c = hist[(size_t)t * (size_t)ncol + j];
+            hist[(size_t)t * (size_t)ncol + j] = at;
+            at += c;
         }
-    free(next);
+    }
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        i64 *next = hist + (size_t)t * (size_t)ncol;
+        for (i64 i = row0[t]; i < row0[t + 1]; ++i)
+            for (i64 k = indptr[i]; k < indptr[i + 1]; ++k) {
+                const i64 p = next[indices[k]]++;
+                crow[p] = (i32)i;
+                cdata[p] = data[k];
+            }
+    }
+    free(hist);
+    free(row0);
 }
 
 /* M = gamma_eq * A^T A + gamma_ineq * I as CSR with sorted column indices
@@ -198,6 +279,7 @@ i64 orc_normal_matrix(i64 nrow, i64 ncol, const i64 *indptr, const i32 *indices,
  * path uses: ADMM.py:77,82,91). */
 void orc_row_scale_l2(i64 nrow, const i64 *indptr, const double *data, double *inv_s)
 {
+#pragma omp parallel for num_threads(g_threads) if (g_threads > 1) schedule(dynamic, 256)
     for (i64 i = 0; i < nrow; ++i) {
         double sum = 0.0;
         for (i64 k = indptr[i]; k < indptr[i + 1]; ++k) {
@@ -227,4 +309,117 @@ void orc_gauss_seidel(i64 n, const i64 *indptr, const i32 *indices, const double
             x[i] = nv;
         }
     }
+}
+
+/* `diags(inv_s) * A` of tools.py:283-284 as scipy evaluates it: a sparse-sparse product (SMMP, csr_matmat) whose
+ * output lists every row in the REVERSE of the order in which its columns were first touched -- with one term per
+ * entry that is the reverse of the input row -- with the values inv_s[i] * a_ik (one rounding) and entries whose value
+ * is exactly 0 dropped.  Two calls: counts[i] = entries row i keeps (out_indices == NULL), then, with out_indptr the
+ * running sum of the counts, the fill. */
+void orc_scale_rows_reversed(i64 nrow, const i64 *indptr, const i32 *indices, const double *data, const double *inv_s,
+                             i64 *counts, const i64 *out_indptr, i32 *out_indices, double *out_data)
+{
+#pragma omp parallel for num_threads(g_threads) if (g_threads > 1) schedule(dynamic, 256)
+    for (i64 i = 0; i < nrow; ++i) {
+        const double f = inv_s[i];
+        if (!out_indices) {
+            i64 c = 0;
+            for (i64 k = indptr[i]; k < indptr[i + 1]; ++k)
+                if (f * data[k] != 0.0) ++c;
+            counts[i] = c;
+        } else {
+            i64 o = out_indptr[i];
+            for (i64 k = indptr[i + 1] - 1; k >= indptr[i]; --k) {
+                const double v = f * data[k];
+                if (v != 0.0) {
+                    out_indices[o] = indices[k];
+                    out_data[o] = v;
+                    ++o;
+                }
+            }
+        }
+    }
+}
+
+/* Rows of [[A_eq, 0], [A_ineq, -I]] before they are sorted (tools.py:112-118, scipy hstack / vstack through COO):
+ * an equality row keeps its entries, inequality row i keeps its entries followed by (n + i, -1.0).
+ * out_indptr is given (row lengths are known to the caller). */
+void orc_stack_standard_form(i64 me, i64 ni, i64 n, const i64 *ep, const i32 *ej, const double *ex, const i64 *ip,
+                             const i32 *ij, const double *ix, const i64 *out_indptr, i32 *out_indices, double *out_data)
+{
+#pragma omp parallel for num_threads(g_threads) if (g_threads > 1) schedule(dynamic, 256)
+    for (i64 r = 0; r < me + ni; ++r) {
+        i64 o = out_indptr[r];
+        if (r < me) {
+            for (i64 k = ep[r]; k < ep[r + 1]; ++k, ++o) { out_indices[o] = ej[k]; out_data[o] = ex[k]; }
+        } else {
+            const i64 i = r - me;
+            for (i64 k = ip[i]; k < ip[i + 1]; ++k, ++o) { out_indices[o] = ij[k]; out_data[o] = ix[k]; }
+            out_indices[o] = (i32)(n + i);
+            out_data[o] = -1.0;
+        }
+    }
+}
+
+/* Every row stably sorted by column, in place (what scipy's COO -> CSR conversion + sort_indices leave: the stable
+ * order np.lexsort((indices, rows)) gives).  Returns the number of adjacent equal-column pairs left (duplicates; the
+ * caller sums them left to right).  Rows already increasing are left alone, strictly decreasing rows are reversed,
+ * everything else goes through a stable merge sort. */
+static void merge_sort_row(i32 *j, double *v, i32 *tj, double *tv, i64 n)
+{
+    for (i64 w = 1; w < n; w *= 2) {
+        for (i64 lo = 0; lo < n; lo += 2 * w) {
+            const i64 mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            i64 a = lo, b = mid, o = lo;
+            while (a < mid && b < hi) {
+                if (j[b] < j[a]) { tj[o] = j[b]; tv[o] = v[b]; ++b; }
+                else { tj[o] = j[a]; tv[o] = v[a]; ++a; }
+                ++o;
+            }
+            while (a < mid) { tj[o] = j[a]; tv[o] = v[a]; ++a; ++o; }
+            while (b < hi) { tj[o] = j[b]; tv[o] = v[b]; ++b; ++o; }
+        }
+        memcpy(j, tj, (size_t)n * sizeof(i32));
+        memcpy(v, tv, (size_t)n * sizeof(double));
+    }
+}
+
+i64 orc_sort_rows(i64 nrow, const i64 *indptr, i32 *indices, double *data)
+{
+    i64 dups = 0;
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1) reduction(+ : dups)
+    {
+        i64 cap = 0;
+        i32 *tj = NULL;
+        double *tv = NULL;
+#pragma omp for schedule(dynamic, 256)
+        for (i64 i = 0; i < nrow; ++i) {
+            i32 *j = indices + indptr[i];
+            double *v = data + indptr[i];
+            const i64 n = indptr[i + 1] - indptr[i];
+            int inc = 1, dec = 1;
+            for (i64 k = 1; k < n; ++k) {
+                if (j[k] < j[k - 1]) inc = 0;
+                if (j[k] >= j[k - 1]) dec = 0;
+            }
+            if (!inc && dec) {
+                for (i64 a = 0, b = n - 1; a < b; ++a, --b) {
+                    const i32 tji = j[a]; j[a] = j[b]; j[b] = tji;
+                    const double tvi = v[a]; v[a] = v[b]; v[b] = tvi;
+                }
+            } else if (!inc) {
+                if (n > cap) {
+                    cap = 2 * n;
+                    tj = (i32 *)realloc(tj, (size_t)cap * sizeof(i32));
+                    tv = (double *)realloc(tv, (size_t)cap * sizeof(double));
+                }
+                merge_sort_row(j, v, tj, tv, n);
+            }
+            for (i64 k = 1; k < n; ++k)
+                if (j[k] == j[k - 1]) ++dups;
+        }
+        free(tj);
+        free(tv);
+    }
+    return dups;
 }

@@ -488,6 +488,7 @@ static void cg_rows(slp_admm_cg *s, const double *v, double *w_out = nullptr) {
         return;
     }
     SLP_REQUIRE(!s->rs.p, "deferred row scaling needs the strip format in both orientations");
+    require_csr(s->a, "matrix-free ADMM row product (CSR walk)");
     const int lanes = s->lanes_rows;
     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_rows<L>), dim3(grid_for(s->m * lanes, kBlock)), dim3(kBlock), 0, ctx().stream,
                                                  s->m, a.ptr.p, a.idx.p, a.val.p, v, s->ns ? s->sc.p : nullptr, s->n_o, w));
@@ -517,6 +518,7 @@ static void cg_cols(slp_admm_cg *s, const double *w, double *u_out = nullptr, bo
         strip_spmv(*f, cg_scaled_rows(s, w, s->ws0), u);
     } else {
         SLP_REQUIRE(!s->rs.p, "deferred row scaling needs the strip format in both orientations");
+        require_csr(s->a, "matrix-free ADMM column product (CSR walk)");
         const int lanes = s->lanes_cols;
         SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_cols<L>), dim3(grid_for(s->n_o * lanes, kBlock)), dim3(kBlock), 0,
                                                      ctx().stream, s->n_o, at.ptr.p, at.idx.p, at.val.p, w, u));

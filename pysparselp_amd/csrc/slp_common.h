@@ -250,6 +250,7 @@ struct slp_matrix {
     int format_policy = 0;       // slp_matrix_set_format: 0 auto, 1 no value dictionary (fp64 entries), 2 CSR kernels only
     bool scaled = false;         // the stored values were row-normalised in place by an ADMM setup (not idempotent)
     int borrowers = 0;           // live solvers created *_on this matrix (they hold raw pointers into its copies)
+    int csr_bound = 0;           // those of them whose iterations walk the CSR arrays (slp_matrix_release_csr refuses while > 0)
     bool csr_released = false;   // slp_matrix_release_csr: entries only live in the strip copies (row pointers are kept)
 };
 

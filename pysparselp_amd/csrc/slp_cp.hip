@@ -358,10 +358,18 @@ struct slp_cp {
     DevBuf<double> ell_val_rows, ell_val_cols;
     DevBuf<unsigned char> ell_len_rows, ell_len_cols;
     bool distributed = false;
+    bool csr_bound = false;  // an iteration half walks the CSR arrays of `k` (counted in k->csr_bound for borrowed matrices)
     IterGraph graph;
 };
 
 namespace slp {
+
+// Does the primal half run on the strip copy of K^T?  Not in SEQUENTIAL order with both kinds of rows: there the
+// reference's (c + s_eq) + s_ineq needs the two partial sums of a column apart, which only the CSR walk gives.
+static const StripJds *cp_primal_strips(slp_cp *s) {
+    if (s->distributed || s->m_eq == 0 || s->m_ineq == 0 || s->order != SLP_ORDER_SEQUENTIAL) return fast_format(s->k, true);
+    return nullptr;
+}
 
 static void cp_setup(slp_cp *s) {
     hipStream_t st = ctx().stream;
@@ -414,6 +422,8 @@ static void cp_setup(slp_cp *s) {
                            s->sigma.p);
         SLP_HIP(hipGetLastError());
     }
+    // ELL copies are the solver's own; everything else that is not a strip copy walks the matrix's CSR arrays
+    s->csr_bound = (s->n > 0 && !cp_primal_strips(s) && !s->ell_w_cols) || (s->m > 0 && !fast_format(s->k, false) && !s->ell_w_rows);
 }
 
 static void cp_primal(slp_cp *s, bool store_d) {
@@ -426,6 +436,7 @@ static void cp_primal(slp_cp *s, bool store_d) {
         if (const StripJds *f = fast_format(s->k, true)) {
             strip_spmv(*f, s->y.p, s->pre.p);
         } else {
+            require_csr(s->k, "Chambolle-Pock primal step (CSR walk)");
             const int lanes = s->lanes_cols;
             const int grid = grid_for(s->n * lanes, kBlock);
             SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_colsum_y<L>), dim3(grid), dim3(kBlock), 0, st, s->n, at.ptr.p,
@@ -436,8 +447,7 @@ static void cp_primal(slp_cp *s, bool store_d) {
         hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
                            at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
                            s->m_ineq, opt, s->theta);
-    } else if (const StripJds *f = (s->m_eq == 0 || s->m_ineq == 0 || s->order != SLP_ORDER_SEQUENTIAL) ? fast_format(s->k, true)
-                                                                                                        : nullptr) {
+    } else if (const StripJds *f = cp_primal_strips(s)) {
         // long columns: LDS-tiled K^T y, then the elementwise update.  With both kinds of rows this adds the equality
         // and inequality terms of a column in one chain instead of (c + s_eq) + s_ineq: rounding only, and only
         // outside SEQUENTIAL order
@@ -456,6 +466,7 @@ static void cp_primal(slp_cp *s, bool store_d) {
         else SLP_ELL_PRIMAL(16);
 #undef SLP_ELL_PRIMAL
     } else {
+        require_csr(s->k, "Chambolle-Pock primal step (CSR walk)");
         const int lanes = s->lanes_cols;
         const int grid = grid_for(s->n * lanes, kBlock);
         SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_primal<L, false>), dim3(grid), dim3(kBlock), 0, st, s->n, at.ptr.p,
@@ -488,6 +499,7 @@ static void cp_dual(slp_cp *s) {
         SLP_HIP(hipGetLastError());
         return;
     }
+    require_csr(s->k, "Chambolle-Pock dual step (CSR walk)");
     const int lanes = s->lanes_rows;
     const int grid = grid_for(s->m * lanes, kBlock);
     SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_dual<L>), dim3(grid), dim3(kBlock), 0, ctx().stream, s->m, a.ptr.p,
@@ -557,6 +569,7 @@ slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const dou
         require_csr(a, "slp_cp_create_on");  // the preconditioners are sums over the CSR entries
         slp_cp *s = cp_make(a, false, m_eq, b, c, lb, ub, x0, alpha, theta, order);
         ++a->borrowers;
+        if (s->csr_bound) ++a->csr_bound;
         return s;
     })
 }
@@ -564,7 +577,10 @@ slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const dou
 void slp_cp_destroy(slp_cp *s) {
     if (!s) return;
     if (s->owns_k) delete s->k;
-    else --s->k->borrowers;
+    else {
+        --s->k->borrowers;
+        if (s->csr_bound) --s->k->csr_bound;
+    }
     delete s;
 }
 

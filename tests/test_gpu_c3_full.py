@@ -1,14 +1,19 @@
 """BASELINE config 3 at FULL size (1e6 variables x 2e6 inequality rows, density 1e-3, ~2e9 stored entries) and one
 matrix with more than 2^31 stored entries, inside ``pytest -m gpu``.
 
-No CPU run is affordable at this size, so parity is established through
+Parity at this size is established through
   (i)   bit-for-bit agreement of the three kernel families on the full products: value-dictionary strips, fp64 strips
         and the thread-per-row CSR kernel ``k_spmv<1>`` (every one of them sums a row with a single accumulator in
         storage order; ``k_spmv<1>`` is pinned bit-exactly to the oracle at small sizes in test_gpu_parity.py),
   (ii)  the oracle itself on downloaded slices: 2048 rows of A and 2048 rows of the device-built A^T,
   (iii) the adjoint identity <A x, y> = <x, A^T y>,
   (iv)  solver runs: two runs bit-identical, objective after 50 iterations equal to the recorded convergence run
-        (profiles/r01_c3_convergence.json).
+        (profiles/r01_c3_convergence.json) -- a regression check against an earlier GPU run, not a parity claim,
+  (v)   WHOLE SOLVERS against the CPU oracle on the full matrix (downloaded once, ~24 GB): Chambolle-Pock iterates bit for
+        bit, matrix-free ADMM (the bench's reuse level 4) to 1e-9 per entry and 1e-6 relative in the objective
+        (north_star's gate), on the value-dictionary strips and on the general fp64 strips.  The oracle's loops over
+        independent rows / columns run multi-threaded there (bit-identical to its one-thread = reference order,
+        tests/test_oracle_golden.py::test_oracle_threads_do_not_change_a_bit); needs ~250 GB of host memory (skips below).
 """
 import json
 import os
@@ -154,3 +159,81 @@ def test_more_than_2_31_stored_entries():
             assert np.array_equal(oracle.matvec(oracle.as_csr(sl), y), aty[c0:c0 + 4096])
     finally:
         a.close()
+
+
+def _mem_available_gb():
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            return int(line.split()[1]) / 2 ** 20
+    return 0.0
+
+
+def test_c3_whole_solvers_match_the_cpu_oracle_at_full_size(c3):
+    """(v) of the module docstring.  Reference: ChambollePockPPD.py:195-343; ADMM.py:143-268 with the use_cg flags
+    (:182-201) + conjugateGradientLinearSolver.py:30-52, restated in oracle/oracle.py and pinned by tests/golden."""
+    import time
+
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    a, xf, c, lb, ub, b = c3
+    if _mem_available_gb() < 250:
+        pytest.skip("less than 250 GB of host memory available for the full-size oracle run")
+    cp_iters, admm_iters = 6, 5
+    record = {"n": N, "m": M, "stored_entries": a.nnz, "oracle_threads": min(64, os.cpu_count() or 1)}
+    oracle.set_threads(record["oracle_threads"])
+    try:
+        t0 = time.perf_counter()
+        host = oracle.as_csr(a.download())
+        record["download_seconds"] = time.perf_counter() - t0
+        # ---- Chambolle-Pock: every kernel on this path sums in the reference's order -> bit for bit
+        stamps = []
+        t0 = time.perf_counter()
+        x_cpu, _ = oracle.chambolle_pock_ppd(c, None, None, host, None, b, lb, ub, nb_max_iter=cp_iters, nb_iter_plot=10 ** 9,
+                                             iterate_hook=lambda *_: stamps.append(time.perf_counter()))
+        record["chambolle_pock_ppd"] = {"iterations": cp_iters, "oracle_setup_seconds": stamps[0] - t0,
+                                        "oracle_seconds_per_iteration": float(np.mean(np.diff(stamps))),
+                                        "objective_oracle": float(c.dot(x_cpu))}
+        host._csc = None  # 24 GB back before the ADMM chain builds its own copies
+        for policy in (0, 1):  # value-dictionary strips, fp64 strips
+            a.set_format(policy)
+            s = DeviceCP(a, b, c, lb, ub)
+            s.iterate(cp_iters)
+            x_gpu = s.x()
+            s.close()
+            assert np.array_equal(x_gpu, x_cpu), (policy, float(np.max(np.abs(x_gpu - x_cpu))))
+        a.set_format(0)
+        record["chambolle_pock_ppd"]["objective_gpu"] = float(c.dot(x_gpu))
+        # ---- matrix-free ADMM at the bench's reuse level (4): same mathematics, dot products and recurrences round
+        # differently -> 1e-9 per entry, 1e-6 relative in the objective (north_star)
+        stamps = []
+        t0 = time.perf_counter()
+        x_cpu = oracle.lp_admm_cg(c, None, None, host, None, b, lb, ub, nb_iter=admm_iters - 1, nb_iter_plot=10 ** 9,
+                                  iterate_hook=lambda *_: stamps.append(time.perf_counter()))
+        record["admm"] = {"iterations": admm_iters, "oracle_setup_seconds": stamps[0] - t0,
+                          "oracle_seconds_per_iteration": float(np.mean(np.diff(stamps))), "objective_oracle": float(c.dot(x_cpu))}
+        del host
+        obj = float(c.dot(x_cpu))
+        for policy in (0, 1):
+            # policy 1 scales the rows in place (no dictionary): a matrix of its own
+            mat = a if policy == 0 else random_lp_on_device(N, M, P, seed=SEED)[0]
+            mat.set_format(policy)
+            s = DeviceADMM(mat, b, c, lb, ub)
+            assert s.reuse == 4
+            s.iterate(admm_iters)
+            x_gpu = s.x(N)
+            s.close()
+            if policy == 1:
+                mat.close()
+            err = float(np.max(np.abs(x_gpu - x_cpu) / (1 + np.abs(x_cpu))))
+            record["admm"][f"max_scaled_error_policy{policy}"] = err
+            assert err <= 1e-9, (policy, err)
+            assert abs(float(c.dot(x_gpu)) - obj) <= 1e-6 * abs(obj), (policy, float(c.dot(x_gpu)), obj)
+        record["admm"]["objective_gpu"] = float(c.dot(x_gpu))
+    finally:
+        oracle.set_threads(1)
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "c3_full_oracle_parity.json"), "w") as f:
+        json.dump(record, f, indent=1)

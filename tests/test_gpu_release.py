@@ -87,3 +87,38 @@ def test_matrix_guards_raise_clear_errors():
     with pytest.raises(_lib.SlpError, match="already row-normalised"):
         DeviceADMM(a, b, c, lb, ub)           # the matrix now holds scaled values: scaling again would solve another LP
     a.close()
+
+
+def test_release_is_refused_while_a_solver_iterates_on_the_csr_arrays():
+    """Chambolle-Pock in SEQUENTIAL order with equality AND inequality rows keeps the two partial sums of a
+    column apart ((c + s_eq) + s_ineq, ChambollePockPPD.py:206,216), which only the CSR walk gives -- such a solver pins the
+    CSR arrays: the release is refused while it lives, and works (iterates unchanged) for the strip-only orders."""
+    from pysparselp_amd import _lib
+    from pysparselp_amd._lib import ORDER_SEQUENTIAL
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    os.environ["SLP_STRIP_MIN_NNZ"] = "1"
+    try:
+        a, xf, c, lb, ub, b = random_lp_on_device(30000, 40000, 0.001, seed=7)
+        b_eq = b.copy()
+        b_eq[:5000] = a.matvec(xf)[:5000]          # the first 5000 rows as equalities through the feasible point
+        seq = DeviceCP(a, b_eq, c, lb, ub, order=ORDER_SEQUENTIAL, m_eq=5000)
+        seq.iterate(5)
+        x5 = seq.x()
+        with pytest.raises(_lib.SlpError, match="iterates on its CSR arrays"):
+            a.release_csr()
+        seq.iterate(5)                              # still on intact arrays
+        x10 = seq.x()
+        seq.close()
+        auto = DeviceCP(a, b_eq, c, lb, ub, m_eq=5000)
+        auto.iterate(5)
+        a.release_csr()                             # strip-only solver: allowed
+        auto.iterate(5)
+        y10 = auto.x()
+        auto.close()
+        assert not np.array_equal(x5, x10)
+        assert np.allclose(x10, y10, rtol=1e-9, atol=1e-12)   # same iteration, one chain instead of two partial sums
+        a.close()
+    finally:
+        del os.environ["SLP_STRIP_MIN_NNZ"]
