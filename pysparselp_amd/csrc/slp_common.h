@@ -223,7 +223,15 @@ struct StripJds {
     int rpl = 2;                  // sorted positions per lane: 2 (pairs, 2048-row blocks) or 4 (quads, 4096-row blocks)
     DevBuf<unsigned short> ent;   // [2 * nnz]
     const double *dict = nullptr; // [D] sorted distinct values (owned by the slp_matrix)
+    // tall cells (slp_tall.hip): row blocks of tall_R rows x strips of 4096 columns, packets of <= 1024 non-empty rows
+    bool tall = false;
+    int tall_R = 0;
+    DevBuf<i64> tall_base;            // [B + 1] first payload word of every row block
+    DevBuf<i64> tall_pkt;             // [B + 1] first packet of every row block
+    DevBuf<unsigned int> tall_dir;    // [packets * 8] 32-byte packet headers
+    DevBuf<unsigned int> tall_pay;    // payload words
 };
+constexpr int kTallRmax = 9984;       // most rows of a tall-cell row block (their running sums: 78 KB of LDS)
 // sorted distinct stored values of a matrix, when there are at most kDictMax of them
 struct ValueDict {
     int state = -1;                       // -1 not looked at, 0 too many distinct values, 1 available
@@ -236,6 +244,9 @@ bool strip_wanted(const CsrDev &a, int variant);   // variant: 0 fp64 entries, 1
 bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int variant);
 void strip_spmv(const StripJds &f, const double *x, double *out);
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1);  // one pass, two vectors
+bool tall_wanted(const CsrDev &a);   // long rows that are sparse inside every LDS-sized window (slp_tall.hip)
+bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict);
+void tall_spmv(const StripJds &f, const double *x, double *out);
 
 }  // namespace slp
 

@@ -196,6 +196,8 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
         if (ev && (ev[0] == '1' || ev[0] == '2')) variant = ev[0] - '0';
         else if (variant == 2 && !strip_wanted(a, 2) && strip_wanted(a, 1)) variant = 1;  // too sparse for the narrower quad strips
         const bool dict = strip_wanted(a, variant) && matrix_dictionary(m);
+        // long rows that are sparse inside every LDS-sized window (the slice of a 1e7-variable LP): tall cells
+        if (!dict && tall_wanted(a) && matrix_dictionary(m) && tall_build(a, f, &m->vdict)) return &f;
         if (dict) strip_build(a, f, &m->vdict, variant);
         else if (strip_wanted(a, 0)) strip_build(a, f, nullptr, 0);
         else if (strip_wanted(a, 3))  // long rows over a width far beyond an L2: wide strips, x gathered from L2
@@ -582,6 +584,7 @@ int slp_matrix_spmv_kernel(slp_matrix *m, int transposed) {
         SLP_REQUIRE(m, "slp_matrix_spmv_kernel: NULL matrix");
         const StripJds *f = fast_format(m, transposed != 0);
         if (!f) return 0;
+        if (f->tall) return 6;
         if (f->wide) return f->D > 0 ? 4 : 5;
         return f->D > 0 ? (f->rpl == 4 ? 3 : 2) : 1;
     } catch (const std::exception &e) {
@@ -596,6 +599,9 @@ int64_t slp_matrix_format_bytes(slp_matrix *m, int transposed) {
         const StripJds *f = fast_format(m, transposed != 0);
         const CsrDev &a = transposed ? m->at : m->a;
         if (!f) return (int64_t)(12 * a.nnz + 8 * (a.nrow + 1));
+        if (f->tall)
+            return (int64_t)((f->tall_pay.n + f->tall_dir.n) * sizeof(unsigned int) + (f->tall_base.n + f->tall_pkt.n) * sizeof(i64) +
+                             (size_t)f->D * sizeof(double));
         const size_t entries = f->D > 0 ? f->ent.n * sizeof(unsigned short) + (size_t)f->D * sizeof(double)
                                         : f->val.n * sizeof(double) + f->col.n * sizeof(unsigned short);
         return (int64_t)(entries + f->perm.n * sizeof(unsigned short) + f->slen.n + f->soff.n * sizeof(unsigned int) +

@@ -951,6 +951,10 @@ static void wide_launch(const StripJds &f, int nv, const double *x0, const doubl
 }
 
 void strip_spmv(const StripJds &f, const double *x, double *out) {
+    if (f.tall) {
+        tall_spmv(f, x, out);
+        return;
+    }
     if (f.wide) {
         wide_launch(f, 1, x, x, f.S > 1 ? f.part.p : out, nullptr);
         if (f.S > 1)
@@ -1016,7 +1020,7 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
 }
 
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1) {
-    if (f.wide) {
+    if (f.wide || f.tall) {
         // two strips of x would compete for the L2: two passes
         strip_spmv(f, x0, out0);
         strip_spmv(f, x1, out1);
