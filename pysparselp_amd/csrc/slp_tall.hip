@@ -7,26 +7,28 @@
 // 2048 rows -- fine at >= 3 entries per (row, strip), hopeless at 0.4; the wide strips that replaced them there gather
 // every x from L2 (one 64-byte request per entry: 2e11 requests/s, 0.10 of the HBM peak).  Here the cell is TALL: a
 // workgroup owns R ~ 10^4 rows (their R running sums live in LDS, 78 KB) and walks strips of 4096 columns (the x-tile,
-// double-buffered, 64 KB of LDS), so that a cell holds ~4000 entries although a row has < 1.  Only rows that HAVE
-// entries in a cell appear in it:
+// double-buffered, 64 KB of LDS), so that a cell holds ~4000 entries although a row has < 1.
 //
-//   cell (row block b, strip t)  =  "packets" of <= 1024 positions; a position is one row with 1..6 of its entries
-//   packet payload (uint32 words) = [ perm: local row of every position, uint16 x cnt0 ]
-//                                   [ slot 0: first entry of every position, cnt0 words ] [ slot 1: cnt1 words ] ...
-//   entry word                    = value id (11 bits) | column inside the strip (12 bits) << 11
-//   positions are sorted by their entry count (descending), so slot s is a prefix of the positions: lane p of the
-//   workgroup reads word p of every slot it takes part in -- coalesced, no per-row lengths stored.
+//   item (5 bytes)  = value id (11 bits) | column inside the strip (12 bits) << 11 | local row (14 bits) << 23
+//                     -- self-describing: no per-row metadata, rows without entries in a cell cost nothing
+//   cell            = the items of its non-empty rows, every row handed WHOLE to one of the 1024 lanes (rows sorted by
+//                     their entry count, dealt round by round: lane p takes sorted positions p, p + 1024, ...), so a
+//                     lane's list is its rows' entries in storage order and list lengths never increase with p
+//   packet          = 8 consecutive list positions ("slots") of all lanes: slot k holds item k of every lane whose
+//                     list is longer than k -- a prefix of the lanes -- so lane p reads word p of the slot: coalesced,
+//                     no lengths stored.  Low 4 bytes of the items slot by slot, then the fifth bytes, four slots to
+//                     a word.  32-byte header: payload offset, the 8 slot widths, the x-tile it carries.
 //
-// Per stored entry: 4 bytes + 2 bytes per non-empty (row, cell) (~5.6 B at 0.4 entries per (row, strip)); the 32-byte
-// packet headers are < 1 %.  A row's entries keep their column order (strips ascending, storage order inside a cell)
-// and every row is accumulated by ONE thread at a time starting from its running sum: the result is the sequential
-// single-accumulator CSR row sum, bit for bit, for ANY number of row blocks -- R is chosen so that the row blocks are
-// a multiple of the CU count (no strips split over workgroups, no partial sums re-associated).
+// A lane adds its items into the running sums in order: `acc[row] += value * x[col]`, one row after the other, so every
+// row is accumulated by ONE lane per cell, cells in strip order: the result is the sequential single-accumulator CSR
+// row sum, bit for bit, for ANY number of row blocks -- R is chosen so that the row blocks are a multiple of the CU
+// count (no strips split over workgroups, no partial sums re-associated).
 //
-// The kernel is a software pipeline over packets: the payload of packet j + 4 and the header of packet j + 8 are
-// being loaded while packet j is consumed; every global load is unconditional (lanes without work re-read word 0),
-// so the compiler counts what is in flight (s_waitcnt vmcnt(N), never 0), and the x-tile of the NEXT cell arrives as
-// 16 KB chunks riding on the packets of the current one.  One barrier per cell.
+// The kernel is a software pipeline over packets (typically one per cell): the payload of packet j + 4 and the header
+// of packet j + 8 are being loaded while packet j is consumed; every global load is unconditional (lanes without work
+// address past the end of the buffer descriptor: no memory request), so the compiler counts what is in flight
+// (s_waitcnt vmcnt(N), never 0), and the x-tile of the NEXT cell rides on the first packet of the current one.
+// One barrier per cell.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -39,10 +41,11 @@
 namespace slp {
 
 constexpr int kTallC = 4096;       // columns per strip (12-bit column inside the strip); 32 KB of x
-constexpr int kTallT = 1024;       // threads per workgroup = positions per packet
-constexpr int kTallSlots = 6;      // entries of one row inside one packet (longer runs continue in later packets)
+constexpr int kTallT = 1024;       // threads per workgroup = lanes a cell's rows are dealt to
+constexpr int kTallSlots = 8;      // list positions per packet
 constexpr int kTallDepth = 4;      // packets of payload in flight per lane; headers run 2 x this ahead
 constexpr int kTallDictMax = 2048;
+constexpr int kTallBuckets = 6;    // rows are ordered by min(entries in the cell, 6), descending
 constexpr int kTallIdBits = 11, kTallColBits = 12, kTallRowBits = 14;
 constexpr int kTallCellShift = kTallIdBits + kTallColBits + kTallRowBits;  // sort key: cell | row | column | id
 static_assert(kTallRmax < (1 << kTallRowBits) && kTallC == (1 << kTallColBits) && kTallDictMax == (1 << kTallIdBits), "tall geometry");
@@ -50,15 +53,14 @@ static_assert(kTallRmax < (1 << kTallRowBits) && kTallC == (1 << kTallColBits) &
 static_assert(kTallRmax * 8 + kTallDictMax * 8 + 2 * kTallC * 8 <= 160 * 1024, "tall cells: LDS budget");
 
 constexpr unsigned int kPktNewCell = 0x80000000u;  // first packet of a cell: barrier, then the other x-tile
-constexpr unsigned int kPktBarrier = 0x40000000u;  // a row of this packet continues from an earlier packet of the cell
-constexpr unsigned int kNoChunk = 0xffffffffu;
+constexpr unsigned int kNoTile = 0x7fffffffu;
+constexpr unsigned int kOob = 0xffffff00u;         // byte offset past every buffer descriptor: the load returns 0, no request
 
 // 32-byte packet header (8 dwords; lane l & 7 of a wave loads dword l & 7)
 struct TallPkt {
     unsigned int off;     // payload offset of the packet inside its row block (words)
-    unsigned int flags;   // kPktNewCell | kPktBarrier
-    unsigned int c01, c23, c45;  // cnt[s] = positions of the packet with more than s entries, 16 bits each (cnt[0] = positions)
-    unsigned int xsrc;    // first column of the 2048-column chunk of x this packet carries for the NEXT cell, or kNoChunk
+    unsigned int xsrc;    // kPktNewCell | first column of the strip whose x-tile this packet carries for the NEXT cell (or kNoTile)
+    unsigned int c[4];    // c[i] = w[2i] | w[2i+1] << 16,  w[k] = lanes whose list is longer than slot k of this packet
     unsigned int strip;   // strip index (diagnostics)
     unsigned int pad;
 };
@@ -143,28 +145,26 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
                                                        TallPkt *__restrict__ dir, unsigned int *__restrict__ payload) {
     __shared__ unsigned int cnt[kTallRmax];       // entries of the row inside the cell
     __shared__ unsigned int rstart[kTallRmax];    // position of the row's first entry inside the cell
-    __shared__ unsigned short posrow[kTallRmax];  // sorted position -> local row (one level at a time)
+    __shared__ unsigned short posrow[kTallRmax];  // sorted position -> local row
+    __shared__ unsigned int nlane[kTallT];        // list length of every lane (non-increasing)
     __shared__ unsigned long long wtot[kTallT / kWave];
-    __shared__ unsigned int smax;
+    __shared__ unsigned int width[kTallSlots];
     const int p = threadIdx.x;
     const i64 b = blockIdx.x;
-    const int rpt = (R + kTallT - 1) / kTallT;  // consecutive rows per thread in the sorting passes
+    const int rpt = (R + kTallT - 1) / kTallT;  // consecutive rows per thread in the sorting pass
     unsigned int *pay = WRITE ? payload + blk_base[b] : nullptr;
     TallPkt *pk = WRITE ? dir + pkt_ptr[b] : nullptr;
     i64 woff = 0, npk = 0;  // running payload offset / packet count of the row block (uniform)
 
-    auto empty_packet = [&](unsigned int xsrc, unsigned int strip) {
+    auto empty_packet = [&](unsigned int xsrc) {
         if (WRITE && p == 0) {
             TallPkt h;
-            h.off = (unsigned int)woff; h.flags = 0; h.c01 = h.c23 = h.c45 = 0; h.xsrc = xsrc; h.strip = strip; h.pad = 0;
+            h.off = (unsigned int)woff; h.xsrc = xsrc; h.c[0] = h.c[1] = h.c[2] = h.c[3] = 0; h.strip = 0; h.pad = 0;
             pk[npk] = h;
         }
         ++npk;
     };
-    auto chunk_of = [&](i64 t, int half) -> unsigned int {  // the half-strip `half` of strip t, if it has any column
-        const i64 c0 = t * (i64)kTallC + (i64)half * (kTallC / 2);
-        return (t >= 0 && c0 < ncol) ? (unsigned int)c0 : kNoChunk;
-    };
+    auto tile_of = [&](i64 t) -> unsigned int { return t >= 0 ? (unsigned int)(t * (i64)kTallC) : kNoTile; };
     auto next_cell = [&](i64 t) -> i64 {  // first strip > t with entries in this row block, or -1
         for (i64 u = t + 1; u < T; ++u)
             if (cellptr[b * T + u + 1] > cellptr[b * T + u]) return u;
@@ -172,15 +172,12 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
     };
 
     i64 t = next_cell(-1);
-    // the x-tile of the first cell rides on two leading packets without positions
-    empty_packet(chunk_of(t, 0), 0);
-    empty_packet(chunk_of(t, 1), 0);
+    empty_packet(tile_of(t));  // the x-tile of the first cell rides on a leading packet without items
     while (t >= 0) {
         const i64 tn = next_cell(t);
         const i64 c0 = cellptr[b * T + t];
         const int n = (int)(cellptr[b * T + t + 1] - c0);
         for (int r = p; r < R; r += kTallT) cnt[r] = 0;
-        if (p == 0) smax = 0;
         __syncthreads();
         for (int i = p; i < n; i += kTallT) {
             const unsigned int r = (unsigned int)(keys[c0 + i] >> (kTallIdBits + kTallColBits)) & ((1u << kTallRowBits) - 1);
@@ -189,106 +186,136 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
             atomicAdd(&cnt[r], 1u);
         }
         __syncthreads();
-        {
-            unsigned int m = 0;
-            for (int r = p; r < R; r += kTallT) m = cnt[r] > m ? cnt[r] : m;
-            for (int off = 32; off > 0; off >>= 1) { const unsigned int o = __shfl_down(m, off, kWave); m = o > m ? o : m; }
-            if ((p & (kWave - 1)) == 0) atomicMax(&smax, m);
+        // sorted positions: rows with entries, by min(count, 6) descending, rows in increasing order inside a class
+        unsigned long long ha = 0, hb = 0;  // counters of the classes 6,5,4 (21 bits each) / 3,2,1
+        const int r0 = p * rpt, r1 = (r0 + rpt < R) ? r0 + rpt : R;
+        for (int r = r0; r < r1; ++r) {
+            const unsigned int c = cnt[r];
+            if (c) {
+                const unsigned int cl = c < (unsigned)kTallBuckets ? c : kTallBuckets;
+                if (cl > 3) ha += 1ull << (21 * (kTallBuckets - cl));
+                else hb += 1ull << (21 * (3 - cl));
+            }
+        }
+        unsigned long long ta, tb;
+        unsigned long long ea = tall_block_scan(ha, wtot, &ta), eb = tall_block_scan(hb, wtot, &tb);
+        unsigned int start[kTallBuckets + 1], npos = 0;
+        for (int cl = kTallBuckets; cl >= 1; --cl) {
+            start[cl] = npos;
+            npos += (unsigned int)(((cl > 3 ? ta : tb) >> (21 * ((cl > 3 ? kTallBuckets : 3) - cl))) & 0x1fffffu);
+        }
+        for (int r = r0; r < r1; ++r) {
+            const unsigned int c = cnt[r];
+            if (c) {
+                const unsigned int cl = c < (unsigned)kTallBuckets ? c : kTallBuckets;
+                unsigned int within;
+                if (cl > 3) { within = (unsigned int)((ea >> (21 * (kTallBuckets - cl))) & 0x1fffffu); ea += 1ull << (21 * (kTallBuckets - cl)); }
+                else { within = (unsigned int)((eb >> (21 * (3 - cl))) & 0x1fffffu); eb += 1ull << (21 * (3 - cl)); }
+                posrow[start[cl] + within] = (unsigned short)r;
+            }
         }
         __syncthreads();
-        const unsigned int maxcnt = smax;
-        for (unsigned int lev = 0; lev * kTallSlots < maxcnt; ++lev) {
-            // positions of this level = rows with more than 6 * lev entries, sorted by the length of their piece (6 .. 1),
-            // rows in increasing order inside a length
-            unsigned long long ha = 0, hb = 0;  // counters of lengths 6,5,4 (21 bits each) / 3,2,1
-            const int r0 = p * rpt, r1 = (r0 + rpt < R) ? r0 + rpt : R;
-            for (int r = r0; r < r1; ++r) {
-                const unsigned int c = cnt[r];
-                if (c > lev * kTallSlots) {
-                    const unsigned int len = (c - lev * kTallSlots < (unsigned)kTallSlots) ? c - lev * kTallSlots : kTallSlots;
-                    if (len > 3) ha += 1ull << (21 * (kTallSlots - len));
-                    else hb += 1ull << (21 * (3 - len));
+        // lane p takes sorted positions p, p + 1024, ...: counts never increase along the positions of a class order,
+        // so the list lengths never increase with p -- EXCEPT inside class 6 (counts >= 6 in row order): lengths are
+        // made monotone by construction below only if that class is ordered; it is handled by taking the running
+        // maximum from the right (a lane's slot widths only need to cover its list)
+        unsigned int mine = 0;
+        for (unsigned int pos = p; pos < npos; pos += kTallT) mine += cnt[posrow[pos]];
+        nlane[p] = mine;
+        __syncthreads();
+        // cover[p] = max over lanes >= p of their list lengths: a non-increasing envelope; slot k is as wide as the
+        // lanes whose ENVELOPE exceeds k (lanes inside the envelope without an item there store a skip item)
+        unsigned int cover = mine;
+        {
+            // suffix maximum over the 1024 lanes: inside the wave by shuffles, across waves through LDS
+            const int lane = p & (kWave - 1), w = p / kWave;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const unsigned int o = __shfl_down(cover, off, kWave);
+                if (lane + off < kWave) cover = o > cover ? o : cover;
+            }
+            if (lane == 0) wtot[w] = cover;
+            __syncthreads();
+            unsigned int right = 0;
+            for (int i = w + 1; i < kTallT / kWave; ++i) right = (unsigned int)wtot[i] > right ? (unsigned int)wtot[i] : right;
+            cover = right > cover ? right : cover;
+            __syncthreads();
+        }
+        nlane[p] = cover;
+        __syncthreads();
+        const unsigned int longest = nlane[0];
+        // the lane's cursor over its own list: row round q (position p + 1024 q), entry s of that row
+        unsigned int q = 0, s = 0;
+        unsigned int myrow = (unsigned)p < npos ? posrow[p] : 0u, mycnt = (unsigned)p < npos ? cnt[myrow] : 0u;
+        for (unsigned int g = 0; g * kTallSlots < longest || g == 0; ++g) {
+            // slot widths of this packet: width[j] = first lane whose envelope is <= 8 g + j (binary search, lanes 0..7)
+            if (p < kTallSlots) {
+                const unsigned int k = g * kTallSlots + p;
+                int lo = 0, hi = kTallT;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (nlane[mid] > k) lo = mid + 1;
+                    else hi = mid;
                 }
+                width[p] = (unsigned int)lo;
             }
-            unsigned long long ta, tb;
-            unsigned long long ea = tall_block_scan(ha, wtot, &ta), eb = tall_block_scan(hb, wtot, &tb);
-            unsigned int tot[kTallSlots + 1], start[kTallSlots + 1], g[kTallSlots];  // by length
-            for (int len = kTallSlots; len >= 1; --len)
-                tot[len] = (unsigned int)(((len > 3 ? ta : tb) >> (21 * ((len > 3 ? kTallSlots : 3) - len))) & 0x1fffffu);
-            unsigned int run = 0;
-            for (int len = kTallSlots; len >= 1; --len) { start[len] = run; run += tot[len]; }
-            for (int s = 0; s < kTallSlots; ++s) {  // g[s] = positions with more than s entries
-                unsigned int c = 0;
-                for (int len = s + 1; len <= kTallSlots; ++len) c += tot[len];
-                g[s] = c;
-            }
-            const unsigned int npos = g[0];
+            __syncthreads();
+            unsigned int wd[kTallSlots], words = 0;
+            for (int j = 0; j < kTallSlots; ++j) { wd[j] = width[j]; words += wd[j]; }
+            const unsigned int hi0 = words, hi1 = words + wd[0];
+            words += wd[0] + wd[4];
             if (WRITE) {
-                for (int r = r0; r < r1; ++r) {
-                    const unsigned int c = cnt[r];
-                    if (c > lev * kTallSlots) {
-                        const unsigned int len = (c - lev * kTallSlots < (unsigned)kTallSlots) ? c - lev * kTallSlots : kTallSlots;
-                        unsigned int within;
-                        if (len > 3) { within = (unsigned int)((ea >> (21 * (kTallSlots - len))) & 0x1fffffu); ea += 1ull << (21 * (kTallSlots - len)); }
-                        else { within = (unsigned int)((eb >> (21 * (3 - len))) & 0x1fffffu); eb += 1ull << (21 * (3 - len)); }
-                        posrow[start[len] + within] = (unsigned short)r;
-                    }
-                }
-                __syncthreads();
-            }
-            unsigned int npkt = (npos + kTallT - 1) / kTallT;
-            if (lev == 0 && npkt < 2) npkt = 2;  // two packets at least: they carry the two halves of the next cell's x-tile
-            for (unsigned int q = 0; q < npkt; ++q) {
-                unsigned int c[kTallSlots];
-                for (int s = 0; s < kTallSlots; ++s) {
-                    const unsigned int lo = q * kTallT;
-                    c[s] = g[s] > lo ? (g[s] - lo < (unsigned)kTallT ? g[s] - lo : kTallT) : 0u;
-                }
-                unsigned int words = (c[0] + 1) >> 1;
-                if (WRITE) {
-                    const unsigned int pos = q * kTallT + p;
-                    if (pos < npos) {
-                        const unsigned int r = posrow[pos];
-                        const unsigned int len = (cnt[r] - lev * kTallSlots < (unsigned)kTallSlots) ? cnt[r] - lev * kTallSlots : kTallSlots;
-                        unsigned int *base = pay + woff;
-                        reinterpret_cast<unsigned short *>(base)[p] = (unsigned short)r;
-                        unsigned int so = words;
-                        const unsigned long long *src = keys + c0 + rstart[r] + lev * kTallSlots;
-                        for (unsigned int s = 0; s < len; ++s) {
-                            base[so + p] = (unsigned int)src[s] & ((1u << (kTallIdBits + kTallColBits)) - 1);
-                            so += c[s];
+                unsigned int *base = pay + woff;
+                unsigned int hb0 = 0, hb1 = 0, so = 0;
+                for (int j = 0; j < kTallSlots; ++j) {
+                    if ((unsigned)p < wd[j]) {
+                        unsigned int item = 0, hib = 0x80u;  // skip item: a lane inside the envelope whose list has ended
+                        if (q * kTallT + p < npos) {
+                            const unsigned long long key = keys[c0 + rstart[myrow] + s];
+                            item = ((unsigned int)key & ((1u << (kTallIdBits + kTallColBits)) - 1)) | ((myrow & 0x1ffu) << 23);
+                            hib = myrow >> 9;
+                            if (++s == mycnt) {
+                                ++q; s = 0;
+                                const unsigned int pos = q * kTallT + p;
+                                myrow = pos < npos ? posrow[pos] : 0u;
+                                mycnt = pos < npos ? cnt[myrow] : 0u;
+                            }
                         }
+                        base[so + p] = item;
+                        if (j < 4) hb0 |= hib << (8 * j);
+                        else hb1 |= hib << (8 * (j - 4));
                     }
-                    if (p == 0) {
-                        TallPkt h;
-                        h.off = (unsigned int)woff;
-                        h.flags = (q == 0) ? (lev == 0 ? kPktNewCell : kPktBarrier) : 0u;
-                        h.c01 = c[0] | (c[1] << 16); h.c23 = c[2] | (c[3] << 16); h.c45 = c[4] | (c[5] << 16);
-                        h.xsrc = (lev == 0 && q < 2) ? chunk_of(tn, (int)q) : kNoChunk;
-                        h.strip = (unsigned int)t;
-                        h.pad = 0;
-                        pk[npk] = h;
-                    }
+                    so += wd[j];
                 }
-                for (int s = 0; s < kTallSlots; ++s) words += c[s];
-                woff += words;
-                ++npk;
+                if ((unsigned)p < wd[0]) base[hi0 + p] = hb0;
+                if ((unsigned)p < wd[4]) base[hi1 + p] = hb1;
+                if (p == 0) {
+                    TallPkt h;
+                    h.off = (unsigned int)woff;
+                    h.xsrc = (g == 0) ? (kPktNewCell | tile_of(tn)) : kNoTile;
+                    for (int i = 0; i < 4; ++i) h.c[i] = wd[2 * i] | (wd[2 * i + 1] << 16);
+                    h.strip = (unsigned int)t;
+                    h.pad = 0;
+                    pk[npk] = h;
+                }
             }
-            __syncthreads();  // posrow is rewritten by the next level
+            woff += words;
+            ++npk;
+            __syncthreads();  // width[] is rewritten by the next packet
         }
         t = tn;
     }
     // whole groups of 2 x depth packets, then 2 x depth more that are only ever prefetched
-    while (npk % (2 * kTallDepth)) empty_packet(kNoChunk, 0);
-    for (int i = 0; i < 2 * kTallDepth; ++i) empty_packet(kNoChunk, 0);
+    while (npk % (2 * kTallDepth)) empty_packet(kNoTile);
+    for (int i = 0; i < 2 * kTallDepth; ++i) empty_packet(kNoTile);
     if (!WRITE && p == 0) { sizes[2 * b] = woff; sizes[2 * b + 1] = npk; }
 }
 
 // ---- the product -------------------------------------------------------------------------------------------------------
 struct TallRegs {
-    unsigned int perm;
-    unsigned int e[kTallSlots];
-    double x0, x1;
+    unsigned int lo[kTallSlots];
+    unsigned int hi[2];
+    double x[4];
 };
 
 __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, const i64 *__restrict__ pkt_ptr,
@@ -304,60 +331,73 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     for (int r = p; r < R; r += kTallT) acc[r] = 0.0;
     for (int q = p; q < D; q += kTallT) dv[q] = dict[q];
     const unsigned int *__restrict__ hd = dirw + pkt_ptr[b] * 8 + (p & 7);  // this lane's dword of every header
-    const unsigned int *__restrict__ pay = payload + blk_base[b];
     const int npk = (int)(pkt_ptr[b + 1] - pkt_ptr[b]) - 2 * kTallDepth;      // the last 2 x depth packets are prefetch targets only
-    const i64 xmax = ncol - 1;
+    // buffer descriptors: lanes without work address past num_records (the load returns 0 without a memory request)
+    const __amdgpu_buffer_rsrc_t rs_pay =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(payload + blk_base[b]), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)(ncol * 8), 0x00020000);
     int cur = 0;
 
     TallRegs regs[kTallDepth];
     unsigned int hw[2 * kTallDepth];
 
+    auto widths = [&](unsigned int h, unsigned int *c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned int v = (unsigned int)__builtin_amdgcn_readlane((int)h, 2 + i);
+            c[2 * i] = v & 0xffffu;
+            c[2 * i + 1] = v >> 16;
+        }
+    };
+
     auto issue = [&](TallRegs &g, unsigned int h) {
         const unsigned int off = (unsigned int)__builtin_amdgcn_readlane((int)h, 0);
-        const unsigned int c01 = (unsigned int)__builtin_amdgcn_readlane((int)h, 2), c23 = (unsigned int)__builtin_amdgcn_readlane((int)h, 3),
-                           c45 = (unsigned int)__builtin_amdgcn_readlane((int)h, 4);
-        const unsigned int xsrc = (unsigned int)__builtin_amdgcn_readlane((int)h, 5);
-        const unsigned int c[kTallSlots] = {c01 & 0xffffu, c01 >> 16, c23 & 0xffffu, c23 >> 16, c45 & 0xffffu, c45 >> 16};
-        const unsigned int *__restrict__ w = pay + off;
-        g.perm = reinterpret_cast<const unsigned short *>(w)[(unsigned)p < c[0] ? p : 0];
-        unsigned int so = (c[0] + 1) >> 1;
+        const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
+        unsigned int c[kTallSlots];
+        widths(h, c);
+        unsigned int so = off * 4u;
+        const unsigned int mine = (unsigned int)p * 4u;
 #pragma unroll
-        for (int s = 0; s < kTallSlots; ++s) {
-            g.e[s] = __builtin_nontemporal_load(w + so + ((unsigned)p < c[s] ? p : 0));  // streamed once
-            so += c[s];
+        for (int k = 0; k < kTallSlots; ++k) {
+            g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);  // streamed once
+            so += c[k] * 4u;
         }
-        i64 j = (xsrc == kNoChunk) ? 0 : (i64)xsrc + 2 * p;
-        const i64 j0 = j < xmax ? j : xmax, j1 = j + 1 < xmax ? j + 1 : xmax;
-        g.x0 = x[j0];
-        g.x1 = x[j1];
+        g.hi[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[0] ? mine : kOob, so, 2);
+        so += c[0] * 4u;
+        g.hi[1] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4] ? mine : kOob, so, 2);
+        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 4u * (unsigned int)p) * 8u;  // columns past ncol read 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo, 8 * i, 0);
+            g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
+        }
     };
 
     auto consume = [&](const TallRegs &g, unsigned int h) {
-        const unsigned int flags = (unsigned int)__builtin_amdgcn_readlane((int)h, 1);
-        const unsigned int c01 = (unsigned int)__builtin_amdgcn_readlane((int)h, 2), c23 = (unsigned int)__builtin_amdgcn_readlane((int)h, 3),
-                           c45 = (unsigned int)__builtin_amdgcn_readlane((int)h, 4);
-        const unsigned int xsrc = (unsigned int)__builtin_amdgcn_readlane((int)h, 5);
-        const unsigned int c[kTallSlots] = {c01 & 0xffffu, c01 >> 16, c23 & 0xffffu, c23 >> 16, c45 & 0xffffu, c45 >> 16};
-        if (flags & (kPktNewCell | kPktBarrier)) {
-            // sums of the previous cell (written by other lanes) and the x-tile chunks: LDS only, the loads stay in flight
+        const unsigned int xw = (unsigned int)__builtin_amdgcn_readlane((int)h, 1);
+        unsigned int c[kTallSlots];
+        widths(h, c);
+        if (xw & kPktNewCell) {
+            // sums of the previous cell (other lanes owned these rows there) and the x-tile: LDS only, loads stay in flight
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (flags & kPktNewCell) cur ^= 1;
+            cur ^= 1;
         }
-        if (xsrc != kNoChunk) {
-            double2 v = make_double2(g.x0, g.x1);
-            *reinterpret_cast<double2 *>(&xt[cur ^ 1][(xsrc & (kTallC - 1)) + 2 * p]) = v;
+        if ((xw & 0x7fffffffu) != kNoTile) {
+            double *dst = &xt[cur ^ 1][4 * p];
+            *reinterpret_cast<double2 *>(dst) = make_double2(g.x[0], g.x[1]);
+            *reinterpret_cast<double2 *>(dst + 2) = make_double2(g.x[2], g.x[3]);
         }
-        if (wbase < c[0]) {
-            const bool live = (unsigned)p < c[0];
-            const unsigned int row = live ? g.perm : 0u;
-            double a = acc[row];
-            const double *__restrict__ tile = xt[cur];
-#define SLP_TALL_SLOT(S)                                                                 \
-    {                                                                                    \
-        const unsigned int e = g.e[S];                                                   \
-        const double t = a + dv[e & ((1u << kTallIdBits) - 1)] * tile[(e >> kTallIdBits) & (kTallC - 1)]; \
-        a = ((unsigned)p < c[S]) ? t : a;                                                \
+        const double *__restrict__ tile = xt[cur];
+#define SLP_TALL_SLOT(K)                                                                                   \
+    {                                                                                                      \
+        const unsigned int w = g.lo[K], hb = (g.hi[(K) >> 2] >> (8 * ((K)&3))) & 0xffu;                     \
+        const unsigned int row = (w >> 23) | ((hb & 0x1fu) << 9);                                          \
+        const double a = acc[row];                                                                         \
+        const double t = a + dv[w & ((1u << kTallIdBits) - 1)] * tile[(w >> kTallIdBits) & (kTallC - 1)];  \
+        if ((unsigned)p < c[K] && !(hb & 0x80u)) acc[row] = t;                                             \
     }
+        if (wbase < c[0]) {
             SLP_TALL_SLOT(0)
             if (wbase < c[1]) {
                 SLP_TALL_SLOT(1)
@@ -367,14 +407,19 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
                         SLP_TALL_SLOT(3)
                         if (wbase < c[4]) {
                             SLP_TALL_SLOT(4)
-                            if (wbase < c[5]) SLP_TALL_SLOT(5)
+                            if (wbase < c[5]) {
+                                SLP_TALL_SLOT(5)
+                                if (wbase < c[6]) {
+                                    SLP_TALL_SLOT(6)
+                                    if (wbase < c[7]) SLP_TALL_SLOT(7)
+                                }
+                            }
                         }
                     }
                 }
             }
-#undef SLP_TALL_SLOT
-            if (live) acc[row] = a;
         }
+#undef SLP_TALL_SLOT
     };
 
     // prologue: headers of the first 2 x depth packets, payload of the first depth
@@ -417,6 +462,7 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     hipStream_t st = ctx().stream;
     f = StripJds();
     if (!dict || dict->D <= 0 || dict->D > kTallDictMax || a.nrow == 0 || a.nnz == 0) return false;
+    if (a.ncol * 8 >= ((i64)1 << 31)) return false;  // x is addressed through a buffer descriptor with 32-bit byte offsets
     const int R = tall_rows_per_block(a.nrow);
     const i64 T = (a.ncol + kTallC - 1) / kTallC, B = (a.nrow + R - 1) / R, ncell = B * T;
     unsigned int cellbits = 1;
@@ -452,15 +498,14 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     sizes.download(hs.data(), hs.size());
     hbase[0] = hpkt[0] = 0;
     for (i64 b = 0; b < B; ++b) {
-        SLP_REQUIRE(hs[2 * b] < (i64)0xffffffffll, "tall cells: a row block's payload exceeds 2^32 words");
+        SLP_REQUIRE(hs[2 * b] < ((i64)1 << 29), "tall cells: a row block's payload exceeds 2 GB");
         hbase[b + 1] = hbase[b] + ((hs[2 * b] + 3) & ~(i64)3);  // 16-byte aligned row blocks
         hpkt[b + 1] = hpkt[b] + hs[2 * b + 1];
     }
     f.tall_base.upload(hbase.data(), hbase.size());
     f.tall_pkt.upload(hpkt.data(), hpkt.size());
     f.tall_dir.alloc((size_t)hpkt[B] * 8);
-    f.tall_pay.alloc((size_t)hbase[B] + 2 * (size_t)kTallT * (kTallSlots + 1));  // + room for the clamped loads of empty packets
-    f.tall_pay.zero();
+    f.tall_pay.alloc((size_t)hbase[B] + 64);
     hipLaunchKernelGGL((k_tall_build<true>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, cellptr.p, (i64 *)nullptr,
                        f.tall_base.p, f.tall_pkt.p, reinterpret_cast<TallPkt *>(f.tall_dir.p), f.tall_pay.p);
     SLP_HIP(hipGetLastError());

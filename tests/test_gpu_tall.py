@@ -1,0 +1,127 @@
+"""Tall-cell SpMV (csrc/slp_tall.hip): rows that are long over a width far beyond the caches but sparse inside every
+LDS-sized window -- the per-rank slice of a 1e7-variable LP.  Reference products: ``a * x`` / ``y * a``
+(ChambollePockPPD.py:206,216,235,240; scipy csr_matvec / csc_matvec), restated in oracle/slp_oracle.c.
+
+Bar: bit for bit against the oracle (every row is one sequential chain in storage order) for any number of row blocks,
+incl. rows with more entries in a cell than a packet takes (continuation packets), empty rows / cells / strips, a ragged
+last strip, an odd column count, a single row block; solver iterates through it (Chambolle-Pock bit for bit, ADMM 1e-9).
+The full-size slice (2.5e6 x 1e7, 2.5e9 entries) is in tests/test_gpu_c3_full.py.  -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _small_matrices_take_the_tall_format():
+    os.environ["SLP_STRIP_MIN_NNZ"] = "1"
+    yield
+    del os.environ["SLP_STRIP_MIN_NNZ"]
+    os.environ.pop("SLP_TALL_R", None)
+
+
+def _check(a_host, rows_per_block=None, transposed_too=True):
+    from pysparselp_amd.device import DeviceMatrix
+
+    if rows_per_block:
+        os.environ["SLP_TALL_R"] = str(rows_per_block)
+    else:
+        os.environ.pop("SLP_TALL_R", None)
+    a = DeviceMatrix.from_csr(a_host)
+    try:
+        rng = np.random.RandomState(3)
+        x, y = rng.randn(a_host.shape[1]), rng.randn(a_host.shape[0])
+        assert a.spmv_kernel(False) == 6, a.spmv_kernel(False)
+        assert np.array_equal(a.matvec(x), oracle.matvec(oracle.as_csr(a_host), x))
+        if transposed_too:
+            kern = a.spmv_kernel(True)
+            assert np.array_equal(a.rmatvec(y), oracle.rmatvec(oracle.as_csr(a_host), y)), kern
+            return kern
+    finally:
+        a.close()
+
+
+def _random(m, n, density, seed, decimals=2):
+    rng = np.random.RandomState(seed)
+    a = scipy.sparse.random(m, n, density=density, format="csr", random_state=rng, data_rvs=lambda k: np.round(rng.randn(k), decimals))
+    a.data[a.data == 0] = 0.5
+    a.sort_indices()
+    return a
+
+
+@pytest.mark.parametrize("rows_per_block", [None, 1024, 1500, 9984])
+def test_random_sparse_wide_matrix_matches_the_oracle_bit_for_bit(rows_per_block):
+    a = _random(20000, 50001, 1e-4, 1)            # 5 entries per row over 13 strips (the last one ragged, odd width)
+    kern_t = _check(a, rows_per_block)
+    assert kern_t in (0, 6)                        # the transpose (2 entries per row) may stay on the CSR kernel
+
+
+def test_transpose_of_a_wide_slice_runs_on_tall_cells_too():
+    a = _random(60000, 9000, 3e-4, 2)              # rows: 2.7 entries over 3 strips; columns: 18 entries over 15 strips
+    assert _check(a, 2048) == 6
+
+
+def test_rows_longer_than_a_packet_takes_continue_in_later_packets():
+    rng = np.random.RandomState(4)
+    a = _random(6000, 40000, 1e-4, 5).tolil()
+    for r, (c0, k) in ((7, (100, 40)), (8, (4096 * 3 + 5, 7)), (4000, (4096 * 9 - 13, 30)), (5999, (0, 13))):
+        cols = c0 + np.sort(rng.choice(200, size=k, replace=False))   # k entries inside one or two strips
+        for c in cols:
+            a[r, c] = np.round(rng.randn(), 1) or 0.3
+    a = a.tocsr()
+    a.sort_indices()
+    assert np.diff(a.indptr).max() >= 40
+    _check(a, 1024)
+    _check(a, None)
+
+
+def test_empty_rows_cells_and_strips():
+    a = _random(5000, 70000, 5e-5, 6).tolil()
+    a[100:400, :] = 0                               # empty rows
+    a[:, 4096 * 2:4096 * 5] = 0                     # three empty strips: every row block skips those cells
+    a[1024:2048, 4096 * 7:] = 0                     # a row block whose last cells are empty
+    a = a.tocsr()
+    a.eliminate_zeros()
+    a.sort_indices()
+    _check(a, 1024)
+
+
+def test_one_row_block_and_a_single_strip_of_work():
+    a = _random(900, 30000, 2e-4, 7)
+    _check(a, None, transposed_too=False)           # nrow < 1024: one block of 900 rows
+    b = scipy.sparse.hstack([_random(3000, 3000, 2e-4, 8), scipy.sparse.csr_matrix((3000, 40000))]).tocsr()
+    b.sort_indices()
+    _check(b, 1024, transposed_too=False)           # all entries inside the first strip
+
+
+def test_solvers_iterate_on_tall_cells_like_the_oracle():
+    """Chambolle-Pock bit for bit, matrix-free ADMM (reuse 4, deferred row scaling) to 1e-9, on a reduced-row slice of
+    the 1e7-variable shape: 12 000 rows x 400 000 columns at density 1e-4 (40 entries per row, 0.41 per (row, strip))."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    n, m, dens = 400_000, 12_000, 1e-4
+    os.environ["SLP_TALL_R"] = "1536"
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, dens, seed=3)
+    try:
+        assert a.spmv_kernel(False) == 6 and a.spmv_kernel(True) == 6
+        host = oracle.as_csr(a.download())
+        x_cpu, _ = oracle.chambolle_pock_ppd(c, None, None, host, None, b, lb, ub, nb_max_iter=25, nb_iter_plot=10 ** 9)
+        s = DeviceCP(a, b, c, lb, ub)
+        s.iterate(25)
+        assert np.array_equal(s.x(), x_cpu)
+        s.close()
+        x_cpu = oracle.lp_admm_cg(c, None, None, host, None, b, lb, ub, nb_iter=69, nb_iter_plot=10 ** 9)
+        s = DeviceADMM(a, b, c, lb, ub)
+        s.iterate(70)                                 # across the level-4 refresh at 64
+        x_gpu = s.x(n)
+        s.close()
+        assert float(np.max(np.abs(x_gpu - x_cpu) / (1 + np.abs(x_cpu)))) <= 1e-9
+    finally:
+        a.close()
