@@ -215,16 +215,35 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
             }
         }
         __syncthreads();
-        // lane p takes sorted positions p, p + 1024, ...: counts never increase along the positions of a class order,
-        // so the list lengths never increase with p -- EXCEPT inside class 6 (counts >= 6 in row order): lengths are
-        // made monotone by construction below only if that class is ordered; it is handled by taking the running
-        // maximum from the right (a lane's slot widths only need to cover its list)
-        unsigned int mine = 0;
-        for (unsigned int pos = p; pos < npos; pos += kTallT) mine += cnt[posrow[pos]];
-        nlane[p] = mine;
-        __syncthreads();
-        // cover[p] = max over lanes >= p of their list lengths: a non-increasing envelope; slot k is as wide as the
-        // lanes whose ENVELOPE exceeds k (lanes inside the envelope without an item there store a skip item)
+        // Dealing rows to lanes.  Sparse cells (every row beyond the first 1024 sorted positions has ONE entry -- the
+        // regime this format is for): lane p takes position p, then as many one-entry rows as bring its list to the
+        // mean length tau = ceil(items / 1024) -- consecutive positions, lanes filled in order -- so all lists are tau
+        // long except those of the few rows longer than tau: the 16 waves of the workgroup reach the cell's barrier
+        // together.  Otherwise round by round: lane p takes positions p, p + 1024, ...
+        const unsigned int c0p = (unsigned)p < npos ? cnt[posrow[p]] : 0u;
+        const bool fill = npos > (unsigned)kTallT && cnt[posrow[kTallT]] <= 1u;  // uniform
+        unsigned int extra0 = 0, extra = 0, mine = c0p;
+        if (fill) {
+            const unsigned int tau = ((unsigned)n + kTallT - 1) / kTallT, avail = npos - kTallT;
+            const unsigned int want = c0p < tau ? tau - c0p : 0u;
+            unsigned long long total;
+            extra0 = (unsigned int)tall_block_scan(want, wtot, &total);
+            extra = extra0 >= avail ? 0u : (want < avail - extra0 ? want : avail - extra0);
+            mine += extra;
+        } else {
+            for (unsigned int pos = p + kTallT; pos < npos; pos += kTallT) mine += cnt[posrow[pos]];
+        }
+        // sorted position of the lane's q-th row, or npos when its list has ended
+        auto rowpos = [&](unsigned int q) -> unsigned int {
+            if (q == 0) return (unsigned)p < npos ? (unsigned)p : npos;
+            if (fill) return q - 1 < extra ? kTallT + extra0 + (q - 1) : npos;
+            const unsigned int pos = q * kTallT + p;
+            return pos < npos ? pos : npos;
+        };
+        // List lengths never increase with p in either scheme while counts never increase along the sorted positions;
+        // they do inside the class of rows with >= 6 entries (kept in row order).  Slot widths therefore come from the
+        // non-increasing envelope cover[p] = max over lanes >= p of their list lengths: slot k is as wide as the lanes
+        // whose ENVELOPE exceeds k, and a lane inside it whose own list has ended stores a skip item there.
         unsigned int cover = mine;
         {
             // suffix maximum over the 1024 lanes: inside the wave by shuffles, across waves through LDS
@@ -244,9 +263,9 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
         nlane[p] = cover;
         __syncthreads();
         const unsigned int longest = nlane[0];
-        // the lane's cursor over its own list: row round q (position p + 1024 q), entry s of that row
-        unsigned int q = 0, s = 0;
-        unsigned int myrow = (unsigned)p < npos ? posrow[p] : 0u, mycnt = (unsigned)p < npos ? cnt[myrow] : 0u;
+        // the lane's cursor over its own list: its q-th row (sorted position mypos), entry s of that row
+        unsigned int q = 0, s = 0, mypos = rowpos(0);
+        unsigned int myrow = mypos < npos ? posrow[mypos] : 0u, mycnt = mypos < npos ? cnt[myrow] : 0u;
         for (unsigned int g = 0; g * kTallSlots < longest || g == 0; ++g) {
             // slot widths of this packet: width[j] = first lane whose envelope is <= 8 g + j (binary search, lanes 0..7)
             if (p < kTallSlots) {
@@ -270,15 +289,15 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
                 for (int j = 0; j < kTallSlots; ++j) {
                     if ((unsigned)p < wd[j]) {
                         unsigned int item = 0, hib = 0x80u;  // skip item: a lane inside the envelope whose list has ended
-                        if (q * kTallT + p < npos) {
+                        if (mypos < npos) {
                             const unsigned long long key = keys[c0 + rstart[myrow] + s];
                             item = ((unsigned int)key & ((1u << (kTallIdBits + kTallColBits)) - 1)) | ((myrow & 0x1ffu) << 23);
                             hib = myrow >> 9;
                             if (++s == mycnt) {
                                 ++q; s = 0;
-                                const unsigned int pos = q * kTallT + p;
-                                myrow = pos < npos ? posrow[pos] : 0u;
-                                mycnt = pos < npos ? cnt[myrow] : 0u;
+                                mypos = rowpos(q);
+                                myrow = mypos < npos ? posrow[mypos] : 0u;
+                                mycnt = mypos < npos ? cnt[myrow] : 0u;
                             }
                         }
                         base[so + p] = item;
@@ -389,37 +408,34 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
             *reinterpret_cast<double2 *>(dst + 2) = make_double2(g.x[2], g.x[3]);
         }
         const double *__restrict__ tile = xt[cur];
-#define SLP_TALL_SLOT(K)                                                                                   \
-    {                                                                                                      \
-        const unsigned int w = g.lo[K], hb = (g.hi[(K) >> 2] >> (8 * ((K)&3))) & 0xffu;                     \
-        const unsigned int row = (w >> 23) | ((hb & 0x1fu) << 9);                                          \
-        const double a = acc[row];                                                                         \
-        const double t = a + dv[w & ((1u << kTallIdBits) - 1)] * tile[(w >> kTallIdBits) & (kTallC - 1)];  \
-        if ((unsigned)p < c[K] && !(hb & 0x80u)) acc[row] = t;                                             \
-    }
-        if (wbase < c[0]) {
-            SLP_TALL_SLOT(0)
-            if (wbase < c[1]) {
-                SLP_TALL_SLOT(1)
-                if (wbase < c[2]) {
-                    SLP_TALL_SLOT(2)
-                    if (wbase < c[3]) {
-                        SLP_TALL_SLOT(3)
-                        if (wbase < c[4]) {
-                            SLP_TALL_SLOT(4)
-                            if (wbase < c[5]) {
-                                SLP_TALL_SLOT(5)
-                                if (wbase < c[6]) {
-                                    SLP_TALL_SLOT(6)
-                                    if (wbase < c[7]) SLP_TALL_SLOT(7)
-                                }
-                            }
-                        }
-                    }
-                }
+        // Four slots at a time: all twelve LDS reads (running sums, values, x) are issued together, the products do not
+        // depend on the sums, and a sum that the lane has just updated is carried in a register (a lane's items of one
+        // row are consecutive) -- the LDS latency is paid once per group, not once per item.  The additions of a row
+        // stay one chain in list order.
+        auto group = [&](const int k0) {
+            unsigned int w[4], hb[4], row[4];
+            double ar[4], pr[4], t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                w[k] = g.lo[k0 + k];
+                hb[k] = (g.hi[k0 >> 2] >> (8 * k)) & 0xffu;
+                row[k] = (w[k] >> 23) | ((hb[k] & 0x1fu) << 9);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ar[k] = acc[row[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pr[k] = dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)];
+            t[0] = ar[0] + pr[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) t[k] = ((row[k] == row[k - 1]) ? t[k - 1] : ar[k]) + pr[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((unsigned)p < c[k0 + k] && !(hb[k] & 0x80u)) acc[row[k]] = t[k];
+        };
+        if (wbase < c[0]) {
+            group(0);
+            if (wbase < c[4]) group(4);
         }
-#undef SLP_TALL_SLOT
     };
 
     // prologue: headers of the first 2 x depth packets, payload of the first depth

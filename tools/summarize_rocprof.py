@@ -90,7 +90,7 @@ def db_sq(path):
         agg[short(name)][counter].append(float(value))
     out = {}
     for k, d in agg.items():
-        if not k.startswith("slp::k_") or "strip_spmv" not in k:
+        if not k.startswith("slp::k_") or ("strip_spmv" not in k and "tall_spmv" not in k):
             continue
         r = {c: sum(v) / len(v) for c, v in d.items()}
         r["launches"] = len(next(iter(d.values())))
