@@ -48,6 +48,8 @@ from pysparselp_amd.device import DeviceMatrix  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a plain copy achieves)
 
 KERNEL_NAMES = {
+    6: "k_tall_spmv (tall cells: 10^4-row blocks x 4096-column strips, running sums and x-tile in LDS, 5-byte "
+       "self-describing value-dictionary items, lossless)",
     5: "k_wstrip_spmv<false> (wide strips: x gathered from L2, fp64 entries)",
     4: "k_wstrip_spmv<true> (wide strips: x gathered from L2, value-dictionary entries)",
     3: "k_qstrip_spmv<1> (LDS-tiled strip-JDS SpMV over the value-dictionary copy: 12-bit value id + 12-bit column per "
@@ -63,11 +65,16 @@ PMC_FILES = {
     2: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_dict.json"), "slp::k_dstrip_spmv<1"),   # argument lists grew between rounds
     1: (("r02_c3_pmc_hbm.json", "r01_cp_c3_pmc_hbm.json"), "slp::k_strip_spmv<0"),
 }
+# named workloads: (variables, rows, density); c4slice = the 1/8 row slice of a 1e7 x 2e7, density-1e-4 LP -- BASELINE
+# config 4's per-rank shape at a density that fits (the 1e-3 of config 4 is 2.4 TB of CSR)
+CONFIGS = {"c3": (1_000_000, 2_000_000, 1e-3), "c4slice": (10_000_000, 2_500_000, 1e-4)}
+PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: (("r03_tall_slice_pmc_hbm.json",), "slp::k_tall_spmv")}}
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--config", default=None, choices=sorted(CONFIGS), help="named workload (sets --n / --m / --density)")
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     # (--vars / --rows: spellings that torch.distributed.run's own parser does not mistake for abbreviations of its options)
@@ -88,7 +95,10 @@ def parse():
     p.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU sample (default m / 10)")
     p.add_argument("--format", type=int, default=0, choices=[0, 1, 2],
                    help="slp_matrix_set_format policy of the timed run: 0 best available, 1 no value dictionary, 2 CSR kernels")
-    return p.parse_args()
+    args = p.parse_args()
+    if args.config:
+        args.n, args.m, args.density = CONFIGS[args.config]
+    return args
 
 
 def device_memory_in_use(lib):
@@ -104,9 +114,10 @@ def spmv_bytes(nnz, rows, cols):
 
 def pmc_traffic(kernel_id, shape):
     """(HBM bytes per launch from the committed rocprofv3 PMC summary of this workload, its path) or (None, None)."""
-    if kernel_id not in PMC_FILES or shape != (1_000_000, 2_000_000, 1e-3):
+    table = PMC_FILES if shape == (1_000_000, 2_000_000, 1e-3) else PMC_FILES_BY_SHAPE.get(shape, {})
+    if kernel_id not in table:
         return None, None
-    names, kern = PMC_FILES[kernel_id]
+    names, kern = table[kernel_id]
     for name in names:
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):

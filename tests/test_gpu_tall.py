@@ -125,3 +125,28 @@ def test_solvers_iterate_on_tall_cells_like_the_oracle():
         assert float(np.max(np.abs(x_gpu - x_cpu) / (1 + np.abs(x_cpu)))) <= 1e-9
     finally:
         a.close()
+
+
+def test_full_width_of_the_1e7_variable_shape_with_few_rows():
+    """All 1e7 columns (2442 strips, an 80 MB x) with 24 000 rows at density 1e-4 (2.4e7 entries; row blocks of 1024 rows
+    -> 24 workgroups): both orientations bit for bit against the oracle, Chambolle-Pock iterates bit for bit."""
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    n, m, dens = 10_000_000, 24_000, 1e-4
+    os.environ["SLP_TALL_R"] = "1024"
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, dens, seed=9)
+    try:
+        assert a.spmv_kernel(False) == 6
+        host = oracle.as_csr(a.download())
+        rng = np.random.RandomState(1)
+        x, y = rng.randn(n), rng.randn(m)
+        assert np.array_equal(a.matvec(x), oracle.matvec(host, x))
+        assert np.array_equal(a.rmatvec(y), oracle.rmatvec(host, y))
+        x_cpu, _ = oracle.chambolle_pock_ppd(c, None, None, host, None, b, lb, ub, nb_max_iter=8, nb_iter_plot=10 ** 9)
+        s = DeviceCP(a, b, c, lb, ub)
+        s.iterate(8)
+        assert np.array_equal(s.x(), x_cpu)
+        s.close()
+    finally:
+        a.close()
