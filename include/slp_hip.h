@@ -100,9 +100,11 @@ slp_matrix *slp_matrix_remove_columns(slp_matrix *a, const unsigned char *keep, 
  * far; fails while a solver created on the matrix is alive. */
 int slp_matrix_set_format(slp_matrix *a, int policy);
 /* Drop the CSR entries (column indices and values, both orientations) of a matrix whose products run on strip copies in
- * both orientations (slp_matrix_spmv_kernel >= 1): afterwards only the products -- and the solvers' iterations -- work;
- * downloads, row gathers, format changes, slp_cp_report and new solver set-ups fail with a clear error.  At BASELINE
- * config 3 this takes the resident matrix data from 66 GB (two CSR orientations + value-dictionary strips) to 17 GB. */
+ * both orientations (slp_matrix_spmv_kernel >= 1): afterwards the products, the solvers' iterations AND their periodic
+ * reports (slp_cp_report, slp_admm_cg_report: formed through the strip copies) work; downloads, row gathers, format
+ * changes and new solver set-ups fail with a clear error.  Refused while a solver created on the matrix iterates on
+ * the CSR arrays (Chambolle-Pock in SLP_ORDER_SEQUENTIAL with equality and inequality rows).  At BASELINE config 3
+ * this takes the resident matrix data from 66 GB (two CSR orientations + value-dictionary strips) to 17 GB. */
 int slp_matrix_release_csr(slp_matrix *a);
 /* hipMemGetInfo of the bound device. */
 int slp_device_memory(int64_t *free_bytes, int64_t *total_bytes);

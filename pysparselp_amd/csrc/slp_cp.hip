@@ -282,6 +282,40 @@ __global__ __launch_bounds__(kBlock) void k_cp_report_rows(i64 m, const i64 *__r
     }
 }
 
+// The same partials from the three products taken beforehand (strip copies: K x, K x4, K z as vectors) -- the form the
+// report takes whenever the matrix runs on strip copies, with or without its CSR arrays (slp_matrix_release_csr).
+__global__ __launch_bounds__(kBlock) void k_cp_report_rows_from(i64 m, const double *__restrict__ kxv, const double *__restrict__ kx4v,
+                                                                const double *__restrict__ kzv, const double *__restrict__ b,
+                                                                const double *__restrict__ y, i64 m_eq, double *__restrict__ part) {
+    __shared__ double lds[kBlock / kWave];
+    double s1 = 0.0, s2 = 0.0, veq = -__builtin_inf(), vin = -__builtin_inf(), veqx = -__builtin_inf();
+    for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < m; i += (i64)gridDim.x * kBlock) {
+        const double kx = kxv[i], kx4 = kx4v[i], kz = kzv[i], bi = b[i], yi = y[i];
+        s1 += yi * (kx - bi);
+        s2 += yi * (kx4 - bi);
+        if (i < m_eq) {
+            const double a = fabs(kz - bi), ax = fabs(kx - bi);
+            veq = a > veq ? a : veq;
+            veqx = ax > veqx ? ax : veqx;
+        } else {
+            const double v = kx - bi;
+            vin = v > vin ? v : vin;
+        }
+    }
+    const double r0 = block_reduce<false>(s1, lds);
+    const double r1 = block_reduce<false>(s2, lds);
+    const double r2 = block_reduce<true>(veq, lds);
+    const double r3 = block_reduce<true>(vin, lds);
+    const double r4 = block_reduce<true>(veqx, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 5 + 0] = r0;
+        part[blockIdx.x * 5 + 1] = r1;
+        part[blockIdx.x * 5 + 2] = r2;
+        part[blockIdx.x * 5 + 3] = r3;
+        part[blockIdx.x * 5 + 4] = r4;
+    }
+}
+
 // column pass: x4 and the two cost dot products; part[0] sum c x, part[1] sum c x4
 __global__ __launch_bounds__(kBlock) void k_cp_report_cols(i64 n, const double *__restrict__ c, const double *__restrict__ x,
                                                            const double *__restrict__ d, const double *__restrict__ lb,
@@ -351,7 +385,7 @@ struct slp_cp {
     double alpha = 1, theta = 1;
     int order = SLP_ORDER_AUTO;
     int lanes_rows = 1, lanes_cols = 1;
-    DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, kz, rowparts, colparts, out;
+    DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, kz, rep, rowparts, colparts, out;
     // ELL copies for short rows (0 = not used)
     int ell_w_rows = 0, ell_w_cols = 0;
     DevBuf<i32> ell_idx_rows, ell_idx_cols;
@@ -601,7 +635,6 @@ int slp_cp_dual_step(slp_cp *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); c
 int slp_cp_report(slp_cp *s, double out[5]) {
     SLP_API_INT({
         SLP_REQUIRE(s && out, "slp_cp_report: NULL argument");
-        require_csr(s->k, "slp_cp_report");  // the report's fused row pass walks the CSR
         hipStream_t st = ctx().stream;
         const CsrDev &a = s->k->a;
         int gc = grid_for(s->n, kBlock);
@@ -612,9 +645,23 @@ int slp_cp_report(slp_cp *s, double out[5]) {
         const int lanes = s->lanes_rows;
         int gr = grid_for(s->m * lanes, kBlock);
         if (gr > kMaxPartials) gr = kMaxPartials;
-        SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_report_rows<L>), dim3(gr), dim3(kBlock), 0, st, s->m, a.ptr.p,
-                                                     a.idx.p, a.val.p, s->x.p, s->x4.p, s->z.p, s->b.p, s->y.p, s->m_eq,
-                                                     s->rowparts.p));
+        if (const StripJds *f = fast_format(s->k, false)) {
+            // strip copies: the three products as vectors (the same values with or without the CSR arrays), then one
+            // elementwise pass; the dual step's K z scratch is free between the two halves of an iteration
+            if (s->rep.n < 2 * (size_t)s->m) s->rep.alloc(2 * (size_t)s->m);
+            if (s->kz.n < (size_t)s->m) s->kz.alloc((size_t)s->m);
+            strip_spmv2(*f, s->x.p, s->x4.p, s->rep.p, s->rep.p + s->m);
+            strip_spmv(*f, s->z.p, s->kz.p);
+            gr = grid_for(s->m, kBlock);
+            if (gr > kMaxPartials) gr = kMaxPartials;
+            hipLaunchKernelGGL(k_cp_report_rows_from, dim3(gr), dim3(kBlock), 0, st, s->m, s->rep.p, s->rep.p + s->m, s->kz.p, s->b.p,
+                               s->y.p, s->m_eq, s->rowparts.p);
+        } else {
+            require_csr(s->k, "slp_cp_report");  // (unreachable: a release needs strip copies in both orientations)
+            SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_report_rows<L>), dim3(gr), dim3(kBlock), 0, st, s->m, a.ptr.p,
+                                                         a.idx.p, a.val.p, s->x.p, s->x4.p, s->z.p, s->b.p, s->y.p, s->m_eq,
+                                                         s->rowparts.p));
+        }
         SLP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_cp_report_final, dim3(1), dim3(kBlock), 0, st, gr, s->rowparts.p, gc, s->colparts.p, s->out.p);
         SLP_HIP(hipGetLastError());

@@ -60,8 +60,19 @@ def _recv_exact(conn, nbytes):
     return buf
 
 
-MAGIC = b"SLPRDZV1"
+MAGIC = b"SLPRDZV2"
 PORT_TRIES = 8
+
+
+def job_token(world):
+    """8 bytes that identify THIS job in the rendezvous hello and reply: two jobs on one host whose candidate ports overlap
+    (or a stale rank-0 server of a killed run) then reject each other instead of cross-connecting.  Derived from what
+    every rank of a job shares: MASTER_ADDR / MASTER_PORT, the world size and the launcher's run id (or SLP_JOB_TOKEN)."""
+    import hashlib
+
+    parts = [os.environ.get("SLP_JOB_TOKEN", ""), os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29511"),
+             str(int(world)), os.environ.get("TORCHELASTIC_RUN_ID", "")]
+    return hashlib.sha256("|".join(parts).encode()).digest()[:8]
 
 
 def rendezvous_port():
@@ -79,6 +90,7 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300
     foreign listener on one of the candidate ports is skipped and a stray connection cannot take a rank's place."""
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = rendezvous_port() if port is None else int(port)
+    hello_tag = MAGIC + job_token(world)
     if rank == 0:
         uid = make_id()
         assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
@@ -105,12 +117,12 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300
                 with conn:
                     conn.settimeout(10.0)
                     try:
-                        hello = _recv_exact(conn, len(MAGIC) + 4)
+                        hello = _recv_exact(conn, len(hello_tag) + 4)
                     except (ConnectionError, socket.timeout, OSError):
                         continue
-                    peer = int.from_bytes(hello[len(MAGIC):], "little")
-                    if hello[:len(MAGIC)] == MAGIC and 0 < peer < world and peer not in served:
-                        conn.sendall(MAGIC + bytes(uid))
+                    peer = int.from_bytes(hello[len(hello_tag):], "little")
+                    if hello[:len(hello_tag)] == hello_tag and 0 < peer < world and peer not in served:
+                        conn.sendall(hello_tag + bytes(uid))
                         served.add(peer)
         return bytes(uid)
     deadline = time.monotonic() + timeout
@@ -119,10 +131,10 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300
             try:
                 with socket.create_connection((addr, p), timeout=5.0) as conn:
                     conn.settimeout(10.0)
-                    conn.sendall(MAGIC + int(rank).to_bytes(4, "little"))
-                    reply = _recv_exact(conn, len(MAGIC) + 128)
-                    if reply[:len(MAGIC)] == MAGIC:
-                        return reply[len(MAGIC):]
+                    conn.sendall(hello_tag + int(rank).to_bytes(4, "little"))
+                    reply = _recv_exact(conn, len(hello_tag) + 128)
+                    if reply[:len(hello_tag)] == hello_tag:
+                        return reply[len(hello_tag):]
             except (ConnectionError, socket.timeout, OSError):
                 pass
         if time.monotonic() > deadline:
@@ -145,6 +157,7 @@ class HostTcpAllreduce:
         self.peers = {}
         if self.world == 1:
             return
+        hello_tag = MAGIC + job_token(self.world)
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -154,10 +167,15 @@ class HostTcpAllreduce:
             while len(self.peers) < self.world - 1:
                 conn, _ = srv.accept()
                 conn.settimeout(timeout)
-                hello = _recv_exact(conn, len(MAGIC) + 4)
-                peer = int.from_bytes(hello[len(MAGIC):], "little")
-                if hello[:len(MAGIC)] == MAGIC and 0 < peer < self.world and peer not in self.peers:
+                try:
+                    hello = _recv_exact(conn, len(hello_tag) + 4)
+                except (ConnectionError, socket.timeout, OSError):
+                    conn.close()
+                    continue
+                peer = int.from_bytes(hello[len(hello_tag):], "little")
+                if hello[:len(hello_tag)] == hello_tag and 0 < peer < self.world and peer not in self.peers:
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.sendall(hello_tag)  # the client checks that it reached ITS job's rank 0
                     self.peers[peer] = conn
                 else:
                     conn.close()
@@ -174,7 +192,9 @@ class HostTcpAllreduce:
                     time.sleep(0.05)
             conn.settimeout(timeout)
             conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            conn.sendall(MAGIC + self.rank.to_bytes(4, "little"))
+            conn.sendall(hello_tag + self.rank.to_bytes(4, "little"))
+            if _recv_exact(conn, len(hello_tag)) != hello_tag:
+                raise ConnectionError("host transport: the listener on this port belongs to another job")
             self.peers[0] = conn
         self.callback = _lib.HOST_ALLREDUCE_FN(self._allreduce)
 

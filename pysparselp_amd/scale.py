@@ -87,6 +87,21 @@ class DeviceCP:
     def iterate(self, k):
         _lib.check(self._l.slp_cp_iterate(self._h, int(k)))
 
+    def primal_step(self):
+        """First half of an iteration (ChambollePockPPD.py:198-240), keeping ``d`` for the report."""
+        _lib.check(self._l.slp_cp_primal_step(self._h))
+
+    def dual_step(self):
+        _lib.check(self._l.slp_cp_dual_step(self._h))
+
+    def report(self):
+        """``(energy1, energy2, max_violated_equality, max_violated_inequality_at_z, max_violated_inequality)`` between the
+        two halves of an iteration, as the reference's periodic report computes them (ChambollePockPPD.py:242-329).  Runs on
+        the strip copies when the matrix has them -- also after ``release_csr``."""
+        out = np.zeros(5)
+        _lib.check(self._l.slp_cp_report(self._h, _lib.ptr(out)))
+        return out
+
     def x_reduced(self):
         """The iterate over the free variables (what the solver works on)."""
         out = np.empty(self.n)

@@ -306,3 +306,51 @@ def test_host_tcp_transport_reduces_identically_on_every_rank():
     for r in range(world):
         assert np.array_equal(res[r][0], want_sum) and np.array_equal(res[r][1], want_max)
         assert np.array_equal(res[r][2], np.full(300_000, 6.0))
+
+
+def test_rendezvous_rejects_a_rank_of_another_job():
+    """the hello and the reply carry a job token (hash of MASTER_ADDR / MASTER_PORT / world size / run id or
+    SLP_JOB_TOKEN): a rank of ANOTHER job that scans the same candidate ports neither receives this job's id nor takes a
+    rank's place; the job's own rank still gets through afterwards."""
+    import threading
+
+    from pysparselp_amd import parallel
+
+    port = _free_port()
+    got = {}
+
+    def serve():
+        os.environ["SLP_JOB_TOKEN"] = "job-A"   # (threads share the environment: the server's token is fixed at its start)
+        got["server"] = parallel.rendezvous_unique_id(0, 2, lambda: bytes(range(128)), addr="127.0.0.1", port=port, timeout=30.0)
+
+    tag_a = None
+    os.environ["SLP_JOB_TOKEN"] = "job-A"
+    try:
+        tag_a = parallel.MAGIC + parallel.job_token(2)
+        th = threading.Thread(target=serve)
+        th.start()
+        import socket
+        import time
+
+        time.sleep(0.3)
+        # a foreign rank 1 (other token): rank 0 never answers it with the id
+        foreign = parallel.MAGIC + b"\x00" * 8
+        reply = b""
+        for _ in range(50):
+            try:
+                with socket.create_connection(("127.0.0.1", port), timeout=2.0) as conn:
+                    conn.settimeout(2.0)
+                    conn.sendall(foreign + (1).to_bytes(4, "little"))
+                    try:
+                        reply = conn.recv(200)
+                    except socket.timeout:
+                        reply = b""
+                break
+            except OSError:
+                time.sleep(0.1)
+        assert reply == b"" and th.is_alive()      # connection closed without the id; the server keeps waiting for ITS rank 1
+        uid = parallel.rendezvous_unique_id(1, 2, None, addr="127.0.0.1", port=port, timeout=30.0)
+        th.join(timeout=30)
+        assert uid == bytes(range(128)) == got["server"] and tag_a is not None
+    finally:
+        del os.environ["SLP_JOB_TOKEN"]

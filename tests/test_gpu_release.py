@@ -33,7 +33,16 @@ def test_iterations_are_unchanged_after_the_csr_entries_are_released():
                     DeviceCP(a, b, c, lb, ub)
             cp.iterate(40)
             admm.iterate(40)
-            out.append((cp.x(), admm.x(30000), a.matvec(xf), a.rmatvec(b)))
+            # the reference's periodic report (ChambollePockPPD.py:242-329, ADMM.py:213-248) between the two halves of an
+            # iteration: formed through the strip copies, so it needs no CSR arrays and does not change with the release
+            cp.primal_step()
+            cp_report = cp.report()
+            cp.dual_step()
+            admm.xstep()
+            admm_report = admm.report()
+            admm.multiplier_step()
+            assert np.all(np.isfinite(cp_report)) and np.all(np.isfinite(admm_report))
+            out.append((cp.x(), admm.x(30000), a.matvec(xf), a.rmatvec(b), cp_report, admm_report))
             cp.close()
             admm.close()
             a.close()
