@@ -48,6 +48,8 @@ from pysparselp_amd.device import DeviceMatrix  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a plain copy achieves)
 
 KERNEL_NAMES = {
+    7: "k_tall_spmv<false> (tall cells: 10^4-row blocks x 4096-column strips, running sums and x-tile in LDS, 4-byte "
+       "(column, row) items + fp64 values)",
     6: "k_tall_spmv (tall cells: 10^4-row blocks x 4096-column strips, running sums and x-tile in LDS, 5-byte "
        "self-describing value-dictionary items, lossless)",
     5: "k_wstrip_spmv<false> (wide strips: x gathered from L2, fp64 entries)",
@@ -226,11 +228,12 @@ def general_block(lib, args, a, b, c, lb, ub, shape):
     ax, which = spmv_block(lib, a, False, shape)
     aty, _ = spmv_block(lib, a, True, shape)
     t_build = time.perf_counter() - t0
-    out = {"what": "same matrix, value dictionary ruled out (slp_matrix_set_format(a, 1)): fp64 value + uint16 column per "
-                   "stored entry; the path a matrix with arbitrary coefficients takes",
+    out = {"what": "same matrix, value dictionary ruled out (slp_matrix_set_format(a, 1)): fp64 value per stored entry "
+                   "(strips: + uint16 column; tall cells: + 4-byte (column, row) item); the path a matrix with arbitrary "
+                   "coefficients takes",
            "spmv": ax, "spmv_transposed": aty, "format_build_and_spmv_seconds": t_build}
-    if which != 1:
-        out["note"] = "the matrix does not qualify for the fp64 strip format at this size"
+    if which not in (1, 7):
+        out["note"] = "the matrix does not qualify for an LDS-tiled fp64 format at this size"
     steps = max(5, min(args.steps, 20))
     cp = make_solver("chambolle_pock_ppd", a, b, c, lb, ub)
     dt = timed_steps(lib, cp, 2, steps)

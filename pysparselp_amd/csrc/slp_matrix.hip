@@ -200,6 +200,7 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
         if (!dict && tall_wanted(a) && matrix_dictionary(m) && tall_build(a, f, &m->vdict)) return &f;
         if (dict) strip_build(a, f, &m->vdict, variant);
         else if (strip_wanted(a, 0)) strip_build(a, f, nullptr, 0);
+        else if (tall_wanted(a) && tall_build(a, f, nullptr)) return &f;  // the same shape with arbitrary values: fp64 entries
         else if (strip_wanted(a, 3))  // long rows over a width far beyond an L2: wide strips, x gathered from L2
             strip_build(a, f, matrix_dictionary(m) ? &m->vdict : nullptr, 3);
     }
@@ -584,7 +585,7 @@ int slp_matrix_spmv_kernel(slp_matrix *m, int transposed) {
         SLP_REQUIRE(m, "slp_matrix_spmv_kernel: NULL matrix");
         const StripJds *f = fast_format(m, transposed != 0);
         if (!f) return 0;
-        if (f->tall) return 6;
+        if (f->tall) return f->D > 0 ? 6 : 7;
         if (f->wide) return f->D > 0 ? 4 : 5;
         return f->D > 0 ? (f->rpl == 4 ? 3 : 2) : 1;
     } catch (const std::exception &e) {
@@ -601,7 +602,7 @@ int64_t slp_matrix_format_bytes(slp_matrix *m, int transposed) {
         if (!f) return (int64_t)(12 * a.nnz + 8 * (a.nrow + 1));
         if (f->tall)
             return (int64_t)((f->tall_pay.n + f->tall_dir.n) * sizeof(unsigned int) + (f->tall_base.n + f->tall_pkt.n) * sizeof(i64) +
-                             (size_t)f->D * sizeof(double));
+                             (size_t)f->D * sizeof(double) + (f->D > 0 ? 0 : f->val.n * sizeof(double)));
         const size_t entries = f->D > 0 ? f->ent.n * sizeof(unsigned short) + (size_t)f->D * sizeof(double)
                                         : f->val.n * sizeof(double) + f->col.n * sizeof(unsigned short);
         return (int64_t)(entries + f->perm.n * sizeof(unsigned short) + f->slen.n + f->soff.n * sizeof(unsigned int) +

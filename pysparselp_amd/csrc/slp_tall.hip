@@ -88,14 +88,17 @@ __global__ __launch_bounds__(kBlock) void k_tall_keys(i64 nrow, int R, i64 T, in
         for (i64 k = s + lane; k < e; k += kWave) {
             const i32 j = idx[k];
             if (k > s && idx[k - 1] >= j) atomicOr(bad, 1);  // rows must be strictly increasing in column
-            const unsigned long long key = tall_value_key((unsigned long long)__double_as_longlong(val[k]));
-            int lo = 0, hi = D - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (skey[mid] < key) lo = mid + 1;
-                else hi = mid;
+            int lo = 0;
+            if (D > 0) {  // (D == 0: fp64 entries, the value travels beside the key)
+                const unsigned long long key = tall_value_key((unsigned long long)__double_as_longlong(val[k]));
+                int hi = D - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (skey[mid] < key) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (skey[lo] != key) atomicOr(bad, 2);
             }
-            if (skey[lo] != key) atomicOr(bad, 2);
             const unsigned long long t = (unsigned long long)(j / kTallC), cl = (unsigned long long)(j % kTallC);
             keys[k] = ((b * (unsigned long long)T + t) << kTallCellShift) | (rl << (kTallIdBits + kTallColBits)) | (cl << kTallIdBits) |
                       (unsigned long long)lo;
@@ -138,11 +141,13 @@ __device__ __forceinline__ unsigned long long tall_block_scan(unsigned long long
 
 // One workgroup per row block walks its cells in strip order.  WRITE = false: sizes only (payload words, packets);
 // WRITE = true: headers and payload at the offsets the host derived from the sizes.
-template <bool WRITE>
+// DICT: 5-byte items (value id inside); !DICT: 4-byte items (column | row << 12) + the fp64 value in a parallel array at the same offsets.
+template <bool WRITE, bool DICT>
 __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, const unsigned long long *__restrict__ keys,
-                                                       const i64 *__restrict__ cellptr, i64 *__restrict__ sizes,
-                                                       const i64 *__restrict__ blk_base, const i64 *__restrict__ pkt_ptr,
-                                                       TallPkt *__restrict__ dir, unsigned int *__restrict__ payload) {
+                                                       const double *__restrict__ svals, const i64 *__restrict__ cellptr,
+                                                       i64 *__restrict__ sizes, const i64 *__restrict__ blk_base,
+                                                       const i64 *__restrict__ pkt_ptr, TallPkt *__restrict__ dir,
+                                                       unsigned int *__restrict__ payload, double *__restrict__ pvals) {
     __shared__ unsigned int cnt[kTallRmax];       // entries of the row inside the cell
     __shared__ unsigned int rstart[kTallRmax];    // position of the row's first entry inside the cell
     __shared__ unsigned short posrow[kTallRmax];  // sorted position -> local row
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
     const i64 b = blockIdx.x;
     const int rpt = (R + kTallT - 1) / kTallT;  // consecutive rows per thread in the sorting pass
     unsigned int *pay = WRITE ? payload + blk_base[b] : nullptr;
+    double *payv = (WRITE && !DICT) ? pvals + blk_base[b] : nullptr;
     TallPkt *pk = WRITE ? dir + pkt_ptr[b] : nullptr;
     i64 woff = 0, npk = 0;  // running payload offset / packet count of the row block (uniform)
 
@@ -282,17 +288,23 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
             unsigned int wd[kTallSlots], words = 0;
             for (int j = 0; j < kTallSlots; ++j) { wd[j] = width[j]; words += wd[j]; }
             const unsigned int hi0 = words, hi1 = words + wd[0];
-            words += wd[0] + wd[4];
+            if (DICT) words += wd[0] + wd[4];
             if (WRITE) {
                 unsigned int *base = pay + woff;
                 unsigned int hb0 = 0, hb1 = 0, so = 0;
                 for (int j = 0; j < kTallSlots; ++j) {
                     if ((unsigned)p < wd[j]) {
-                        unsigned int item = 0, hib = 0x80u;  // skip item: a lane inside the envelope whose list has ended
+                        unsigned int item = DICT ? 0u : 0x80000000u, hib = 0x80u;  // skip item: a lane inside the envelope whose list has ended
+                        double value = 0.0;
                         if (mypos < npos) {
                             const unsigned long long key = keys[c0 + rstart[myrow] + s];
-                            item = ((unsigned int)key & ((1u << (kTallIdBits + kTallColBits)) - 1)) | ((myrow & 0x1ffu) << 23);
-                            hib = myrow >> 9;
+                            if (DICT) {
+                                item = ((unsigned int)key & ((1u << (kTallIdBits + kTallColBits)) - 1)) | ((myrow & 0x1ffu) << 23);
+                                hib = myrow >> 9;
+                            } else {
+                                item = ((unsigned int)(key >> kTallIdBits) & (kTallC - 1)) | (myrow << kTallColBits);
+                                value = svals[c0 + rstart[myrow] + s];
+                            }
                             if (++s == mycnt) {
                                 ++q; s = 0;
                                 mypos = rowpos(q);
@@ -301,13 +313,14 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
                             }
                         }
                         base[so + p] = item;
+                        if (!DICT) payv[woff + so + p] = value;
                         if (j < 4) hb0 |= hib << (8 * j);
                         else hb1 |= hib << (8 * (j - 4));
                     }
                     so += wd[j];
                 }
-                if ((unsigned)p < wd[0]) base[hi0 + p] = hb0;
-                if ((unsigned)p < wd[4]) base[hi1 + p] = hb1;
+                if (DICT && (unsigned)p < wd[0]) base[hi0 + p] = hb0;
+                if (DICT && (unsigned)p < wd[4]) base[hi1 + p] = hb1;
                 if (p == 0) {
                     TallPkt h;
                     h.off = (unsigned int)woff;
@@ -324,23 +337,30 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
         }
         t = tn;
     }
-    // whole groups of 2 x depth packets, then 2 x depth more that are only ever prefetched
+    // whole groups of 2 x depth packets, then 2 x depth more that are only ever prefetched (the deeper pipeline's count
+    // serves both kernels)
     while (npk % (2 * kTallDepth)) empty_packet(kNoTile);
     for (int i = 0; i < 2 * kTallDepth; ++i) empty_packet(kNoTile);
     if (!WRITE && p == 0) { sizes[2 * b] = woff; sizes[2 * b + 1] = npk; }
 }
 
 // ---- the product -------------------------------------------------------------------------------------------------------
+template <bool DICT>
 struct TallRegs {
     unsigned int lo[kTallSlots];
-    unsigned int hi[2];
+    unsigned int hi[DICT ? 2 : 1];
+    double val[DICT ? 1 : kTallSlots];
     double x[4];
 };
 
+// DICT: depth 4 (20 KB of payload per packet); fp64 entries: depth 2 (48 KB per packet, 16 more registers per packet)
+template <bool DICT>
 __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, const i64 *__restrict__ pkt_ptr,
                                                       const i64 *__restrict__ blk_base, const unsigned int *__restrict__ dirw,
-                                                      const unsigned int *__restrict__ payload, const double *__restrict__ dict, int D,
-                                                      const double *__restrict__ x, double *__restrict__ out) {
+                                                      const unsigned int *__restrict__ payload, const double *__restrict__ pvals,
+                                                      const double *__restrict__ dict, int D, const double *__restrict__ x,
+                                                      double *__restrict__ out) {
+    constexpr int kDepth = DICT ? kTallDepth : 2;
     __shared__ double acc[kTallRmax];
     __shared__ double dv[kTallDictMax];
     __shared__ double xt[2][kTallC];
@@ -348,7 +368,8 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
     const i64 b = blockIdx.x;
     for (int r = p; r < R; r += kTallT) acc[r] = 0.0;
-    for (int q = p; q < D; q += kTallT) dv[q] = dict[q];
+    if (DICT)
+        for (int q = p; q < D; q += kTallT) dv[q] = dict[q];
     const unsigned int *__restrict__ hd = dirw + pkt_ptr[b] * 8 + (p & 7);  // this lane's dword of every header
     const int npk = (int)(pkt_ptr[b + 1] - pkt_ptr[b]) - 2 * kTallDepth;      // the last 2 x depth packets are prefetch targets only
     // buffer descriptors: lanes without work address past num_records (the load returns 0 without a memory request)
@@ -356,10 +377,12 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(payload + blk_base[b]), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)(ncol * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_val =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : pvals + blk_base[b]), 0, 0x7fffffff, 0x00020000);
     int cur = 0;
 
-    TallRegs regs[kTallDepth];
-    unsigned int hw[2 * kTallDepth];
+    TallRegs<DICT> regs[kDepth];
+    unsigned int hw[2 * kDepth];
 
     auto widths = [&](unsigned int h, unsigned int *c) {
 #pragma unroll
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
         }
     };
 
-    auto issue = [&](TallRegs &g, unsigned int h) {
+    auto issue = [&](TallRegs<DICT> &g, unsigned int h) {
         const unsigned int off = (unsigned int)__builtin_amdgcn_readlane((int)h, 0);
         const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
         unsigned int c[kTallSlots];
@@ -380,11 +403,17 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #pragma unroll
         for (int k = 0; k < kTallSlots; ++k) {
             g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);  // streamed once
+            if (!DICT) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_val, (unsigned)p < c[k] ? 2u * mine : kOob, 2u * so, 2);
+                g.val[k] = __hiloint2double((int)v[1], (int)v[0]);
+            }
             so += c[k] * 4u;
         }
-        g.hi[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[0] ? mine : kOob, so, 2);
-        so += c[0] * 4u;
-        g.hi[1] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4] ? mine : kOob, so, 2);
+        if (DICT) {
+            g.hi[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[0] ? mine : kOob, so, 2);
+            so += c[0] * 4u;
+            g.hi[DICT ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4] ? mine : kOob, so, 2);
+        }
         const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 4u * (unsigned int)p) * 8u;  // columns past ncol read 0
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
         }
     };
 
-    auto consume = [&](const TallRegs &g, unsigned int h) {
+    auto consume = [&](const TallRegs<DICT> &g, unsigned int h) {
         const unsigned int xw = (unsigned int)__builtin_amdgcn_readlane((int)h, 1);
         unsigned int c[kTallSlots];
         widths(h, c);
@@ -418,13 +447,20 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 w[k] = g.lo[k0 + k];
-                hb[k] = (g.hi[k0 >> 2] >> (8 * k)) & 0xffu;
-                row[k] = (w[k] >> 23) | ((hb[k] & 0x1fu) << 9);
+                if (DICT) {
+                    hb[k] = (g.hi[DICT ? (k0 >> 2) : 0] >> (8 * k)) & 0xffu;
+                    row[k] = (w[k] >> 23) | ((hb[k] & 0x1fu) << 9);
+                } else {
+                    hb[k] = (w[k] >> 24) & 0x80u;   // bit 31: skip item
+                    row[k] = (w[k] >> kTallColBits) & ((1u << kTallRowBits) - 1);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) ar[k] = acc[row[k]];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pr[k] = dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)];
+            for (int k = 0; k < 4; ++k)
+                pr[k] = DICT ? dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)]
+                             : g.val[DICT ? 0 : k0 + k] * tile[w[k] & (kTallC - 1)];
             t[0] = ar[0] + pr[0];
 #pragma unroll
             for (int k = 1; k < 4; ++k) t[k] = ((row[k] == row[k - 1]) ? t[k - 1] : ar[k]) + pr[k];
@@ -440,16 +476,16 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 
     // prologue: headers of the first 2 x depth packets, payload of the first depth
 #pragma unroll
-    for (int u = 0; u < 2 * kTallDepth; ++u) hw[u] = hd[(i64)u * 8];
+    for (int u = 0; u < 2 * kDepth; ++u) hw[u] = hd[(i64)u * 8];
 #pragma unroll
-    for (int u = 0; u < kTallDepth; ++u) issue(regs[u], hw[u]);
+    for (int u = 0; u < kDepth; ++u) issue(regs[u], hw[u]);
     __syncthreads();
-    for (int jj = 0; jj < npk; jj += 2 * kTallDepth) {
+    for (int jj = 0; jj < npk; jj += 2 * kDepth) {
 #pragma unroll
-        for (int u = 0; u < 2 * kTallDepth; ++u) {
-            consume(regs[u % kTallDepth], hw[u]);                                   // packet jj + u
-            issue(regs[u % kTallDepth], hw[(u + kTallDepth) % (2 * kTallDepth)]);   // payload of packet jj + u + depth
-            hw[u] = hd[(i64)(jj + u + 2 * kTallDepth) * 8];                         // header of packet jj + u + 2 depth
+        for (int u = 0; u < 2 * kDepth; ++u) {
+            consume(regs[u % kDepth], hw[u]);                               // packet jj + u
+            issue(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)]);       // payload of packet jj + u + depth
+            hw[u] = hd[(i64)(jj + u + 2 * kDepth) * 8];                     // header of packet jj + u + 2 depth
         }
     }
     __syncthreads();
@@ -477,7 +513,7 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     Phase ph("tall_build");
     hipStream_t st = ctx().stream;
     f = StripJds();
-    if (!dict || dict->D <= 0 || dict->D > kTallDictMax || a.nrow == 0 || a.nnz == 0) return false;
+    if ((dict && (dict->D <= 0 || dict->D > kTallDictMax)) || a.nrow == 0 || a.nnz == 0) return false;
     if (a.ncol * 8 >= ((i64)1 << 31)) return false;  // x is addressed through a buffer descriptor with 32-bit byte offsets
     const int R = tall_rows_per_block(a.nrow);
     const i64 T = (a.ncol + kTallC - 1) / kTallC, B = (a.nrow + R - 1) / R, ncell = B * T;
@@ -486,35 +522,49 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     if (kTallCellShift + cellbits > 64) return false;
     DevBuf<i64> cellptr((size_t)ncell + 1);
     DevBuf<unsigned long long> sorted((size_t)a.nnz);
+    DevBuf<double> svals;  // fp64 entries: the values in the sorted order
     {
         DevBuf<unsigned long long> keys((size_t)a.nnz);
         DevBuf<int> bad(1);
         bad.zero();
-        hipLaunchKernelGGL(k_tall_keys, dim3(grid_for(a.nrow * kWave, kBlock)), dim3(kBlock), 0, st, a.nrow, R, T, dict->D, dict->keys.p,
-                           a.ptr.p, a.idx.p, a.val.p, keys.p, bad.p);
+        hipLaunchKernelGGL(k_tall_keys, dim3(grid_for(a.nrow * kWave, kBlock)), dim3(kBlock), 0, st, a.nrow, R, T, dict ? dict->D : 0,
+                           dict ? dict->keys.p : (const unsigned long long *)nullptr, a.ptr.p, a.idx.p, a.val.p, keys.p, bad.p);
         SLP_HIP(hipGetLastError());
         int hbad = 0;
         bad.download(&hbad, 1);
         if (hbad) return false;  // unsorted rows (or a value outside the dictionary)
         size_t bytes = 0;
-        SLP_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys.p, sorted.p, (size_t)a.nnz, (unsigned)kTallCellShift,
-                                         (unsigned)kTallCellShift + cellbits, st));
-        DevBuf<char> tmp(bytes);
-        SLP_HIP(rocprim::radix_sort_keys(tmp.p, bytes, keys.p, sorted.p, (size_t)a.nnz, (unsigned)kTallCellShift,
-                                         (unsigned)kTallCellShift + cellbits, st));
-        SLP_HIP(hipStreamSynchronize(st));
+        const unsigned b0 = (unsigned)kTallCellShift, b1 = (unsigned)kTallCellShift + cellbits;
+        if (dict) {
+            SLP_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys.p, sorted.p, (size_t)a.nnz, b0, b1, st));
+            DevBuf<char> tmp(bytes);
+            SLP_HIP(rocprim::radix_sort_keys(tmp.p, bytes, keys.p, sorted.p, (size_t)a.nnz, b0, b1, st));
+            SLP_HIP(hipStreamSynchronize(st));
+        } else {
+            svals.alloc((size_t)a.nnz);
+            SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, sorted.p, a.val.p, svals.p, (size_t)a.nnz, b0, b1, st));
+            DevBuf<char> tmp(bytes);
+            SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.p, sorted.p, a.val.p, svals.p, (size_t)a.nnz, b0, b1, st));
+            SLP_HIP(hipStreamSynchronize(st));
+        }
     }
     hipLaunchKernelGGL(k_tall_cellptr, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, ncell, sorted.p, cellptr.p);
     SLP_HIP(hipGetLastError());
     DevBuf<i64> sizes(2 * (size_t)B);
-    hipLaunchKernelGGL((k_tall_build<false>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, cellptr.p, sizes.p,
-                       (const i64 *)nullptr, (const i64 *)nullptr, (TallPkt *)nullptr, (unsigned int *)nullptr);
+    if (dict)
+        hipLaunchKernelGGL((k_tall_build<false, true>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, (const double *)nullptr,
+                           cellptr.p, sizes.p, (const i64 *)nullptr, (const i64 *)nullptr, (TallPkt *)nullptr, (unsigned int *)nullptr,
+                           (double *)nullptr);
+    else
+        hipLaunchKernelGGL((k_tall_build<false, false>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, (const double *)nullptr,
+                           cellptr.p, sizes.p, (const i64 *)nullptr, (const i64 *)nullptr, (TallPkt *)nullptr, (unsigned int *)nullptr,
+                           (double *)nullptr);
     SLP_HIP(hipGetLastError());
     std::vector<i64> hs(2 * (size_t)B), hbase((size_t)B + 1), hpkt((size_t)B + 1);
     sizes.download(hs.data(), hs.size());
     hbase[0] = hpkt[0] = 0;
     for (i64 b = 0; b < B; ++b) {
-        SLP_REQUIRE(hs[2 * b] < ((i64)1 << 29), "tall cells: a row block's payload exceeds 2 GB");
+        SLP_REQUIRE(hs[2 * b] < ((i64)1 << 28), "tall cells: a row block's payload exceeds 2 GB");
         hbase[b + 1] = hbase[b] + ((hs[2 * b] + 3) & ~(i64)3);  // 16-byte aligned row blocks
         hpkt[b + 1] = hpkt[b] + hs[2 * b + 1];
     }
@@ -522,13 +572,20 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     f.tall_pkt.upload(hpkt.data(), hpkt.size());
     f.tall_dir.alloc((size_t)hpkt[B] * 8);
     f.tall_pay.alloc((size_t)hbase[B] + 64);
-    hipLaunchKernelGGL((k_tall_build<true>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, cellptr.p, (i64 *)nullptr,
-                       f.tall_base.p, f.tall_pkt.p, reinterpret_cast<TallPkt *>(f.tall_dir.p), f.tall_pay.p);
+    if (dict) {
+        hipLaunchKernelGGL((k_tall_build<true, true>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, (const double *)nullptr,
+                           cellptr.p, (i64 *)nullptr, f.tall_base.p, f.tall_pkt.p, reinterpret_cast<TallPkt *>(f.tall_dir.p), f.tall_pay.p,
+                           (double *)nullptr);
+    } else {
+        f.val.alloc((size_t)hbase[B] + 64);
+        hipLaunchKernelGGL((k_tall_build<true, false>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, svals.p, cellptr.p,
+                           (i64 *)nullptr, f.tall_base.p, f.tall_pkt.p, reinterpret_cast<TallPkt *>(f.tall_dir.p), f.tall_pay.p, f.val.p);
+    }
     SLP_HIP(hipGetLastError());
     SLP_HIP(hipStreamSynchronize(st));
     f.nrow = a.nrow; f.ncol = a.ncol; f.nnz = a.nnz; f.T = T; f.B = B; f.C = kTallC; f.rpl = 1;
-    f.D = dict->D;
-    f.dict = dict->values.p;
+    f.D = dict ? dict->D : 0;
+    f.dict = dict ? dict->values.p : nullptr;
     f.tall = true;
     f.tall_R = R;
     f.S = 1;
@@ -537,8 +594,12 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
 }
 
 void tall_spmv(const StripJds &f, const double *x, double *out) {
-    hipLaunchKernelGGL(k_tall_spmv, dim3((unsigned)f.B), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.tall_pkt.p,
-                       f.tall_base.p, f.tall_dir.p, f.tall_pay.p, f.dict, f.D, x, out);
+    if (f.D > 0)
+        hipLaunchKernelGGL((k_tall_spmv<true>), dim3((unsigned)f.B), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.tall_pkt.p,
+                           f.tall_base.p, f.tall_dir.p, f.tall_pay.p, (const double *)nullptr, f.dict, f.D, x, out);
+    else
+        hipLaunchKernelGGL((k_tall_spmv<false>), dim3((unsigned)f.B), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.tall_pkt.p,
+                           f.tall_base.p, f.tall_dir.p, f.tall_pay.p, f.val.p, (const double *)nullptr, 0, x, out);
     SLP_HIP(hipGetLastError());
 }
 

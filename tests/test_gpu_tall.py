@@ -36,12 +36,17 @@ def _check(a_host, rows_per_block=None, transposed_too=True):
     try:
         rng = np.random.RandomState(3)
         x, y = rng.randn(a_host.shape[1]), rng.randn(a_host.shape[0])
-        assert a.spmv_kernel(False) == 6, a.spmv_kernel(False)
-        assert np.array_equal(a.matvec(x), oracle.matvec(oracle.as_csr(a_host), x))
-        if transposed_too:
-            kern = a.spmv_kernel(True)
-            assert np.array_equal(a.rmatvec(y), oracle.rmatvec(oracle.as_csr(a_host), y)), kern
-            return kern
+        ax, aty = oracle.matvec(oracle.as_csr(a_host), x), oracle.rmatvec(oracle.as_csr(a_host), y)
+        kern = None
+        for policy, want in ((0, 6), (1, 7)):   # value-dictionary items (5 bytes) / fp64 entries (4 + 8 bytes)
+            a.set_format(policy)
+            assert a.spmv_kernel(False) == want, (policy, a.spmv_kernel(False))
+            assert np.array_equal(a.matvec(x), ax), policy
+            if transposed_too:
+                k = a.spmv_kernel(True)
+                assert np.array_equal(a.rmatvec(y), aty), (policy, k)
+                kern = k if policy == 0 else kern
+        return kern
     finally:
         a.close()
 
@@ -101,7 +106,8 @@ def test_one_row_block_and_a_single_strip_of_work():
 
 def test_solvers_iterate_on_tall_cells_like_the_oracle():
     """Chambolle-Pock bit for bit, matrix-free ADMM (reuse 4, deferred row scaling) to 1e-9, on a reduced-row slice of
-    the 1e7-variable shape: 12 000 rows x 400 000 columns at density 1e-4 (40 entries per row, 0.41 per (row, strip))."""
+    the 1e7-variable shape: 12 000 rows x 400 000 columns at density 1e-4 (40 entries per row, 0.41 per (row, strip));
+    then the same with the value dictionary ruled out: fp64 entries, rows scaled in place by the ADMM setup."""
     from pysparselp_amd.admm_cg import DeviceADMM
     from pysparselp_amd.problems import random_lp_on_device
     from pysparselp_amd.scale import DeviceCP
@@ -120,6 +126,13 @@ def test_solvers_iterate_on_tall_cells_like_the_oracle():
         x_cpu = oracle.lp_admm_cg(c, None, None, host, None, b, lb, ub, nb_iter=69, nb_iter_plot=10 ** 9)
         s = DeviceADMM(a, b, c, lb, ub)
         s.iterate(70)                                 # across the level-4 refresh at 64
+        x_gpu = s.x(n)
+        s.close()
+        assert float(np.max(np.abs(x_gpu - x_cpu) / (1 + np.abs(x_cpu)))) <= 1e-9
+        a.set_format(1)
+        s = DeviceADMM(a, b, c, lb, ub)               # no dictionary: the rows of `a` are normalised in place
+        assert a.spmv_kernel(False) == 7 and a.spmv_kernel(True) == 7
+        s.iterate(70)
         x_gpu = s.x(n)
         s.close()
         assert float(np.max(np.abs(x_gpu - x_cpu) / (1 + np.abs(x_cpu)))) <= 1e-9

