@@ -134,16 +134,6 @@ __global__ void k_ptr_from_sorted(i64 nnz, i64 ncol, const unsigned int *__restr
     }
 }
 
-// After the stable sort by column: position p of the transposed matrix holds source entry perm[p].
-__global__ void k_gather_transposed(i64 nnz, const i32 *__restrict__ rowid, const double *__restrict__ val,
-                                    const unsigned int *__restrict__ perm, i32 *__restrict__ trow, double *__restrict__ tval) {
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (i64)gridDim.x * blockDim.x) {
-        const i64 src = perm[p];
-        trow[p] = rowid[src];
-        tval[p] = val[src];
-    }
-}
-
 __global__ void k_max_row_len(i64 nrow, const i64 *__restrict__ ptr, unsigned long long *out) {
     unsigned long long m = 0;
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
@@ -246,9 +236,9 @@ void finish_stats(CsrDev &a) {  // fills a.max_row_len (kernel choices depend on
     a.max_row_len = (i64)h;
 }
 
-// Stable device transposition: a radix sort of the entry positions keyed by
-// column keeps, inside every column, the entries in storage order of A, i.e.
-// by increasing row (and storage order inside a row) -- the order in which
+// Stable device transposition: a radix sort of the entries keyed by column
+// keeps, inside every column, the entries in storage order of A, i.e. by
+// increasing row (and storage order inside a row) -- the order in which
 // scipy's csc_matvec accumulates `y * A`.
 void build_transpose(slp_matrix *m) {
     if (m->have_at) return;
@@ -260,34 +250,33 @@ void build_transpose(slp_matrix *m) {
     t.nrow = a.ncol;
     t.ncol = a.nrow;
     t.nnz = a.nnz;
-    SLP_REQUIRE(a.nnz < (i64)0xffffffffll, "transpose: more than 2^32-1 stored entries per device block");
     t.ptr.alloc((size_t)t.nrow + 1);
     t.idx.alloc((size_t)a.nnz);
     t.val.alloc((size_t)a.nnz);
     if (a.nnz) {
-        // stable LSD radix sort of (column, position) pairs; positions come from a counting iterator
-        DevBuf<unsigned int> pos_out((size_t)a.nnz), key_out((size_t)a.nnz);
-        unsigned int bits = 1;
-        while (bits < 32 && ((i64)1 << bits) < a.ncol) ++bits;
-        size_t bytes = 0;
-        const unsigned int *keys_in = reinterpret_cast<const unsigned int *>(a.idx.p);
-        rocprim::counting_iterator<unsigned int> pos_in(0u);
-        SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, key_out.p, pos_in, pos_out.p, (size_t)a.nnz, 0u, bits, st));
-        {
-            DevBuf<char> tmp(bytes);
-            SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys_in, key_out.p, pos_in, pos_out.p, (size_t)a.nnz, 0u, bits, st));
-            SLP_HIP(hipStreamSynchronize(st));
-        }
-        // column pointer straight from the sorted keys
-        hipLaunchKernelGGL(k_ptr_from_sorted, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, t.nrow, key_out.p, t.ptr.p);
-        SLP_HIP(hipGetLastError());
-        SLP_HIP(hipStreamSynchronize(st));
-        key_out.release();
-        // row of every source entry (coalesced expansion), then two gathers per transposed entry
+        // Stable LSD radix sort of the entries keyed by column, the (row, value) pair of every entry travelling with its key:
+        // whole records stream through every pass (no positions, so no 2^32 limit and no random gather afterwards -- the
+        // gather by sorted position moved 0.3-0.5 TB at config 3, profiles/r02_c3_pmc_hbm.json).  The row of every source
+        // entry comes from a coalesced expansion of the row pointer.
         DevBuf<i32> rowid((size_t)a.nnz);
         hipLaunchKernelGGL(k_expand_rows, dim3(grid_for(a.nrow * kWave, kBlock)), dim3(kBlock), 0, st, a.nrow, a.ptr.p, rowid.p);
-        hipLaunchKernelGGL(k_gather_transposed, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, rowid.p, a.val.p, pos_out.p,
-                           t.idx.p, t.val.p);
+        SLP_HIP(hipGetLastError());
+        DevBuf<unsigned int> key_out((size_t)a.nnz);
+        unsigned int bits = 1;
+        while (bits < 32 && ((i64)1 << bits) < a.ncol) ++bits;
+        const unsigned int *keys_in = reinterpret_cast<const unsigned int *>(a.idx.p);
+        auto vals_in = rocprim::make_zip_iterator(rocprim::make_tuple((const i32 *)rowid.p, (const double *)a.val.p));
+        auto vals_out = rocprim::make_zip_iterator(rocprim::make_tuple(t.idx.p, t.val.p));
+        size_t bytes = 0;
+        SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, key_out.p, vals_in, vals_out, (size_t)a.nnz, 0u, bits, st));
+        {
+            DevBuf<char> tmp(bytes);
+            SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys_in, key_out.p, vals_in, vals_out, (size_t)a.nnz, 0u, bits, st));
+            SLP_HIP(hipStreamSynchronize(st));
+        }
+        rowid.release();
+        // column pointer straight from the sorted keys
+        hipLaunchKernelGGL(k_ptr_from_sorted, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, t.nrow, key_out.p, t.ptr.p);
         SLP_HIP(hipGetLastError());
         SLP_HIP(hipStreamSynchronize(st));
     } else {

@@ -524,6 +524,7 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     DevBuf<unsigned long long> sorted((size_t)a.nnz);
     DevBuf<double> svals;  // fp64 entries: the values in the sorted order
     {
+        Phase p1("  tall: keys + sort");
         DevBuf<unsigned long long> keys((size_t)a.nnz);
         DevBuf<int> bad(1);
         bad.zero();
@@ -551,6 +552,7 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     hipLaunchKernelGGL(k_tall_cellptr, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, ncell, sorted.p, cellptr.p);
     SLP_HIP(hipGetLastError());
     DevBuf<i64> sizes(2 * (size_t)B);
+    Phase p2("  tall: packets (sizes + fill)");
     if (dict)
         hipLaunchKernelGGL((k_tall_build<false, true>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, (const double *)nullptr,
                            cellptr.p, sizes.p, (const i64 *)nullptr, (const i64 *)nullptr, (TallPkt *)nullptr, (unsigned int *)nullptr,

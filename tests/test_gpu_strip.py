@@ -46,7 +46,7 @@ def test_strip_spmv_bit_exact(strips_everywhere, n, m, p):
     assert np.array_equal(a.matvec(x), oracle.matvec(oa, x))
     assert np.array_equal(a.rmatvec(y), oracle.rmatvec(oa, y))
     want = KERNEL_CODE[strips_everywhere]
-    assert _kernel(a, 0) == want and _kernel(a, 1) in (0, want)  # short transposed rows stay on the CSR kernel
+    assert _kernel(a, 0) == want and _kernel(a, 1) in (0, want, 6, 7)  # short transposed rows: CSR kernel or tall cells
 
 
 def test_value_dictionary_only_when_few_distinct_values(monkeypatch):
@@ -132,13 +132,16 @@ def test_strip_split_over_workgroups(strips_everywhere, monkeypatch, split):
 @pytest.mark.parametrize("dict_on", ["1", "0"])
 def test_wide_strips_bit_exact(monkeypatch, dict_on):
     """Rows too sparse for the LDS tile over a width far beyond an L2 (here 4 x 10^5 columns, ~40 entries per row): strips of
-    131072 columns with x gathered from L2 (k_wstrip_spmv), with the value dictionary (kernel code 4) and with fp64 entries (5)."""
+    131072 columns with x gathered from L2 (k_wstrip_spmv), with the value dictionary (kernel code 4) and with fp64 entries (5).
+    Since round 3 this shape runs on tall cells (tests/test_gpu_tall.py); the wide strips remain the fallback for what those
+    do not take (SLP_TALL=0 here)."""
     from pysparselp_amd.admm_cg import DeviceADMM
     from pysparselp_amd.problems import random_lp_on_device
     from pysparselp_amd.scale import DeviceCP
 
     monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
     monkeypatch.setenv("SLP_VALUE_DICT", dict_on)
+    monkeypatch.setenv("SLP_TALL", "0")
     n, m, p = 400000, 300000, 1e-4
     a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=2)
     s = a.download()
@@ -192,12 +195,12 @@ def test_value_dictionary_size_limit(monkeypatch, ndistinct, want):
 
 def test_randomised_shapes_all_kernel_families():
     """tools/fuzz_spmv.py: 120 random shapes around the block / strip boundaries, empty rows, both orientations, every
-    kernel family (CSR, fp64 strips, dictionary pairs and quads, wide strips) -- bit for bit against the oracle."""
+    kernel family (CSR, fp64 strips, dictionary pairs and quads, wide strips, tall cells) -- bit for bit against the oracle."""
     import os
     import sys
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_spmv
 
-    seen = fuzz_spmv.run(120, seed=1)
-    assert all(seen.get(code, 0) > 0 for code in (0, 1, 2, 3, 4, 5)), seen
+    seen = fuzz_spmv.run(160, seed=1)
+    assert all(seen.get(code, 0) > 0 for code in (0, 1, 2, 3, 4, 5, 6, 7)), seen

@@ -23,7 +23,7 @@ def run(cases, seed, verbose=False):
     seen = {}
     edges_r = [1, 2, 63, 64, 1023, 1024, 2047, 2048, 2049, 4095, 4096, 4097, 6000]
     edges_c = [1, 7, 3967, 3968, 3969, 5887, 5888, 5889, 7679, 7680, 7681, 12000, 131071, 131072, 131073, 300000]
-    saved = {k: os.environ.get(k) for k in ("SLP_STRIP_MIN_NNZ", "SLP_VALUE_DICT", "SLP_DICT_VARIANT")}
+    saved = {k: os.environ.get(k) for k in ("SLP_STRIP_MIN_NNZ", "SLP_VALUE_DICT", "SLP_DICT_VARIANT", "SLP_TALL", "SLP_TALL_R")}
     for case in range(cases):
         nrow = int(rng.choice(edges_r)) if rng.rand() < 0.7 else int(rng.randint(1, 9000))
         ncol = int(rng.choice(edges_c)) if rng.rand() < 0.7 else int(rng.randint(1, 20000))
@@ -47,6 +47,10 @@ def run(cases, seed, verbose=False):
         os.environ["SLP_STRIP_MIN_NNZ"] = "100000000000" if mode == "csr" else "1"
         os.environ["SLP_VALUE_DICT"] = "0" if mode == "fp64" else "1"
         os.environ["SLP_DICT_VARIANT"] = "2" if mode == "quads" else "1"
+        # tall cells (sparse rows over many strips) take precedence over the wide strips: rule them out now and then, and
+        # vary the height of their row blocks
+        os.environ["SLP_TALL"] = "0" if rng.rand() < 0.35 else "1"
+        os.environ["SLP_TALL_R"] = str(int(rng.choice([1024, 1500, 4096, 9984])))
         if verbose:
             print("case", case, mode, nrow, ncol, a.nnz, flush=True)
             faulthandler.cancel_dump_traceback_later()
@@ -77,7 +81,7 @@ def main():
     p.add_argument("--verbose", action="store_true")
     args = p.parse_args()
     seen = run(args.cases, args.seed, args.verbose)
-    print("ok:", args.cases, "cases; kernel codes used (0 CSR, 1 fp64 strips, 2 pairs, 3 quads, 4/5 wide):", dict(sorted(seen.items())))
+    print("ok:", args.cases, "cases; kernel codes used (0 CSR, 1 fp64 strips, 2 pairs, 3 quads, 4/5 wide, 6/7 tall cells):", dict(sorted(seen.items())))
 
 
 if __name__ == "__main__":
