@@ -203,4 +203,4 @@ def test_randomised_shapes_all_kernel_families():
     import fuzz_spmv
 
     seen = fuzz_spmv.run(160, seed=1)
-    assert all(seen.get(code, 0) > 0 for code in (0, 1, 2, 3, 4, 5, 6, 7)), seen
+    assert all(seen.get(code, 0) > 0 for code in (0, 1, 2, 3, 4, 5, 6, 7)), str(sorted(seen.items()))

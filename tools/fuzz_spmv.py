@@ -49,7 +49,7 @@ def run(cases, seed, verbose=False):
         os.environ["SLP_DICT_VARIANT"] = "2" if mode == "quads" else "1"
         # tall cells (sparse rows over many strips) take precedence over the wide strips: rule them out now and then, and
         # vary the height of their row blocks
-        os.environ["SLP_TALL"] = "0" if rng.rand() < 0.35 else "1"
+        os.environ["SLP_TALL"] = "0" if (case % 2 if ncol > 100000 else rng.rand() < 0.2) else "1"
         os.environ["SLP_TALL_R"] = str(int(rng.choice([1024, 1500, 4096, 9984])))
         if verbose:
             print("case", case, mode, nrow, ncol, a.nnz, flush=True)
