@@ -259,6 +259,74 @@ class SparseLP:
     def check_solution(self, solution, tol=1e-6):
         return bool(self.max_constraint_violation(solution) < tol)
 
+    # ------------------------------------------------------------------------- I/O
+    def save_mps(self, filename):
+        """Write the LP as an MPS file (reference SparseLP.py:280-366: objective row ``OBJ``, equality rows ``E<i>``,
+        inequality rows ``I<i>``, variables ``X<j>``, right-hand-side set ``RHS0``, bound set ``bound``).
+
+        Differences from the reference, which cannot run as written (``a_eq.ruse_preconditioning``, :310) and prints six
+        decimals: numbers are written with 17 significant digits, so that reading the file back
+        (``MPSparser.mps_parser``) returns the arrays bit for bit; two-sided and lower-bounded inequality rows are written
+        (``G`` rows, ``RANGES`` -- the reference asserts ``b_lower is None``); bounds are written only where they differ
+        from the MPS default ``[0, +inf)``.  Integer variables are refused (the reader refuses them too)."""
+        if np.any(self.is_integer):
+            raise NotImplementedError("save_mps: integer variables are not supported")
+        n = self.nb_variables
+        a_eq, a_in = scipy.sparse.csc_matrix(self.a_equalities), scipy.sparse.csc_matrix(self.a_inequalities)
+        m_in = a_in.shape[0]
+        up = np.full(m_in, np.inf) if self.b_upper is None else np.asarray(self.b_upper, dtype=np.float64)
+        lo = np.full(m_in, -np.inf) if self.b_lower is None else np.asarray(self.b_lower, dtype=np.float64)
+        if np.any(np.isneginf(lo) & np.isposinf(up)):
+            raise ValueError("save_mps: an inequality row without any finite bound cannot be written")
+
+        def num(v):
+            return "%.17g" % v
+
+        with open(filename, "w") as f:
+            f.write("NAME          exportedFromPython\nROWS\n N  OBJ\n")
+            for i in range(a_eq.shape[0]):
+                f.write(" E  E%d\n" % i)
+            # a two-sided row is an L row with a range (b_lower = rhs - range) unless only the G form (b_upper = rhs + range)
+            # reproduces both bounds exactly
+            g_row = ~np.isfinite(up)
+            both = np.isfinite(up) & np.isfinite(lo)
+            with np.errstate(invalid="ignore"):
+                g_row |= both & (up - (up - lo) != lo) & (lo + (up - lo) == up)
+            for i in range(m_in):
+                f.write(" %s  I%d\n" % ("G" if g_row[i] else "L", i))
+            f.write("COLUMNS\n")
+            for j in range(n):
+                f.write("    X%-9d OBJ        %s\n" % (j, num(self.costsvector[j])))
+                for k in range(a_eq.indptr[j], a_eq.indptr[j + 1]):
+                    f.write("    X%-9d E%-9d %s\n" % (j, a_eq.indices[k], num(a_eq.data[k])))
+                for k in range(a_in.indptr[j], a_in.indptr[j + 1]):
+                    f.write("    X%-9d I%-9d %s\n" % (j, a_in.indices[k], num(a_in.data[k])))
+            f.write("RHS\n")
+            for i in range(a_eq.shape[0]):
+                f.write("    RHS0       E%-9d %s\n" % (i, num(self.b_equalities[i])))
+            for i in range(m_in):
+                f.write("    RHS0       I%-9d %s\n" % (i, num(lo[i] if g_row[i] else up[i])))
+            f.write("RANGES\n")
+            for i in range(m_in):
+                if np.isfinite(up[i]) and np.isfinite(lo[i]):
+                    f.write("    RNG0       I%-9d %s\n" % (i, num(up[i] - lo[i])))
+            f.write("BOUNDS\n")
+            for j in range(n):
+                l, u = self.lower_bounds[j], self.upper_bounds[j]
+                if np.isneginf(l) and np.isposinf(u):
+                    f.write(" FR bound      X%d\n" % j)
+                    continue
+                if l == u:
+                    f.write(" FX bound      X%-9d %s\n" % (j, num(l)))
+                    continue
+                if np.isneginf(l):
+                    f.write(" MI bound      X%d\n" % j)
+                elif l != 0:
+                    f.write(" LO bound      X%-9d %s\n" % (j, num(l)))
+                if not np.isposinf(u):
+                    f.write(" UP bound      X%-9d %s\n" % (j, num(u)))
+            f.write("ENDATA\n")
+
     # ----------------------------------------------------------------------- solve
     def solve(
         self,

@@ -101,3 +101,55 @@ def test_netlib_problem_through_the_modelling_layer():
     lp.add_inequality_constraints_sparse(d["a_ineq"], d["b_lower"], d["b_upper"])
     assert lp.check_solution(gt)
     assert abs(lp.costsvector @ gt - (-406659 / 875)) < 1e-9  # data/perPlex/afiro.txt "Objvalue"
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "KB2", "SC50A", "SC50B", "SC105"])
+def test_save_mps_round_trips_through_the_reader(name, tmp_path):
+    """``SparseLP.save_mps`` (reference SparseLP.py:280-366, which cannot run as written: :310): the five netlib problems
+    written and read back give the same LP array for array (rows and variables are renamed E<i> / I<i> / X<j> in order)."""
+    from conftest import lp_from_golden  # noqa: F401  (same construction, from the parsed dictionary)
+    from pysparselp_amd.SparseLP import SparseLP
+
+    d = get_problem(name, data_dir=NETLIB)
+    lp = SparseLP()
+    lp.nb_variables = d["cost_vector"].size
+    lp.costsvector, lp.lower_bounds, lp.upper_bounds = d["cost_vector"], d["lower_bounds"], d["upper_bounds"]
+    lp.is_integer = np.zeros(lp.nb_variables, dtype=bool)
+    lp.a_equalities, lp.b_equalities = scipy.sparse.csr_matrix(d["a_eq"]), d["b_eq"]
+    lp.a_inequalities, lp.b_lower, lp.b_upper = scipy.sparse.csr_matrix(d["a_ineq"]), d["b_lower"], d["b_upper"]
+    path = tmp_path / (name + ".mps")
+    lp.save_mps(str(path))
+    with open(path) as f:
+        back = mps_parser(f)
+    for key in ("cost_vector", "upper_bounds", "lower_bounds", "b_eq", "b_lower", "b_upper"):
+        assert np.array_equal(back[key], d[key]), key
+    for key in ("a_eq", "a_ineq"):
+        m0, m1 = scipy.sparse.csr_matrix(d[key]), scipy.sparse.csr_matrix(back[key])
+        m0.sort_indices()
+        m1.sort_indices()
+        assert m0.shape == m1.shape and np.array_equal(m0.indptr, m1.indptr) and np.array_equal(m0.indices, m1.indices)
+        assert np.array_equal(m0.data, m1.data)
+
+
+def test_save_mps_two_sided_rows_free_and_fixed_variables(tmp_path):
+    from pysparselp_amd.SparseLP import SparseLP
+
+    lp = SparseLP()
+    x = lp.add_variables_array(5, lower_bounds=None, upper_bounds=None, costs=np.array([1.0, -2.5, 0.1, 0.0, 1e-17]))
+    lp.set_bounds_on_variables(x[1:2], 0.25, 0.25)          # fixed
+    lp.set_bounds_on_variables(x[2:3], -np.inf, 3.0)        # MI + UP
+    lp.set_bounds_on_variables(x[3:4], 1.0 / 3.0, np.inf)   # LO only
+    lp.set_bounds_on_variables(x[4:5], 0.0, np.inf)         # the MPS default: nothing written
+    a = scipy.sparse.csr_matrix(np.array([[1.0, 2.0, 0, 0, 0.1], [0, 1.0 / 7.0, -1.0, 0, 0], [0, 0, 0, 5.0, 1.0]]))
+    lp.add_inequality_constraints_sparse(a, lower_bounds=np.array([-1.0, -np.inf, 0.5]), upper_bounds=np.array([2.0, 4.0, np.inf]))
+    lp.add_equality_constraints_sparse(scipy.sparse.csr_matrix(np.array([[1.0, 1.0, 1.0, 1.0, 1.0]])), np.array([2.0 / 3.0]))
+    path = tmp_path / "small.mps"
+    lp.save_mps(str(path))
+    with open(path) as f:
+        back = mps_parser(f)
+    assert np.array_equal(back["cost_vector"], lp.costsvector)
+    assert np.array_equal(back["lower_bounds"], lp.lower_bounds) and np.array_equal(back["upper_bounds"], lp.upper_bounds)
+    assert np.array_equal(back["b_eq"], lp.b_equalities)
+    assert np.array_equal(back["b_upper"], lp.b_upper) and np.array_equal(back["b_lower"], lp.b_lower)
+    assert np.array_equal(scipy.sparse.csr_matrix(back["a_ineq"]).toarray(), lp.a_inequalities.toarray())
+    assert np.array_equal(scipy.sparse.csr_matrix(back["a_eq"]).toarray(), lp.a_equalities.toarray())
