@@ -68,7 +68,10 @@ __device__ __forceinline__ double at_elem(i64 j, i64 n_o, const double *__restri
 
 // Elementwise passes over the N unknowns.  Each also produces one dot product, split into the part over
 // the replicated original variables (slot) and the part over this rank's slack variables (slot + 1).
-enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7, E_RESID_REUSE = 8, E_GRAD = 9, E_RESID_FUSED = 10, E_LINE_DMD_MD = 11 };
+enum { E_RHS = 0, E_LINE_T = 1, E_LINE_DMD = 2, E_LINE_STEP = 3, E_RESID = 4, E_PAP = 5, E_UPDATE = 6, E_PROJECT = 7, E_RESID_REUSE = 8, E_GRAD = 9, E_RESID_FUSED = 10, E_LINE_DMD_MD = 11,
+       E_GRAD_DMD = 12,    // E_GRAD and E_LINE_DMD_MD in one pass (two dot products: part[b] and part[kCgPartials + b])
+       E_STEP_RESID = 13   // E_LINE_STEP and E_RESID_FUSED in one pass (both need the line-search step only)
+};
 
 struct CgVecs {
     const double *q, *c, *lb, *ub, *u, *sc, *w;
@@ -86,10 +89,10 @@ struct CgVecs {
 template <int OP>
 __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict__ part, int go) {
     __shared__ double lds[kBlock / kWave];
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
     double f = 0.0;
     bool on = true;
-    if (OP == E_LINE_STEP || OP == E_RESID_REUSE || OP == E_RESID_FUSED) {
+    if (OP == E_LINE_STEP || OP == E_RESID_REUSE || OP == E_RESID_FUSED || OP == E_STEP_RESID) {
         const double t = -(a.scal[S_T] + a.scal[S_T + 1]);
         on = fabs(t) > 0.0;                                      // ADMM.py:192
         f = t / (a.scal[S_DMD] + a.scal[S_DMD + 1]);             // :193
@@ -141,6 +144,18 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
             const double r = on ? -(a.mx[j] + f * a.md[j]) : -a.mx[j];
             a.r[j] = r;
             term = r * r;
+        } else if (OP == E_GRAD_DMD) {  // E_GRAD, then E_LINE_DMD_MD on the same j (same arithmetic, one pass over dir)
+            const double g = (at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.x[j]) - ((a.q[j] + a.gamma_ineq * a.xp[j]) - a.lin[j]);
+            a.mx[j] = g;
+            a.xprev[j] = a.x[j];
+            const double dj = a.dir[j];
+            term = dj * g;
+            acc2 += dj * a.md[j];
+        } else if (OP == E_STEP_RESID) {  // E_LINE_STEP, then E_RESID_FUSED on the same j
+            if (on) a.x[j] = a.x[j] + f * a.dir[j];
+            const double r = on ? -(a.mx[j] + f * a.md[j]) : -a.mx[j];
+            a.r[j] = r;
+            term = r * r;
         } else if (OP == E_PAP) {  // p.(M p) (conjgrad :37-38)
             const double ap = a.gamma_eq * at_elem(j, a.n_o, a.u, a.sc, a.w) + a.gamma_ineq * a.r[j];
             if (a.carry_md) a.y[j] = ap;  // y is free in the fused form
@@ -162,9 +177,13 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
         acc += term;
     }
     if (OP == E_LINE_T || OP == E_LINE_DMD || OP == E_RESID || OP == E_RESID_REUSE || OP == E_PAP || OP == E_GRAD ||
-        OP == E_RESID_FUSED || OP == E_LINE_DMD_MD) {
+        OP == E_RESID_FUSED || OP == E_LINE_DMD_MD || OP == E_GRAD_DMD || OP == E_STEP_RESID) {
         const double r = block_reduce<false>(acc, lds);
         if (threadIdx.x == 0) part[blockIdx.x] = r;
+    }
+    if (OP == E_GRAD_DMD) {
+        const double r = block_reduce<false>(acc2, lds);
+        if (threadIdx.x == 0) part[kCgPartials + blockIdx.x] = r;
     }
 }
 
@@ -191,6 +210,25 @@ __global__ __launch_bounds__(kBlock) void k_cg_finish(int go, int nparts, const 
             sl = fabs(t) > 0.0 ? (tail[0] + 2.0 * f * tail[1]) + (f * f) * tail[2] : tail[0];
         }
         scal[slot + 1] = sl;
+    }
+}
+
+// k_cg_finish for the two dot products of E_GRAD_DMD: (S_T from part[.], S_DMD from part[kCgPartials + .]); with the
+// packed exchange their slack parts are tail[0] and tail[1]
+__global__ __launch_bounds__(kBlock) void k_cg_finish2(int go, int nparts, const double *__restrict__ part, double *__restrict__ scal,
+                                                       const double *__restrict__ tail, int tail_mode) {
+    __shared__ double lds[kBlock / kWave];
+    for (int which = 0; which < 2; ++which) {
+        const double *pp = part + which * kCgPartials;
+        double a = 0.0, b = 0.0;
+        for (int i = threadIdx.x; i < go; i += kBlock) a += pp[i];
+        for (int i = go + threadIdx.x; i < nparts; i += kBlock) b += pp[i];
+        const double ra = block_reduce<false>(a, lds), rb = block_reduce<false>(b, lds);
+        if (threadIdx.x == 0) {
+            const int slot = which == 0 ? S_T : S_DMD;
+            scal[slot] = ra;
+            scal[slot + 1] = tail_mode == 1 ? tail[which] : rb;
+        }
     }
 }
 
@@ -256,17 +294,29 @@ __global__ void k_cg_wd_update(i64 m, const double *__restrict__ scal, const dou
 }
 
 // lambda_eq_i += gamma_eq (w_i - b_i)  (:261-263), w = A x
+// (rs != NULL: deferred row scaling -- the copy rs o v1 that the A^T product of the next x-step reads is written here too,
+// instead of by a pass of its own in front of that product)
 __global__ void k_cg_multiplier(i64 m, const double *__restrict__ w, const double *__restrict__ b, double gamma_eq,
-                                double *__restrict__ lam, double *__restrict__ v1) {
+                                double *__restrict__ lam, double *__restrict__ v1, const double *__restrict__ rs,
+                                double *__restrict__ v1s) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
         const double l = lam[i] + gamma_eq * (w[i] - b[i]);
         lam[i] = l;
-        if (v1) v1[i] = gamma_eq * w[i] + l;  // fused mode: A^T (g_eq A x + lambda) is one product in the next iteration
+        if (v1) {  // fused mode: A^T (g_eq A x + lambda) is one product in the next iteration
+            const double v = gamma_eq * w[i] + l;
+            v1[i] = v;
+            if (rs) v1s[i] = rs[i] * v;
+        }
     }
 }
 
-__global__ void k_cg_v1(i64 m, const double *__restrict__ w, const double *__restrict__ lam, double gamma_eq, double *__restrict__ v1) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) v1[i] = gamma_eq * w[i] + lam[i];
+__global__ void k_cg_v1(i64 m, const double *__restrict__ w, const double *__restrict__ lam, double gamma_eq, double *__restrict__ v1,
+                        const double *__restrict__ rs, double *__restrict__ v1s) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        const double v = gamma_eq * w[i] + lam[i];
+        v1[i] = v;
+        if (rs) v1s[i] = rs[i] * v;
+    }
 }
 
 __global__ void k_cg_q(i64 N, i64 n_o, const double *__restrict__ c, const double *__restrict__ u, const double *__restrict__ sc,
@@ -436,6 +486,7 @@ struct slp_admm_cg {
                           // 2: additionally A^T (g_eq A x + lambda_eq) as one product (6 products, 4 passes with strips)
     DevBuf<double> sc, b, lam, w;                                         // rows
     DevBuf<double> rs, ws0, ws1;   // deferred row scaling (value-dictionary strips): A = diag(rs) A0; scratch rs o w
+    DevBuf<double> wsw, wsv1;      // ... rs o w and rs o v1, written by the kernels that produce w and v1
     DevBuf<double> c, lb, ub, x, xp, y, q, dir, xprev, r, lin, u, mx, md;        // unknowns (u: n_o)
     DevBuf<double> part, rowpart, colpart, scal, out;
     DevBuf<double> wx, wd, u2, v1;   // batched form: A x, A dir, g_eq A x + lambda (rows) and the two A^T products (2 n_o)
@@ -447,13 +498,15 @@ struct slp_admm_cg {
 namespace slp {
 
 // w = rs o w (deferred row scale, optional) + sc o vs (the slack column, optional)
+// (wsc != NULL: also rs o w of the finished w, the vector the A^T product that follows reads)
 __global__ void k_cg_add_slack(i64 m, const double *__restrict__ rs, const double *__restrict__ sc, const double *__restrict__ vs,
-                               double *__restrict__ w) {
+                               double *__restrict__ w, double *__restrict__ wsc) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
         double v = w[i];
         if (rs) v = rs[i] * v;
         if (sc) v = v + sc[i] * vs[i];
         w[i] = v;
+        if (wsc) wsc[i] = rs[i] * v;
     }
 }
 
@@ -463,14 +516,18 @@ __global__ void k_cg_row_scaled(i64 m, const double *__restrict__ rs, const doub
 
 static void cg_finish_rows(slp_admm_cg *s, const double *v, double *w) {
     if (!s->ns && !s->rs.p) return;
+    // the solver's own w = A v is what cg_cols multiplies next: its row-scaled copy is written in the same pass
+    double *wsc = (s->rs.p && w == s->w.p) ? s->wsw.p : nullptr;
     hipLaunchKernelGGL(k_cg_add_slack, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->rs.p,
-                       s->ns ? s->sc.p : (double *)nullptr, v + s->n_o, w);
+                       s->ns ? s->sc.p : (double *)nullptr, v + s->n_o, w, wsc);
     SLP_HIP(hipGetLastError());
 }
 
 // rs o w in scratch (deferred row scaling) or w itself
 static const double *cg_scaled_rows(slp_admm_cg *s, const double *w, DevBuf<double> &tmp) {
     if (!s->rs.p) return w;
+    if (w == s->w.p) return s->wsw.p;                 // written by cg_finish_rows together with w
+    if (w == s->v1.p && s->v1.p) return s->wsv1.p;    // written by k_cg_multiplier / k_cg_v1 together with v1
     if (tmp.n < (size_t)s->m) tmp.alloc((size_t)s->m);
     hipLaunchKernelGGL(k_cg_row_scaled, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->rs.p, w, tmp.p);
     SLP_HIP(hipGetLastError());
@@ -576,6 +633,19 @@ static void cg_elem(slp_admm_cg *s, int slot, const double *u = nullptr, const d
     }
 }
 
+// E_GRAD and E_LINE_DMD_MD in one pass, both dot products finished by one launch
+static void cg_elem2_grad_dmd(slp_admm_cg *s, const double *u, const double *w, const double *tail, int tail_mode) {
+    int go, gs;
+    cg_grids(s, &go, &gs);
+    hipLaunchKernelGGL((k_cg_elem<E_GRAD_DMD>), dim3(go + gs), dim3(kBlock), 0, ctx().stream, cg_vecs(s, u, w), s->part.p, go);
+    hipLaunchKernelGGL(k_cg_finish2, dim3(1), dim3(kBlock), 0, ctx().stream, go, go + gs, s->part.p, s->scal.p, tail, tail_mode);
+    SLP_HIP(hipGetLastError());
+    if (s->distributed && !tail_mode) {  // (not reached at level 4: the packed exchange carries the slack parts)
+        comm_allreduce_dev(s->scal.p + S_T + 1, 1, 0);
+        comm_allreduce_dev(s->scal.p + S_DMD + 1, 1, 0);
+    }
+}
+
 // Packed exchange: the rank-local slack sums land in `tail` (device, right behind the vector the next all-reduce sends)
 static void cg_slack_pre(slp_admm_cg *s, bool refresh, double *tail) {
     const int g = std::min(grid_for(s->N - s->n_o, kBlock), kCgPartials / 8);
@@ -621,7 +691,7 @@ static void cg_xstep(slp_admm_cg *s) {
         if (!s->have_w) {
             cg_refresh_products(s);
             hipLaunchKernelGGL(k_cg_v1, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->wx.p, s->lam.p,
-                               s->gamma_eq, s->v1.p);
+                               s->gamma_eq, s->v1.p, s->rs.p, s->wsv1.p);
             SLP_HIP(hipGetLastError());
         }
         // Rows partitioned, level 4: the slack parts of ALL dot products of the iteration ride behind the two vector
@@ -632,10 +702,8 @@ static void cg_xstep(slp_admm_cg *s) {
             double *tail = s->u2.p + s->n_o;
             if (packed) cg_slack_pre(s, false, tail);
             cg_cols(s, s->v1.p, s->u2.p, true, packed ? 5 : 0);
-            cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p, tail, packed ? 1 : 0);
-            cg_elem<E_LINE_DMD_MD>(s, S_DMD, nullptr, nullptr, tail + 1, packed ? 1 : 0);
-            cg_elem<E_LINE_STEP>(s, -1);
-            cg_elem<E_RESID_FUSED>(s, S_RS, nullptr, nullptr, tail + 2, packed ? 2 : 0);
+            cg_elem2_grad_dmd(s, s->u2.p, s->v1.p, tail, packed ? 1 : 0);
+            cg_elem<E_STEP_RESID>(s, S_RS, nullptr, nullptr, tail + 2, packed ? 2 : 0);
         } else {
             double *tail = s->u2.p + 2 * s->n_o;
             if (packed) cg_slack_pre(s, true, tail);
@@ -643,8 +711,7 @@ static void cg_xstep(slp_admm_cg *s) {
             cg_elem<E_GRAD>(s, S_T, s->u2.p, s->v1.p, tail, packed ? 1 : 0);
             cg_elem<E_LINE_DMD>(s, S_DMD, s->u2.p + s->n_o, s->wd.p, tail + 1, packed ? 1 : 0);
             s->need_md = false;
-            cg_elem<E_LINE_STEP>(s, -1);
-            cg_elem<E_RESID_FUSED>(s, S_RS, nullptr, nullptr, tail + 2, packed ? 2 : 0);
+            cg_elem<E_STEP_RESID>(s, S_RS, nullptr, nullptr, tail + 2, packed ? 2 : 0);
         }
         cg_rows(s, s->r.p);
         if (packed) cg_slack_pap(s, s->w.p, s->u.p + s->n_o);
@@ -700,7 +767,7 @@ static void cg_multipliers(slp_admm_cg *s) {
     }
     if (s->m) {
         hipLaunchKernelGGL(k_cg_multiplier, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, ax, s->b.p,
-                           s->gamma_eq, s->lam.p, (s->reuse >= 2 && ax == s->wx.p) ? s->v1.p : (double *)nullptr);
+                           s->gamma_eq, s->lam.p, (s->reuse >= 2 && ax == s->wx.p) ? s->v1.p : (double *)nullptr, s->rs.p, s->wsv1.p);
         SLP_HIP(hipGetLastError());
     }
 }
@@ -803,13 +870,15 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
             SLP_REQUIRE(!a_ineq->scaled, "slp_admm_cg_create_on: this matrix was already row-normalised in place by an earlier ADMM "
                                          "setup; scaling it again would solve a different problem -- build the solver on a fresh matrix");
             bool deferred = false;
-            if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1) || strip_wanted(a, 3)) && matrix_dictionary(a_ineq)) {
+            if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1) || strip_wanted(a, 3) || tall_wanted(a)) && matrix_dictionary(a_ineq)) {
                 build_transpose(a_ineq);
                 const StripJds *f0 = fast_format(a_ineq, false), *f1 = fast_format(a_ineq, true);
                 deferred = f0 && f1 && f0->D > 0 && f1->D > 0;
             }
             if (deferred) {
                 s->rs.alloc((size_t)m);
+                s->wsw.alloc((size_t)m);
+                s->wsv1.alloc((size_t)m);
                 const int lanes = lanes_for(a, SLP_ORDER_TREE);
                 SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_row_scales<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0, st,
                                                              m, (i64)m_eq, a.ptr.p, a.val.p, bu.p, s->sc.p, s->rs.p, bl.p));
