@@ -47,6 +47,17 @@ __global__ void k_cp_colsum(i64 n, const i64 *__restrict__ ptr, const i32 *__res
     }
 }
 
+// |dict|^p for the strip copies' value table; fill; T from the two partial column sums
+__global__ void k_cp_dict_pow(int D, const double *__restrict__ dict, double p, double *__restrict__ out) {
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < D; q += gridDim.x * blockDim.x) out[q] = abs_pow(dict[q], p) * 1.0;
+}
+__global__ void k_cp_indicator(i64 m, i64 lo, i64 hi, double *__restrict__ y) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) y[i] = (i >= lo && i < hi) ? 1.0 : 0.0;
+}
+__global__ void k_cp_join_sums(i64 n, const double *__restrict__ se, const double *__restrict__ si, double *__restrict__ t) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) t[j] = (0.0 + se[j]) + si[j];
+}
+
 __global__ void k_invert_or_one(i64 n, double *__restrict__ v) {
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
         double t = v[j];
@@ -441,20 +452,60 @@ static void cp_setup(slp_cp *s) {
         if (small && s->lanes_rows == 1) build(a, s->ell_w_rows, s->ell_idx_rows, s->ell_val_rows, s->ell_len_rows);
         if (small && s->lanes_cols == 1) build(at, s->ell_w_cols, s->ell_idx_cols, s->ell_val_cols, s->ell_len_cols);
     }
+    // Preconditioners (ChambollePockPPD.py:122-179): T_j = 1 / sum_i |K_ij|^(2-alpha), Sigma_i = 1 / sum_j |K_ij|^alpha (0 -> 1).
+    // On value-dictionary copies the sums are products with a vector of ones over the copy whose value table is |v|^p --
+    // the same chain of additions per column / row (storage order, from 0.0) as the CSR walks below, which read every entry
+    // through one thread per row (17-19 x the matrix in HBM traffic at config 3, profiles/r02_c3_pmc_hbm.json) -- and they
+    // need no CSR arrays.  Equality and inequality rows are summed apart ((0 + s_eq) + s_ineq, :134,144): two products.
+    const StripJds *ft = fast_format(s->k, true), *fr = fast_format(s->k, false);
     if (s->n) {
-        hipLaunchKernelGGL(k_cp_colsum, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p, at.val.p,
-                           (i32)s->m_eq, s->m_ineq, 2.0 - s->alpha, s->t.p, s->distributed ? 0 : 1);
-        SLP_HIP(hipGetLastError());
-        if (s->distributed) {
-            comm_allreduce_dev(s->t.p, s->n, 0);
+        if (ft && ft->D > 0) {
+            DevBuf<double> table((size_t)ft->D), ones((size_t)std::max<i64>(s->m, 1));
+            hipLaunchKernelGGL(k_cp_dict_pow, dim3(8), dim3(kBlock), 0, st, ft->D, ft->dict, 2.0 - s->alpha, table.p);
+            if (s->m_eq > 0 && s->m_ineq > 0) {
+                DevBuf<double> se((size_t)s->n), si((size_t)s->n);
+                hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, (i64)0, s->m_eq, ones.p);
+                strip_spmv_with_dict(*ft, table.p, ones.p, se.p);
+                hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, s->m_eq, s->m, ones.p);
+                strip_spmv_with_dict(*ft, table.p, ones.p, si.p);
+                hipLaunchKernelGGL(k_cp_join_sums, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, se.p, si.p, s->t.p);
+                SLP_HIP(hipStreamSynchronize(st));
+            } else {
+                hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, (i64)0, s->m, ones.p);
+                strip_spmv_with_dict(*ft, table.p, ones.p, s->t.p);
+                SLP_HIP(hipStreamSynchronize(st));
+            }
+            SLP_HIP(hipGetLastError());
+            if (s->distributed) comm_allreduce_dev(s->t.p, s->n, 0);
             hipLaunchKernelGGL(k_invert_or_one, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, s->t.p);
             SLP_HIP(hipGetLastError());
+        } else {
+            require_csr(s->k, "Chambolle-Pock preconditioner T (CSR walk)");
+            hipLaunchKernelGGL(k_cp_colsum, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p, at.val.p,
+                               (i32)s->m_eq, s->m_ineq, 2.0 - s->alpha, s->t.p, s->distributed ? 0 : 1);
+            SLP_HIP(hipGetLastError());
+            if (s->distributed) {
+                comm_allreduce_dev(s->t.p, s->n, 0);
+                hipLaunchKernelGGL(k_invert_or_one, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, s->t.p);
+                SLP_HIP(hipGetLastError());
+            }
         }
     }
     if (s->m) {
-        hipLaunchKernelGGL(k_cp_rowsum, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, a.ptr.p, a.val.p, s->alpha,
-                           s->sigma.p);
-        SLP_HIP(hipGetLastError());
+        if (fr && fr->D > 0) {
+            DevBuf<double> table((size_t)fr->D), ones((size_t)std::max<i64>(s->n, 1));
+            hipLaunchKernelGGL(k_cp_dict_pow, dim3(8), dim3(kBlock), 0, st, fr->D, fr->dict, s->alpha, table.p);
+            hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, (i64)0, s->n, ones.p);
+            strip_spmv_with_dict(*fr, table.p, ones.p, s->sigma.p);
+            hipLaunchKernelGGL(k_invert_or_one, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, s->sigma.p);
+            SLP_HIP(hipGetLastError());
+            SLP_HIP(hipStreamSynchronize(st));
+        } else {
+            require_csr(s->k, "Chambolle-Pock preconditioner Sigma (CSR walk)");
+            hipLaunchKernelGGL(k_cp_rowsum, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, a.ptr.p, a.val.p, s->alpha,
+                               s->sigma.p);
+            SLP_HIP(hipGetLastError());
+        }
     }
     // ELL copies are the solver's own; everything else that is not a strip copy walks the matrix's CSR arrays
     s->csr_bound = (s->n > 0 && !cp_primal_strips(s) && !s->ell_w_cols) || (s->m > 0 && !fast_format(s->k, false) && !s->ell_w_rows);
@@ -600,7 +651,6 @@ slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const dou
                          const double *ub, const double *x0, double alpha, double theta, int order) {
     SLP_API_PTR({
         SLP_REQUIRE(a && b && c && lb && ub, "slp_cp_create_on: NULL argument");
-        require_csr(a, "slp_cp_create_on");  // the preconditioners are sums over the CSR entries
         slp_cp *s = cp_make(a, false, m_eq, b, c, lb, ub, x0, alpha, theta, order);
         ++a->borrowers;
         if (s->csr_bound) ++a->csr_bound;

@@ -1019,6 +1019,22 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
     SLP_HIP(hipGetLastError());
 }
 
+// The same product with another value table behind the same ids: the copy of the matrix whose stored values are
+// table[id] instead of dict[id] (e.g. |value|^p for the Chambolle-Pock preconditioners) -- valid for dictionary copies.
+void strip_spmv_with_dict(const StripJds &f, const double *table, const double *x, double *out) {
+    SLP_REQUIRE(f.D > 0 && table, "strip_spmv_with_dict: the copy has no value dictionary");
+    StripJds &g = const_cast<StripJds &>(f);
+    const double *saved = g.dict;
+    g.dict = table;  // (kernel arguments are taken at launch; the launch order on the stream does the rest)
+    try {
+        strip_spmv(f, x, out);
+    } catch (...) {
+        g.dict = saved;
+        throw;
+    }
+    g.dict = saved;
+}
+
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1) {
     if (f.wide || f.tall) {
         // two strips of x would compete for the L2: two passes

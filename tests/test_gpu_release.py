@@ -29,10 +29,15 @@ def test_iterations_are_unchanged_after_the_csr_entries_are_released():
                     a.download()
                 with pytest.raises(_lib.SlpError, match="released"):
                     a.set_format(1)
-                with pytest.raises(_lib.SlpError, match="released"):
-                    DeviceCP(a, b, c, lb, ub)
+                # a NEW Chambolle-Pock solver can still be set up: its preconditioners are products over the strip copies
+                late = DeviceCP(a, b, c, lb, ub)
+                late.iterate(40)
+                x_late = late.x()
+                late.close()
             cp.iterate(40)
             admm.iterate(40)
+            if release:
+                assert np.array_equal(x_late, cp.x())   # set up after the release == set up before it
             # the reference's periodic report (ChambollePockPPD.py:242-329, ADMM.py:213-248) between the two halves of an
             # iteration: formed through the strip copies, so it needs no CSR arrays and does not change with the release
             cp.primal_step()
