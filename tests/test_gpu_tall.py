@@ -52,10 +52,14 @@ def _check(a_host, rows_per_block=None, transposed_too=True):
 
 
 def _random(m, n, density, seed, decimals=2):
+    """Uniformly placed entries with rounded values (few distinct values: a value dictionary exists)."""
     rng = np.random.RandomState(seed)
-    a = scipy.sparse.random(m, n, density=density, format="csr", random_state=rng, data_rvs=lambda k: np.round(rng.randn(k), decimals))
-    a.data[a.data == 0] = 0.5
+    k = int(round(density * m * n))
+    a = scipy.sparse.coo_matrix((np.ones(k), (rng.randint(0, m, size=k), rng.randint(0, n, size=k))), shape=(m, n)).tocsr()
+    a.sum_duplicates()
     a.sort_indices()
+    a.data = np.round(rng.randn(a.nnz), decimals)
+    a.data[a.data == 0] = 0.5
     return a
 
 
@@ -73,12 +77,14 @@ def test_transpose_of_a_wide_slice_runs_on_tall_cells_too():
 
 def test_rows_longer_than_a_packet_takes_continue_in_later_packets():
     rng = np.random.RandomState(4)
-    a = _random(6000, 40000, 1e-4, 5).tolil()
+    base = _random(6000, 40000, 1e-4, 5).tocoo()
+    rows, cols, vals = [base.row], [base.col], [base.data]
     for r, (c0, k) in ((7, (100, 40)), (8, (4096 * 3 + 5, 7)), (4000, (4096 * 9 - 13, 30)), (5999, (0, 13))):
-        cols = c0 + np.sort(rng.choice(200, size=k, replace=False))   # k entries inside one or two strips
-        for c in cols:
-            a[r, c] = np.round(rng.randn(), 1) or 0.3
-    a = a.tocsr()
+        cc = c0 + np.sort(rng.choice(200, size=k, replace=False))   # k entries inside one or two strips
+        keep = ~((rows[0] == r) & np.isin(cols[0], cc))
+        rows[0], cols[0], vals[0] = rows[0][keep], cols[0][keep], vals[0][keep]
+        rows.append(np.full(k, r)); cols.append(cc); vals.append(np.where(np.round(rng.randn(k), 1) == 0, 0.3, np.round(rng.randn(k), 1)))
+    a = scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=base.shape).tocsr()
     a.sort_indices()
     assert np.diff(a.indptr).max() >= 40
     _check(a, 1024)
@@ -86,12 +92,11 @@ def test_rows_longer_than_a_packet_takes_continue_in_later_packets():
 
 
 def test_empty_rows_cells_and_strips():
-    a = _random(5000, 70000, 5e-5, 6).tolil()
-    a[100:400, :] = 0                               # empty rows
-    a[:, 4096 * 2:4096 * 5] = 0                     # three empty strips: every row block skips those cells
-    a[1024:2048, 4096 * 7:] = 0                     # a row block whose last cells are empty
-    a = a.tocsr()
-    a.eliminate_zeros()
+    a = _random(5000, 70000, 5e-5, 6).tocoo()
+    drop = ((a.row >= 100) & (a.row < 400))                                  # empty rows
+    drop |= (a.col >= 4096 * 2) & (a.col < 4096 * 5)                         # three empty strips: every row block skips those cells
+    drop |= (a.row >= 1024) & (a.row < 2048) & (a.col >= 4096 * 7)           # a row block whose last cells are empty
+    a = scipy.sparse.coo_matrix((a.data[~drop], (a.row[~drop], a.col[~drop])), shape=a.shape).tocsr()
     a.sort_indices()
     _check(a, 1024)
 
