@@ -161,6 +161,7 @@ bool comm_active();
 void comm_allreduce_dev(double *buf, i64 count, int op);
 void comm_allreduce_dev_async(double *buf, i64 count, int op);
 void comm_join();
+void comm_sync_side();
 
 // v = xp - lambda / gamma  (original part)
 __global__ void k_rb_v(i64 n, const double *__restrict__ xp, const double *__restrict__ lam, double gamma, double *__restrict__ v) {
@@ -314,6 +315,7 @@ struct slp_blocks {
     // one block per rank over a caller-owned row block (slp_blocks_create_on)
     IterGraph cg_graph;       // `check_every` CG steps captured once (launch-bound problems)
     bool row_block = false, distributed = false;
+    bool grouped = false;     // linked into a group (slp_blocks_group_link): its copy counts are the group's totals
     i64 m_eq = 0;
     DevBuf<unsigned char> used;
     DevBuf<double> copies, acc, vs, xs, xps, lams, slo, shi;
@@ -614,6 +616,17 @@ int slp_blocks_group_link(slp_blocks **blocks, int count) {
         for (int g = 0; g < count; ++g) {
             SLP_REQUIRE(blocks[g] && blocks[g]->row_block, "slp_blocks_group_link: blocks must come from slp_blocks_create_on");
             SLP_REQUIRE(blocks[g]->N == blocks[0]->N && blocks[g]->gamma == blocks[0]->gamma, "slp_blocks_group_link: blocks differ in n / gamma");
+            // linking replaces every block's copy counts by the group totals: a second link (or a block in two groups) would
+            // count its copies twice and the consensus would divide by the wrong number, silently
+            SLP_REQUIRE(!blocks[g]->grouped, "slp_blocks_group_link: a block is already part of a group");
+            for (int h = 0; h < g; ++h) SLP_REQUIRE(blocks[h] != blocks[g], "slp_blocks_group_link: the same block twice");
+        }
+        if (blocks[0]->distributed) {
+            // the overlapped iteration issues `count` all-reduces per iteration: every rank must bring the same number of
+            // blocks, or the ranks deadlock inside the collective library instead of failing here
+            double mm[2] = {(double)count, -(double)count};
+            SLP_REQUIRE(slp_comm_allreduce_host(mm, 2, 1) == 0, slp_last_error());
+            SLP_REQUIRE(mm[0] == (double)count && -mm[1] == (double)count, "slp_blocks_group_link: the ranks link different numbers of blocks");
         }
         // copies_j = number of blocks (of all ranks) that use variable j: each block holds its own count summed over the
         // ranks (slp_blocks_create_on); the group total goes into every block
@@ -623,7 +636,7 @@ int slp_blocks_group_link(slp_blocks **blocks, int count) {
         for (int g = 0; g < count; ++g)
             hipLaunchKernelGGL(k_rb_accumulate, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, blocks[g]->copies.p, total.p);
         SLP_HIP(hipGetLastError());
-        for (int g = 0; g < count; ++g) blocks[g]->copies.copy_from(total);
+        for (int g = 0; g < count; ++g) { blocks[g]->copies.copy_from(total); blocks[g]->grouped = true; }
         SLP_HIP(hipStreamSynchronize(ctx().stream));
     })
 }
@@ -638,9 +651,14 @@ int slp_blocks_group_iterate(slp_blocks **blocks, int count, int64_t k) {
             // travels over xGMI while the NEXT block's projection computes; only the last block's exchange is exposed.
             // (One rank, or one block: a single all-reduce of the sum, as before.)
             const bool overlap = s0->distributed && count > 1;
-            for (int g = 0; g < count; ++g) {
-                rb_project(blocks[g]);
-                if (overlap) comm_allreduce_dev_async(blocks[g]->acc.p, n, 0);
+            try {
+                for (int g = 0; g < count; ++g) {
+                    rb_project(blocks[g]);
+                    if (overlap) comm_allreduce_dev_async(blocks[g]->acc.p, n, 0);
+                }
+            } catch (...) {
+                comm_sync_side();  // no asynchronous all-reduce may still be writing a summand when the error unwinds
+                throw;
             }
             if (overlap) comm_join();
             for (int g = 1; g < count; ++g)  // fixed order: deterministic sums

@@ -134,6 +134,13 @@ void comm_allreduce_dev_async(double *buf, i64 count, int op) {
     g.pending = true;
 }
 
+// Drains the second stream and forgets pending asynchronous all-reduces (allocator trims, error paths): after this no
+// collective can still be writing a buffer that goes back to the cache or to the driver.
+void comm_sync_side() {
+    if (g.side) (void)hipStreamSynchronize(g.side);
+    g.pending = false;
+}
+
 void comm_join() {
     if (!g.pending) return;
     SLP_HIP(hipEventRecord(g.done, g.side));

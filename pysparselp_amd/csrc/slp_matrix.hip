@@ -34,7 +34,10 @@ static std::multimap<size_t, void *> g_free_blocks;  // capacity -> block
 static size_t g_cached_bytes = 0;
 static std::mutex g_alloc_mutex;
 
+void comm_sync_side();  // slp_comm.hip: drains the second stream (asynchronous all-reduces may still write cached blocks)
+
 static void trim_cache() {
+    comm_sync_side();
     for (auto &kv : g_free_blocks) (void)hipFree(kv.second);
     g_free_blocks.clear();
     g_cached_bytes = 0;
@@ -45,8 +48,12 @@ void *dev_alloc(size_t bytes, size_t *capacity) {
     const size_t want = (bytes + 255) & ~(size_t)255;
     std::lock_guard<std::mutex> lock(g_alloc_mutex);
     if (!off) {
+        // a cached block is taken when it is not much larger than the request: up to 2 x for small ones, up to 12.5 % above
+        // 64 MB (a 10 GB request must not sit on a 20 GB block for its whole lifetime: the out-of-memory retry cannot get
+        // that slack back)
+        const size_t limit = want > ((size_t)64 << 20) ? want + want / 8 : 2 * want + (1u << 20);
         auto it = g_free_blocks.lower_bound(want);
-        if (it != g_free_blocks.end() && it->first <= 2 * want + (1u << 20)) {
+        if (it != g_free_blocks.end() && it->first <= limit) {
             void *p = it->second;
             *capacity = it->first;
             g_cached_bytes -= it->first;

@@ -130,6 +130,15 @@ static slp_matrix *matrix_normal(slp_matrix *a, double gamma_eq, double gamma_in
         u64 total = 0;
         SLP_HIP(hipMemcpyAsync(&total, off.p + N, sizeof(u64), hipMemcpyDeviceToHost, st));
         SLP_HIP(hipStreamSynchronize(st));
+        if (total == 0) {  // N == 0 (every column counts its diagonal marker): an empty 0 x 0 matrix, nothing to sort or compact
+            m->a.ptr.zero();
+            m->a.nnz = 0;
+            m->a.idx.alloc(0);
+            m->a.val.alloc(0);
+            finish_stats(m->a);
+            SLP_HIP(hipStreamSynchronize(st));
+            return m;
+        }
         {  // expand-sort-compress holds every product twice (key + value, double-buffered by the sort): 32 bytes each
             size_t free_b = 0, total_b = 0;
             SLP_HIP(hipMemGetInfo(&free_b, &total_b));

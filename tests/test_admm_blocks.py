@@ -163,6 +163,10 @@ def test_several_row_blocks_on_one_rank_match_the_reference_block_decomposition(
     grp.iterate(40)
     x_grp = grp.x()
     assert grp.cg_steps() > 0
+    # linking is not idempotent (it replaces every block's copy counts by the group totals): a second link is refused
+    from pysparselp_amd import _lib
+    with pytest.raises(_lib.SlpError, match="already part of a group"):
+        _lib.check(grp._l.slp_blocks_group_link(grp._handles, len(grp.blocks)))
     grp.close()
     x_ref = oracle.lp_admm_block_decomposition(c, None, None, s, None, b, lb, ub, nb_iter=39, nb_iter_plot=10 ** 9, blocks_eq=[],
                                                blocks_ineq=[(lo, hi - 1) for lo, hi in zip(cuts, cuts[1:])])

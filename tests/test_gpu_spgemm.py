@@ -60,6 +60,18 @@ def test_normal_matrix_matches_the_oracle_on_random_matrices(seed):
     dev.close()
 
 
+def test_normal_matrix_of_a_matrix_without_columns_is_empty():
+    """N == 0 (no columns) used to index position total - 1 = -1 of the sort buffers."""
+    import scipy.sparse
+    from pysparselp_amd.device import DeviceMatrix
+
+    dev = DeviceMatrix.from_csr(scipy.sparse.csr_matrix((5, 0)))
+    m = dev.normal_matrix(2.0, 3.0)
+    assert m.shape == (0, 0) and m.nnz == 0
+    m.close()
+    dev.close()
+
+
 def test_lp_admm_forms_m_on_the_device_and_still_matches_the_reference():
     """lp_admm uploads the standard-form A once; M comes from the device product (not from scipy on the host)."""
     import os

@@ -4,7 +4,7 @@
 # (strip splits for few row blocks), the packed exchange and rank 0's output at FULL BASELINE config 3 size.  Rates are
 # meaningless (ranks time-share one GPU, all-reduces go through Python); the objective after the run must equal the
 # single-process value.   bash tools/multirank_one_gpu.sh > gpurun_out/multirank.txt
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export SLP_DEVICE=0 SLP_COMM_TRANSPORT=host
 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-general | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('N=1', d['objective_after_run'], d['value'])"
 for N in 2 4 8; do

@@ -4,8 +4,8 @@
 # also times the general fp64-strip path (roofline.general_fp64), so one profile covers the dictionary kernels and
 # k_strip_spmv<0>.  Run on the GPU box from the repo root:  bash tools/profile_c3.sh [tag]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
+R="${GRAFT_REPO_ROOT:?}"
+cd "$R" || exit 1
 O=gpurun_out/${1:-prof}
 mkdir -p $O
 SLP_TRACE=1 python3 bench.py > $O/bench_admm.json 2> $O/bench_admm.err

@@ -1,8 +1,8 @@
 # PMC passes over the Gauss-Seidel ADMM on the Potts 256^2 LP: what bounds the single-workgroup sweep?
 # (separate --pmc runs, kernel-trace only; see tools/profile_gs.sh for the timing pass)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
+R="${GRAFT_REPO_ROOT:?}"
+cd "$R" || exit 1
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_INSTS_SMEM" \
