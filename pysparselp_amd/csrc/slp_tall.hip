@@ -154,9 +154,12 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
     __shared__ unsigned int nlane[kTallT];        // list length of every lane (non-increasing)
     __shared__ unsigned long long wtot[kTallT / kWave];
     __shared__ unsigned int width[kTallSlots];
+    __shared__ unsigned int bcnt[kTallBuckets * 32], bstart[kTallBuckets * 32 + 1];  // (count, bank class) buckets
+    __shared__ unsigned long long cbuf[kTallT];  // scans over the 32 threads of a bank class
+    __shared__ unsigned int ccls[kTallT];   // demands of the 32 lanes of every bank class
+    __shared__ unsigned int spare1[32];     // one-entry rows of a bank class that no lane of the class takes
     const int p = threadIdx.x;
     const i64 b = blockIdx.x;
-    const int rpt = (R + kTallT - 1) / kTallT;  // consecutive rows per thread in the sorting pass
     unsigned int *pay = WRITE ? payload + blk_base[b] : nullptr;
     double *payv = (WRITE && !DICT) ? pvals + blk_base[b] : nullptr;
     TallPkt *pk = WRITE ? dir + pkt_ptr[b] : nullptr;
@@ -192,11 +195,30 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
             atomicAdd(&cnt[r], 1u);
         }
         __syncthreads();
-        // sorted positions: rows with entries, by min(count, 6) descending, rows in increasing order inside a class
-        unsigned long long ha = 0, hb = 0;  // counters of the classes 6,5,4 (21 bits each) / 3,2,1
-        const int r0 = p * rpt, r1 = (r0 + rpt < R) ? r0 + rpt : R;
-        for (int r = r0; r < r1; ++r) {
-            const unsigned int c = cnt[r];
+        // Sorted positions: rows with entries, by min(count, 6) descending and, inside a count, by their BANK CLASS
+        // rho = row % 32 (the LDS bank pair of the row's running sum in the product kernel): 192 buckets.
+        // Thread (i, rho) = p walks the rows rho + 32 m of its bank class for a range of m; an exclusive scan over the 32
+        // threads of the class (through LDS) gives every row its place inside its (count, class) bucket -- rows in increasing
+        // order: the same layout in the sizing pass and in the writing pass.
+        const int crows = R > (int)(p & 31) ? (R - (int)(p & 31) + 31) / 32 : 0;  // rows of the class: rho + 32 m, m < crows
+        const int mpl = ((R + 31) / 32 + 31) / 32;                                // consecutive m per thread
+        const int m0 = (p >> 5) * mpl < crows ? (p >> 5) * mpl : crows, m1 = m0 + mpl < crows ? m0 + mpl : crows;
+        auto class_scan = [&](unsigned long long v, unsigned long long *tot) -> unsigned long long {
+            cbuf[(p >> 5) * 32 + (p & 31)] = v;
+            __syncthreads();
+            unsigned long long ex = 0, all = 0;
+            for (int i = 0; i < 32; ++i) {
+                const unsigned long long u = cbuf[i * 32 + (p & 31)];
+                if (i < (p >> 5)) ex += u;
+                all += u;
+            }
+            __syncthreads();
+            *tot = all;
+            return ex;
+        };
+        unsigned long long ha = 0, hb = 0;  // counters of the counts 6,5,4 (21 bits each) / 3,2,1
+        for (int m = m0; m < m1; ++m) {
+            const unsigned int c = cnt[(p & 31) + 32 * m];
             if (c) {
                 const unsigned int cl = c < (unsigned)kTallBuckets ? c : kTallBuckets;
                 if (cl > 3) ha += 1ull << (21 * (kTallBuckets - cl));
@@ -204,52 +226,112 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
             }
         }
         unsigned long long ta, tb;
-        unsigned long long ea = tall_block_scan(ha, wtot, &ta), eb = tall_block_scan(hb, wtot, &tb);
-        unsigned int start[kTallBuckets + 1], npos = 0;
-        for (int cl = kTallBuckets; cl >= 1; --cl) {
-            start[cl] = npos;
-            npos += (unsigned int)(((cl > 3 ? ta : tb) >> (21 * ((cl > 3 ? kTallBuckets : 3) - cl))) & 0x1fffffu);
+        unsigned long long ea = class_scan(ha, &ta), eb = class_scan(hb, &tb);
+        if (p < 32)
+            for (int cl = kTallBuckets; cl >= 1; --cl)
+                bcnt[(kTallBuckets - cl) * 32 + p] = (unsigned int)(((cl > 3 ? ta : tb) >> (21 * ((cl > 3 ? kTallBuckets : 3) - cl))) & 0x1fffffu);
+        __syncthreads();
+        if (p == 0) {
+            unsigned int run = 0;
+            for (int q = 0; q < kTallBuckets * 32; ++q) { bstart[q] = run; run += bcnt[q]; }
+            bstart[kTallBuckets * 32] = run;
         }
-        for (int r = r0; r < r1; ++r) {
-            const unsigned int c = cnt[r];
+        __syncthreads();
+        for (int m = m0; m < m1; ++m) {
+            const unsigned int r = (unsigned int)((p & 31) + 32 * m), c = cnt[r];
             if (c) {
                 const unsigned int cl = c < (unsigned)kTallBuckets ? c : kTallBuckets;
                 unsigned int within;
                 if (cl > 3) { within = (unsigned int)((ea >> (21 * (kTallBuckets - cl))) & 0x1fffffu); ea += 1ull << (21 * (kTallBuckets - cl)); }
                 else { within = (unsigned int)((eb >> (21 * (3 - cl))) & 0x1fffffu); eb += 1ull << (21 * (3 - cl)); }
-                posrow[start[cl] + within] = (unsigned short)r;
+                posrow[bstart[(kTallBuckets - cl) * 32 + (p & 31)] + within] = (unsigned short)r;
             }
         }
         __syncthreads();
-        // Dealing rows to lanes.  Sparse cells (every row beyond the first 1024 sorted positions has ONE entry -- the
-        // regime this format is for): lane p takes position p, then as many one-entry rows as bring its list to the
-        // mean length tau = ceil(items / 1024) -- consecutive positions, lanes filled in order -- so all lists are tau
-        // long except those of the few rows longer than tau: the 16 waves of the workgroup reach the cell's barrier
-        // together.  Otherwise round by round: lane p takes positions p, p + 1024, ...
-        const unsigned int c0p = (unsigned)p < npos ? cnt[posrow[p]] : 0u;
-        const bool fill = npos > (unsigned)kTallT && cnt[posrow[kTallT]] <= 1u;  // uniform
-        unsigned int extra0 = 0, extra = 0, mine = c0p;
+        const unsigned int npos = bstart[kTallBuckets * 32];
+        const unsigned int n2 = bstart[(kTallBuckets - 1) * 32];  // rows with two or more entries come first
+        // Dealing rows to lanes.  Sparse cells (all rows with two or more entries fit the 1024 lanes -- the regime this
+        // format is for): lane p < n2 takes one of those rows, then every lane takes as many one-entry rows as bring its
+        // list to the mean length tau = ceil(items / 1024): all lists are tau long except those of the few rows longer than
+        // tau, so the 16 waves of the workgroup reach the cell's barrier together.  WHICH row of a count a lane takes is
+        // free: lanes take rows of their own bank class (p % 32 == row % 32) as far as those last -- the 32 lanes of a
+        // half-wave then read and write the running sums without bank conflicts -- and the rest in order.
+        // Otherwise (dense cells) round by round: lane p takes positions p, p + 1024, ...
+        const bool fill = n2 <= (unsigned)kTallT;  // uniform
+        const unsigned int rho = (unsigned)p & 31u;
+        unsigned int pos0 = npos, c0p = 0;  // the lane's row of two or more entries (fill mode), or its first position
         if (fill) {
-            const unsigned int tau = ((unsigned)n + kTallT - 1) / kTallT, avail = npos - kTallT;
-            const unsigned int want = c0p < tau ? tau - c0p : 0u;
-            unsigned long long total;
-            extra0 = (unsigned int)tall_block_scan(want, wtot, &total);
-            extra = extra0 >= avail ? 0u : (want < avail - extra0 ? want : avail - extra0);
-            mine += extra;
+            if ((unsigned)p < n2) {
+                int cl = kTallBuckets;  // the count class whose lanes [S, E) hold p
+                while (cl > 2 && (unsigned)p >= bstart[(kTallBuckets - cl + 1) * 32]) --cl;
+                const unsigned int *bs = bstart + (kTallBuckets - cl) * 32;  // bs[r] .. bs[r + 1]: rows of bank class r
+                const unsigned int S = bs[0], E = bs[32];
+                auto lanes_of = [&](unsigned int r) -> unsigned int {  // lanes of [S, E) in bank class r
+                    const unsigned int first = S + ((r + 32u - (S & 31u)) & 31u);
+                    return first < E ? (E - first + 31u) / 32u : 0u;
+                };
+                const unsigned int first = S + ((rho + 32u - (S & 31u)) & 31u), i = ((unsigned)p - first) / 32u;
+                const unsigned int nr = bs[rho + 1] - bs[rho];
+                if (i < nr) {
+                    pos0 = bs[rho] + i;  // a row of the lane's own bank class
+                } else {                 // the u-th lane without one takes the u-th row without a lane
+                    unsigned int u = i - nr;
+                    for (unsigned int r = 0; r < rho; ++r) { const unsigned int nl = lanes_of(r), rr = bs[r + 1] - bs[r]; u += nl > rr ? nl - rr : 0u; }
+                    for (unsigned int r = 0; r < 32u; ++r) {
+                        const unsigned int nl = lanes_of(r), rr = bs[r + 1] - bs[r], spare = rr > nl ? rr - nl : 0u;
+                        if (u < spare) { pos0 = bs[r] + nl + u; break; }
+                        u -= spare;
+                    }
+                }
+                c0p = cnt[posrow[pos0]];
+            }
         } else {
-            for (unsigned int pos = p + kTallT; pos < npos; pos += kTallT) mine += cnt[posrow[pos]];
+            pos0 = (unsigned)p < npos ? (unsigned)p : npos;
+            c0p = pos0 < npos ? cnt[posrow[pos0]] : 0u;
+        }
+        unsigned int mine = c0p, own0 = 0, nown = 0, left0 = 0, nleft = 0;
+        {
+            // one-entry rows (fill mode): first those of the lane's own bank class, in lane order inside the class ...
+            const unsigned int *b1 = bstart + (kTallBuckets - 1) * 32;
+            const unsigned int tau = ((unsigned)n + kTallT - 1) / kTallT;
+            const unsigned int want = (fill && c0p < tau) ? tau - c0p : 0u;
+            ccls[(p >> 5) * 32 + rho] = want;
+            __syncthreads();
+            unsigned int before = 0, all = 0;
+            for (int i = 0; i < 32; ++i) { const unsigned int v = ccls[i * 32 + rho]; if (i < (p >> 5)) before += v; all += v; }
+            const unsigned int n1 = b1[rho + 1] - b1[rho];
+            own0 = b1[rho] + before;
+            nown = before >= n1 ? 0u : (want < n1 - before ? want : n1 - before);
+            if (p < 32) spare1[p] = n1 > all ? n1 - all : 0u;  // rows of the class nobody of the class takes
+            __syncthreads();
+            // ... then, for what is still missing, the rows left over in other classes: in lane order
+            unsigned long long total;
+            left0 = (unsigned int)tall_block_scan(want - nown, wtot, &total);
+            unsigned int nspare = 0;
+            for (int r = 0; r < 32; ++r) nspare += spare1[r];
+            nleft = left0 >= nspare ? 0u : (want - nown < nspare - left0 ? want - nown : nspare - left0);
+            if (fill) mine += nown + nleft;
+            else for (unsigned int pos = p + kTallT; pos < npos; pos += kTallT) mine += cnt[posrow[pos]];
         }
         // sorted position of the lane's q-th row, or npos when its list has ended
         auto rowpos = [&](unsigned int q) -> unsigned int {
-            if (q == 0) return (unsigned)p < npos ? (unsigned)p : npos;
-            if (fill) return q - 1 < extra ? kTallT + extra0 + (q - 1) : npos;
-            const unsigned int pos = q * kTallT + p;
-            return pos < npos ? pos : npos;
+            if (!fill) { const unsigned int pos = q * kTallT + p; return pos < npos ? pos : npos; }
+            if (pos0 < npos) { if (q == 0) return pos0; --q; }
+            if (q < nown) return own0 + q;
+            q -= nown;
+            if (q >= nleft) return npos;
+            const unsigned int *b1 = bstart + (kTallBuckets - 1) * 32;
+            unsigned int u = left0 + q;
+            for (unsigned int r = 0; r < 32u; ++r) {
+                if (u < spare1[r]) return b1[r + 1] - spare1[r] + u;
+                u -= spare1[r];
+            }
+            return npos;
         };
-        // List lengths never increase with p in either scheme while counts never increase along the sorted positions;
-        // they do inside the class of rows with >= 6 entries (kept in row order).  Slot widths therefore come from the
-        // non-increasing envelope cover[p] = max over lanes >= p of their list lengths: slot k is as wide as the lanes
-        // whose ENVELOPE exceeds k, and a lane inside it whose own list has ended stores a skip item there.
+        // List lengths are non-increasing in p up to a few exceptions (rows with >= 6 entries in bucket order; the lanes
+        // that find no one-entry row left).  Slot widths therefore come from the non-increasing envelope cover[p] = max over
+        // lanes >= p of their list lengths: slot k is as wide as the lanes whose ENVELOPE exceeds k, and a lane inside it
+        // whose own list has ended stores a skip item there.
         unsigned int cover = mine;
         {
             // suffix maximum over the 1024 lanes: inside the wave by shuffles, across waves through LDS

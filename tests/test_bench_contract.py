@@ -54,6 +54,24 @@ def test_committed_bench_lines(name):
         assert d["cpu_baseline"]["extrapolated"] is True and d["setup_seconds"] > 0 and d["device_memory"]["csr_released"]
 
 
+@pytest.mark.parametrize("name", ["r03_bench_admm_c4slice.json", "r03_bench_cp_c4slice.json", "r03_bench_admm_c3_500steps.json"])
+def test_committed_round3_bench_lines(name):
+    """`bench.py --config c4slice` (BASELINE config 4's per-rank shape at the density that fits: 2.5e6 rows x 1e7 variables
+    at 1e-4) and the 500-step config-3 line."""
+    d = json.loads(open(os.path.join(REPO, "profiles", name)).read().strip().splitlines()[-1])
+    check_line(d, need_cpu_baseline=True)
+    r = d["roofline"]
+    assert d["n_gpus"] == 1 and 0.0 < r["frac"] <= 1.0 and d["cpu_baseline"]["extrapolated"] is True
+    if "c4slice" in name:
+        assert (d["config"]["n"], d["config"]["m"], d["config"]["density"]) == (10_000_000, 2_500_000, 1e-4)
+        assert "k_tall_spmv" in r["kernel"] and r["frac"] >= 0.30          # VERDICT r02, item 2: >= 0.30 of the HBM peak
+        assert r["traffic"] is not None and abs(r["traffic"] / r["bytes_per_launch"] - 1.0) < 0.15
+    else:
+        assert d["steps"] == 500 and d["config"]["n"] == 1_000_000
+        assert r["traffic_measured_in_this_run"] is False
+        assert d["cpu_baseline"]["full_size_validation"]["source"] == "profiles/r03_cpu_full_c3.json"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["admm", "chambolle_pock_ppd"])
 def test_live_bench_line(method):

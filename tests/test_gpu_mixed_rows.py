@@ -151,4 +151,4 @@ def test_randomised_at_scale_solvers():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_scale
 
-    assert fuzz_scale.run(8, seed=2) == 8
+    assert fuzz_scale.run(12, seed=2) == 12

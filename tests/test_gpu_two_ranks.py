@@ -89,11 +89,12 @@ def _run(world, n, m, p, seed, iters):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("n,m,iters", [(30000, 40001, 70), (3000, 1, 12)])
-def test_two_ranks_on_one_gpu_match_the_single_process_run(n, m, iters):
+@pytest.mark.parametrize("n,m,iters,p", [(30000, 40001, 70, 0.001), (3000, 1, 12, 0.001), (200000, 24001, 70, 1.5e-4)])
+def test_two_ranks_on_one_gpu_match_the_single_process_run(n, m, iters, p):
     """m = 40001: unequal row blocks (20001 / 20000), 70 iterations cross the level-4 refresh at iteration 64.
-    m = 1: rank 1's row block is EMPTY -- it must issue exactly the same collectives over zero-sized products."""
-    p, seed = 0.001, 3
+    m = 1: rank 1's row block is EMPTY -- it must issue exactly the same collectives over zero-sized products.
+    n = 200000 at density 1.5e-4: both orientations of both row blocks run on tall cells (the 1e7-variable shape's format)."""
+    seed = 3
     one = _run(1, n, m, p, seed, iters)[0]
     two = _run(2, n, m, p, seed, iters)
     assert two[0]["rows"] + two[1]["rows"] == m and (m > 1 or two[1]["rows"] == 0)

@@ -1,6 +1,6 @@
 """Randomised cross-check of the at-scale (device-resident) solvers against the oracle on mid-size device-generated LPs:
-DeviceCP and DeviceADMM (reuse levels 0 ... 4) over every strip variant, with equality rows and
-two-sided rows.  DeviceBlocks is checked against the generic split-matrix block solver (the oracle's sparse LU takes minutes
+DeviceCP and DeviceADMM (reuse levels 0 ... 4) over every strip variant and over tall cells (both item forms), with equality
+rows and two-sided rows.  DeviceBlocks is checked against the generic split-matrix block solver (the oracle's sparse LU takes minutes
 beyond a few thousand rows; both are checked against it in tests/test_admm_blocks.py on small LPs).
 python tools/fuzz_scale.py [--cases 16] [--seed 0]"""
 import argparse
@@ -20,20 +20,28 @@ def run(cases, seed, verbose=False):
     from pysparselp_amd.scale import DeviceCP
 
     rng = np.random.RandomState(seed)
-    keys = ("SLP_STRIP_MIN_NNZ", "SLP_VALUE_DICT", "SLP_DICT_VARIANT")
+    keys = ("SLP_STRIP_MIN_NNZ", "SLP_VALUE_DICT", "SLP_DICT_VARIANT", "SLP_TALL_R")
     saved = {k: os.environ.get(k) for k in keys}
     for case in range(cases):
         n = int(rng.choice([9000, 20000, 33000]))
         m = int(rng.choice([7000, 25000, 41000]))
         p = float(rng.choice([0.0008, 0.002]))
-        fmt = rng.choice(["quads", "pairs", "fp64", "csr"])
+        fmt = rng.choice(["quads", "pairs", "fp64", "csr", "tall", "tall_fp64"])
+        if fmt.startswith("tall"):  # rows sparse inside every 4096-column window, in both orientations: tall cells (slp_tall.hip)
+            n = int(rng.choice([90000, 150000]))
+            m = int(rng.choice([12000, 25000]))
+            p = float(rng.choice([1.5e-4, 3e-4]))
+            os.environ["SLP_TALL_R"] = str(int(rng.choice([1024, 2000, 9984])))
         os.environ["SLP_STRIP_MIN_NNZ"] = "100000000000" if fmt == "csr" else "1"
-        os.environ["SLP_VALUE_DICT"] = "0" if fmt == "fp64" else "1"
+        os.environ["SLP_VALUE_DICT"] = "0" if fmt in ("fp64", "tall_fp64") else "1"
         os.environ["SLP_DICT_VARIANT"] = "2" if fmt == "quads" else "1"
         m_eq = int(rng.choice([0, 0, m // 10]))
         two_sided = rng.rand() < 0.5
         level = int(rng.choice([0, 2, 3, 4]))
         a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=int(rng.randint(0, 1000)))
+        if fmt.startswith("tall"):
+            want = 6 if fmt == "tall" else 7
+            assert a.spmv_kernel(False) == want and a.spmv_kernel(True) == want, (fmt, a.spmv_kernel(False), a.spmv_kernel(True))
         s = a.download()
         ax = a.matvec(xf)
         b = b.copy()

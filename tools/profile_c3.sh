@@ -18,6 +18,7 @@ for d in stats_admm pmc_fetch pmc_write pmc_sq; do find $O/$d -name "*.db" | hea
 python3 tools/summarize_rocprof.py db-stats $(find $O/stats_admm -name "*.db" | head -1) > $O/kernel_stats.csv 2>> $O/summ.err
 python3 tools/summarize_rocprof.py db-pmc $(find $O/pmc_fetch -name "*.db" | head -1) $(find $O/pmc_write -name "*.db" | head -1) > $O/pmc_hbm.json 2>> $O/summ.err
 python3 tools/summarize_rocprof.py db-sq $(find $O/pmc_sq -name "*.db" | head -1) > $O/pmc_sq.json 2>> $O/summ.err
-find $O -name "*.db" -size +40M -delete
+find $O -name "*.db" -delete   # raw rocpd files: only the summaries travel back (gpurun merges at most 64 MiB)
 find $O -name "*.csv" -size +20M -delete
+for d in stats_admm pmc_fetch pmc_write pmc_sq; do rm -rf $O/$d; done
 cut -c1-600 $O/bench_admm.json; echo; cut -c1-300 $O/bench_cp.json; echo; grep "slp trace" $O/bench_admm.err
