@@ -245,6 +245,7 @@ bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int varian
 void strip_spmv(const StripJds &f, const double *x, double *out);
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1);  // one pass, two vectors
 void strip_spmv_with_dict(const StripJds &f, const double *table, const double *x, double *out);     // values table[id] instead of dict[id]
+void strip_spmv_pow(const StripJds &f, double pw, const double *x, double *out);                      // fp64 strips: values |v|^pw
 bool tall_wanted(const CsrDev &a);   // long rows that are sparse inside every LDS-sized window (slp_tall.hip)
 bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict);
 void tall_spmv(const StripJds &f, const double *x, double *out);

@@ -15,15 +15,6 @@ constexpr int kMaxPartials = 4096;
 // ---------------------------------------------------------------------------
 // setup: T_j = 1 / (sum_i |Ke_ij|^(2-alpha) + sum_i |Ki_ij|^(2-alpha)),  0 -> 1   (:122-153)
 //        S_i = 1 / sum_j |K_ij|^alpha, 0 -> 1                                      (:158-179)
-// numpy evaluates |a| ** p; p == 1 and p == 0 are exact, other p go through pow.
-__device__ __forceinline__ double abs_pow(double a, double p) {
-    a = fabs(a);
-    if (p == 1.0) return a;
-    if (p == 2.0) return a * a;
-    if (p == 0.0) return 1.0;
-    return pow(a, p);
-}
-
 // column sums over the transposed matrix (rows of K^T = columns of K), eq and ineq parts apart
 __global__ void k_cp_colsum(i64 n, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, const double *__restrict__ val,
                             i32 m_eq, i64 m_ineq, double p, double *__restrict__ part_or_t, int finalize) {
@@ -458,21 +449,26 @@ static void cp_setup(slp_cp *s) {
     // through one thread per row (17-19 x the matrix in HBM traffic at config 3, profiles/r02_c3_pmc_hbm.json) -- and they
     // need no CSR arrays.  Equality and inequality rows are summed apart ((0 + s_eq) + s_ineq, :134,144): two products.
     const StripJds *ft = fast_format(s->k, true), *fr = fast_format(s->k, false);
+    auto plain_fp64 = [](const StripJds *f) { return f && f->D == 0 && !f->wide && !f->tall; };  // fp64 LDS strips: |v|^p on the fly
+    auto powered = [&](const StripJds *f, const double *table, double pw, const double *v, double *out) {
+        if (f->D > 0) strip_spmv_with_dict(*f, table, v, out);
+        else strip_spmv_pow(*f, pw, v, out);
+    };
     if (s->n) {
-        if (ft && ft->D > 0) {
-            DevBuf<double> table((size_t)ft->D), ones((size_t)std::max<i64>(s->m, 1));
-            hipLaunchKernelGGL(k_cp_dict_pow, dim3(8), dim3(kBlock), 0, st, ft->D, ft->dict, 2.0 - s->alpha, table.p);
+        if (ft && (ft->D > 0 || plain_fp64(ft))) {
+            DevBuf<double> table((size_t)std::max(ft->D, 1)), ones((size_t)std::max<i64>(s->m, 1));
+            if (ft->D > 0) hipLaunchKernelGGL(k_cp_dict_pow, dim3(8), dim3(kBlock), 0, st, ft->D, ft->dict, 2.0 - s->alpha, table.p);
             if (s->m_eq > 0 && s->m_ineq > 0) {
                 DevBuf<double> se((size_t)s->n), si((size_t)s->n);
                 hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, (i64)0, s->m_eq, ones.p);
-                strip_spmv_with_dict(*ft, table.p, ones.p, se.p);
+                powered(ft, table.p, 2.0 - s->alpha, ones.p, se.p);
                 hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, s->m_eq, s->m, ones.p);
-                strip_spmv_with_dict(*ft, table.p, ones.p, si.p);
+                powered(ft, table.p, 2.0 - s->alpha, ones.p, si.p);
                 hipLaunchKernelGGL(k_cp_join_sums, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, se.p, si.p, s->t.p);
                 SLP_HIP(hipStreamSynchronize(st));
             } else {
                 hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, (i64)0, s->m, ones.p);
-                strip_spmv_with_dict(*ft, table.p, ones.p, s->t.p);
+                powered(ft, table.p, 2.0 - s->alpha, ones.p, s->t.p);
                 SLP_HIP(hipStreamSynchronize(st));
             }
             SLP_HIP(hipGetLastError());
@@ -492,11 +488,11 @@ static void cp_setup(slp_cp *s) {
         }
     }
     if (s->m) {
-        if (fr && fr->D > 0) {
-            DevBuf<double> table((size_t)fr->D), ones((size_t)std::max<i64>(s->n, 1));
-            hipLaunchKernelGGL(k_cp_dict_pow, dim3(8), dim3(kBlock), 0, st, fr->D, fr->dict, s->alpha, table.p);
+        if (fr && (fr->D > 0 || plain_fp64(fr))) {
+            DevBuf<double> table((size_t)std::max(fr->D, 1)), ones((size_t)std::max<i64>(s->n, 1));
+            if (fr->D > 0) hipLaunchKernelGGL(k_cp_dict_pow, dim3(8), dim3(kBlock), 0, st, fr->D, fr->dict, s->alpha, table.p);
             hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, (i64)0, s->n, ones.p);
-            strip_spmv_with_dict(*fr, table.p, ones.p, s->sigma.p);
+            powered(fr, table.p, s->alpha, ones.p, s->sigma.p);
             hipLaunchKernelGGL(k_invert_or_one, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, s->sigma.p);
             SLP_HIP(hipGetLastError());
             SLP_HIP(hipStreamSynchronize(st));

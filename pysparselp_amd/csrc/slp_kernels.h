@@ -61,6 +61,15 @@ __device__ __forceinline__ double block_reduce(double v, double *lds /* >= kBloc
     return r;
 }
 
+// numpy evaluates |a| ** p; p == 1, 2 and 0 are exact, other p go through pow (ChambollePockPPD.py:134,144,161,172)
+__device__ __forceinline__ double abs_pow(double a, double p) {
+    a = fabs(a);
+    if (p == 1.0) return a;
+    if (p == 2.0) return a * a;
+    if (p == 0.0) return 1.0;
+    return pow(a, p);
+}
+
 // ---- one row . dense vector -------------------------------------------------
 // L == 1: storage order, single accumulator (bit-exact csr_matvec semantics).
 // L  > 1: lane `sub` of the row's L-lane group takes entries sub, sub+L, ...;

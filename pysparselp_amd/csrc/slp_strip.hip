@@ -272,13 +272,14 @@ __device__ __forceinline__ uint2 ld_stream(const uint2 *p) {
 // (two workgroups per CU).  out[row] = sum over the row (single accumulator, storage order).
 // ABLATE != 0 is instantiated only in the -DSLP_ABLATION build (timing experiments, wrong results): 1 = no x-tile
 // staging, 2 = no entry streaming
-template <int ABLATE, bool NT, bool NT4 = true>
+// POW: every stored value v enters as |v|^pw * 1.0 (the matrix of the Chambolle-Pock preconditioner sums, slp_cp.hip).
+template <int ABLATE, bool NT, bool NT4 = true, bool POW = false>
 __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                            const unsigned short *__restrict__ perm,
                                                            const unsigned char *__restrict__ slen,
                                                            const unsigned int *__restrict__ soff, const double *__restrict__ val,
                                                            const unsigned short *__restrict__ col, const double *__restrict__ x,
-                                                           double *__restrict__ out) {
+                                                           double *__restrict__ out, double pw) {
     __shared__ double xt[kStripC];
     __shared__ double acc[kStripR];
     __shared__ unsigned int offs[kStripSL];
@@ -314,7 +315,11 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
         for (; s + 4 <= n0; s += 4) {  // four independent 16-byte + 4-byte loads in flight per lane
             const unsigned int o0 = (offs[s] >> 1) + p, o1 = (offs[s + 1] >> 1) + p, o2 = (offs[s + 2] >> 1) + p,
                                o3 = (offs[s + 3] >> 1) + p;
-            const double2 w0 = ld_stream<NT>(v2 + o0), w1 = ld_stream<NT>(v2 + o1), w2 = ld_stream<NT>(v2 + o2), w3 = ld_stream<NT>(v2 + o3);
+            double2 w0 = ld_stream<NT>(v2 + o0), w1 = ld_stream<NT>(v2 + o1), w2 = ld_stream<NT>(v2 + o2), w3 = ld_stream<NT>(v2 + o3);
+            if (POW) {
+                w0.x = abs_pow(w0.x, pw) * 1.0; w0.y = abs_pow(w0.y, pw) * 1.0; w1.x = abs_pow(w1.x, pw) * 1.0; w1.y = abs_pow(w1.y, pw) * 1.0;
+                w2.x = abs_pow(w2.x, pw) * 1.0; w2.y = abs_pow(w2.y, pw) * 1.0; w3.x = abs_pow(w3.x, pw) * 1.0; w3.y = abs_pow(w3.y, pw) * 1.0;
+            }
             const ushort2 j0 = ld_stream<NT && NT4>(c2 + o0), j1 = ld_stream<NT && NT4>(c2 + o1), j2 = ld_stream<NT && NT4>(c2 + o2),
                           j3 = ld_stream<NT && NT4>(c2 + o3);
             a0 += w0.x * xt[j0.x];
@@ -328,7 +333,8 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
         }
         for (; s < n0; ++s) {
             const unsigned int o = (offs[s] >> 1) + p;
-            const double2 w = ld_stream<NT>(v2 + o);
+            double2 w = ld_stream<NT>(v2 + o);
+            if (POW) { w.x = abs_pow(w.x, pw) * 1.0; w.y = abs_pow(w.y, pw) * 1.0; }
             const ushort2 j = ld_stream<NT && NT4>(c2 + o);
             a0 += w.x * xt[j.x];
             if (s < n1) a1 += w.y * xt[j.y];
@@ -998,7 +1004,7 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
     }
 #define SLP_STRIP_LAUNCH(A)                                                                                                        \
     hipLaunchKernelGGL((k_strip_spmv<A, NTF>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, \
-                       f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out)
+                       f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, 0.0)
     const bool nt = nt_loads();
 #ifdef SLP_ABLATION  // `make ablation` (tools/ablate_strip.py) only: the ablated kernels return WRONG sums; not in libslp_hip.so
     const char *e = getenv("SLP_STRIP_ABLATE");
@@ -1010,10 +1016,20 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
 #endif
     if (nt && nt_level() == 2)
         hipLaunchKernelGGL((k_strip_spmv<0, true, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                           f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out);
+                           f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, 0.0);
     else if (nt) { constexpr bool NTF = true; SLP_STRIP_LAUNCH(0); }
     else { constexpr bool NTF = false; SLP_STRIP_LAUNCH(0); }
 #undef SLP_STRIP_LAUNCH
+    if (f.S > 1)
+        hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
+    SLP_HIP(hipGetLastError());
+}
+
+// y = |A|^pw x over the fp64 strip copy: every row the same chain of additions as the CSR walk with |v|^pw * 1.0 terms.
+void strip_spmv_pow(const StripJds &f, double pw, const double *x, double *out) {
+    SLP_REQUIRE(f.ok && !f.wide && !f.tall && f.D == 0, "strip_spmv_pow: not an fp64 strip copy");
+    hipLaunchKernelGGL((k_strip_spmv<0, true, false, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
+                       f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, pw);
     if (f.S > 1)
         hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
     SLP_HIP(hipGetLastError());

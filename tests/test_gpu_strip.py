@@ -204,3 +204,31 @@ def test_randomised_shapes_all_kernel_families():
 
     seen = fuzz_spmv.run(160, seed=1)
     assert all(seen.get(code, 0) > 0 for code in (0, 1, 2, 3, 4, 5, 6, 7)), str(sorted(seen.items()))
+
+
+@pytest.mark.parametrize("fmt", ["dict", "fp64"])
+@pytest.mark.parametrize("m_eq", [0, 700])
+def test_cp_preconditioners_through_the_strip_copies_match_the_oracle(monkeypatch, fmt, m_eq):
+    """T and Sigma (ChambollePockPPD.py:122-179) as products with ones over the strip copies -- the dictionary copy with
+    a |v|^p value table, the fp64 copy with |v|^p applied on the fly -- bit for bit the oracle's column / row sums, with
+    equality and inequality rows summed apart ((0 + s_eq) + s_ineq) and for alpha != 1 (pow)."""
+    from pysparselp_amd import _lib
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
+    monkeypatch.setenv("SLP_VALUE_DICT", "1" if fmt == "dict" else "0")
+    n, m = 30000, 6000
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, 0.001, seed=4)
+    s = a.download()
+    for alpha in (1.0, 0.5):
+        cp = DeviceCP(a, b, c, lb, ub, alpha=alpha, m_eq=m_eq)
+        assert _kernel(a, 0) in ((2, 3) if fmt == "dict" else (1,)) and _kernel(a, 1) in ((2, 3) if fmt == "dict" else (1,))
+        t, sig = np.empty(n), np.empty(m)
+        _lib.check(cp._l.slp_cp_get_preconditioners(cp._h, _lib.ptr(t), _lib.ptr(sig)))
+        cp.close()
+        ae = oracle.as_csr(s[:m_eq]) if m_eq else None
+        t_ref, se_ref, si_ref = oracle.cp_setup(ae, oracle.as_csr(s[m_eq:]), alpha)
+        assert np.array_equal(t, t_ref), alpha
+        assert np.array_equal(sig, np.concatenate((se_ref, si_ref)) if m_eq else si_ref), alpha
+    a.close()
