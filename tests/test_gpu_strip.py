@@ -218,7 +218,7 @@ def test_cp_preconditioners_through_the_strip_copies_match_the_oracle(monkeypatc
 
     monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
     monkeypatch.setenv("SLP_VALUE_DICT", "1" if fmt == "dict" else "0")
-    n, m = 30000, 6000
+    n, m = 30000, 14000
     a, xf, c, lb, ub, b = random_lp_on_device(n, m, 0.001, seed=4)
     s = a.download()
     for alpha in (1.0, 0.5):
