@@ -256,6 +256,10 @@ def main():
     local = int(os.environ.get("SLP_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # SLP_DEVICE: several ranks on one GPU (tests)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.method == "admm_blocks":
+        # short, very wide row blocks: tall row blocks whose strips are shared by several workgroups (partial row sums added
+        # in a fixed order; the block ADMM's conjugate gradients have a tolerance bar, slp_tall.hip)
+        os.environ.setdefault("SLP_TALL_SPLIT", "-1")
     lib = _lib.lib(local)
     distributed = world > 1 or os.environ.get("SLP_BENCH_FORCE_DIST") == "1"  # the latter: one-GPU test of the N > 1 plumbing
     if distributed:

@@ -143,7 +143,7 @@ __device__ __forceinline__ unsigned long long tall_block_scan(unsigned long long
 // WRITE = true: headers and payload at the offsets the host derived from the sizes.
 // DICT: 5-byte items (value id inside); !DICT: 4-byte items (column | row << 12) + the fp64 value in a parallel array at the same offsets.
 template <bool WRITE, bool DICT>
-__global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 ncol, const unsigned long long *__restrict__ keys,
                                                        const double *__restrict__ svals, const i64 *__restrict__ cellptr,
                                                        i64 *__restrict__ sizes, const i64 *__restrict__ blk_base,
                                                        const i64 *__restrict__ pkt_ptr, TallPkt *__restrict__ dir,
@@ -159,10 +159,13 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
     __shared__ unsigned int ccls[kTallT];   // demands of the 32 lanes of every bank class
     __shared__ unsigned int spare1[32];     // one-entry rows of a bank class that no lane of the class takes
     const int p = threadIdx.x;
-    const i64 b = blockIdx.x;
-    unsigned int *pay = WRITE ? payload + blk_base[b] : nullptr;
-    double *payv = (WRITE && !DICT) ? pvals + blk_base[b] : nullptr;
-    TallPkt *pk = WRITE ? dir + pkt_ptr[b] : nullptr;
+    // workgroup v = (row block b, strip range sr of S): its own packet stream (S > 1: few, tall row blocks whose strips are
+    // shared by S workgroups -- see tall_geometry)
+    const i64 v = blockIdx.x, b = v / S;
+    const i64 t_begin = T * (v % S) / S, t_end = T * (v % S + 1) / S;
+    unsigned int *pay = WRITE ? payload + blk_base[v] : nullptr;
+    double *payv = (WRITE && !DICT) ? pvals + blk_base[v] : nullptr;
+    TallPkt *pk = WRITE ? dir + pkt_ptr[v] : nullptr;
     i64 woff = 0, npk = 0;  // running payload offset / packet count of the row block (uniform)
 
     auto empty_packet = [&](unsigned int xsrc) {
@@ -174,13 +177,13 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
         ++npk;
     };
     auto tile_of = [&](i64 t) -> unsigned int { return t >= 0 ? (unsigned int)(t * (i64)kTallC) : kNoTile; };
-    auto next_cell = [&](i64 t) -> i64 {  // first strip > t with entries in this row block, or -1
-        for (i64 u = t + 1; u < T; ++u)
+    auto next_cell = [&](i64 t) -> i64 {  // first strip > t of this workgroup's range with entries in the row block, or -1
+        for (i64 u = t + 1; u < t_end; ++u)
             if (cellptr[b * T + u + 1] > cellptr[b * T + u]) return u;
         return -1;
     };
 
-    i64 t = next_cell(-1);
+    i64 t = next_cell(t_begin - 1);
     empty_packet(tile_of(t));  // the x-tile of the first cell rides on a leading packet without items
     while (t >= 0) {
         const i64 tn = next_cell(t);
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, i64 ncol, c
     // serves both kernels)
     while (npk % (2 * kTallDepth)) empty_packet(kNoTile);
     for (int i = 0; i < 2 * kTallDepth; ++i) empty_packet(kNoTile);
-    if (!WRITE && p == 0) { sizes[2 * b] = woff; sizes[2 * b + 1] = npk; }
+    if (!WRITE && p == 0) { sizes[2 * v] = woff; sizes[2 * v + 1] = npk; }
 }
 
 // ---- the product -------------------------------------------------------------------------------------------------------
@@ -437,7 +440,7 @@ struct TallRegs {
 
 // DICT: depth 4 (20 KB of payload per packet); fp64 entries: depth 2 (48 KB per packet, 16 more registers per packet)
 template <bool DICT>
-__global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, const i64 *__restrict__ pkt_ptr,
+__global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, int S, const i64 *__restrict__ pkt_ptr,
                                                       const i64 *__restrict__ blk_base, const unsigned int *__restrict__ dirw,
                                                       const unsigned int *__restrict__ payload, const double *__restrict__ pvals,
                                                       const double *__restrict__ dict, int D, const double *__restrict__ x,
@@ -448,19 +451,19 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     __shared__ double xt[2][kTallC];
     const int p = threadIdx.x;
     const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
-    const i64 b = blockIdx.x;
+    const i64 v = blockIdx.x, b = v / S;  // workgroup v walks the strips of range v % S of row block b
     for (int r = p; r < R; r += kTallT) acc[r] = 0.0;
     if (DICT)
         for (int q = p; q < D; q += kTallT) dv[q] = dict[q];
-    const unsigned int *__restrict__ hd = dirw + pkt_ptr[b] * 8 + (p & 7);  // this lane's dword of every header
-    const int npk = (int)(pkt_ptr[b + 1] - pkt_ptr[b]) - 2 * kTallDepth;      // the last 2 x depth packets are prefetch targets only
+    const unsigned int *__restrict__ hd = dirw + pkt_ptr[v] * 8 + (p & 7);  // this lane's dword of every header
+    const int npk = (int)(pkt_ptr[v + 1] - pkt_ptr[v]) - 2 * kTallDepth;      // the last 2 x depth packets are prefetch targets only
     // buffer descriptors: lanes without work address past num_records (the load returns 0 without a memory request)
     const __amdgpu_buffer_rsrc_t rs_pay =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(payload + blk_base[b]), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(payload + blk_base[v]), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)(ncol * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : pvals + blk_base[b]), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : pvals + blk_base[v]), 0, 0x7fffffff, 0x00020000);
     int cur = 0;
 
     TallRegs<DICT> regs[kDepth];
@@ -573,22 +576,37 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     __syncthreads();
     for (int r = p; r < R; r += kTallT) {
         const i64 row = b * (i64)R + r;
-        if (row < nrow) out[row] = acc[r];
+        if (row < nrow) out[(v % S) * nrow + row] = acc[r];  // (S > 1: partial sums of this strip range, added up in range order)
     }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 // Rows per block: as tall as the LDS allows, and such that the blocks are (nearly) a multiple of the CU count -- every
 // CU then walks the same number of row blocks and no strip is ever split over workgroups.
-static int tall_rows_per_block(i64 nrow) {
-    const char *e = getenv("SLP_TALL_R");
-    if (e && atoi(e) > 0) return std::min(atoi(e), kTallRmax);
+// Strip-range split (SLP_TALL_SPLIT = S, or -1 = automatic; default 0 = never): short, very wide matrices -- a row block of the
+// block-splitting ADMM with 5e5 rows x 5e7 columns -- have too few rows for 256 tall row blocks: with R = rows / 256 every
+// workgroup re-stages the whole x (400 MB) for a few hundred items per cell.  With the split the row blocks stay as tall as the
+// LDS allows and S workgroups share the strips of one; the partial sums of a row are added in range order (k_strip_combine):
+// deterministic, but no longer the single chain of the CSR row sum -- for solvers with a tolerance bar (block ADMM's
+// conjugate gradients), hence opt-in.
+static void tall_geometry(i64 nrow, i64 T, int *R_out, int *S_out) {
     const i64 cus = ctx().num_cu;
+    const char *es = getenv("SLP_TALL_SPLIT");
+    const int want = es ? atoi(es) : 0;
+    const char *e = getenv("SLP_TALL_R");
+    if (want != 0 && !(e && atoi(e) > 0)) {
+        const i64 R = std::min<i64>(kTallRmax, std::max<i64>(nrow, 1)), B = (nrow + R - 1) / R;
+        i64 S = want > 0 ? want : std::max<i64>(1, cus / B);
+        S = std::max<i64>(1, std::min<i64>(S, std::max<i64>(1, T / 64)));  // at least 64 strips per range
+        if (S > 1) { *R_out = (int)R; *S_out = (int)S; return; }
+    }
+    *S_out = 1;
+    if (e && atoi(e) > 0) { *R_out = std::min(atoi(e), kTallRmax); return; }
     i64 k = (nrow + cus * (i64)kTallRmax - 1) / (cus * (i64)kTallRmax);
     if (k < 1) k = 1;
     i64 R = (nrow + k * cus - 1) / (k * cus);
     if (R < 1024) R = std::min<i64>(1024, std::max<i64>(nrow, 1));  // small matrices: fewer, still tall blocks
-    return (int)std::min<i64>(R, kTallRmax);
+    *R_out = (int)std::min<i64>(R, kTallRmax);
 }
 
 bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
@@ -597,8 +615,10 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     f = StripJds();
     if ((dict && (dict->D <= 0 || dict->D > kTallDictMax)) || a.nrow == 0 || a.nnz == 0) return false;
     if (a.ncol * 8 >= ((i64)1 << 31)) return false;  // x is addressed through a buffer descriptor with 32-bit byte offsets
-    const int R = tall_rows_per_block(a.nrow);
-    const i64 T = (a.ncol + kTallC - 1) / kTallC, B = (a.nrow + R - 1) / R, ncell = B * T;
+    const i64 T = (a.ncol + kTallC - 1) / kTallC;
+    int R = 0, S = 1;
+    tall_geometry(a.nrow, T, &R, &S);
+    const i64 B = (a.nrow + R - 1) / R, ncell = B * T, V = B * S;  // V workgroups: (row block, strip range)
     unsigned int cellbits = 1;
     while (((i64)1 << cellbits) < ncell) ++cellbits;
     if (kTallCellShift + cellbits > 64) return false;
@@ -633,36 +653,36 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     }
     hipLaunchKernelGGL(k_tall_cellptr, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, ncell, sorted.p, cellptr.p);
     SLP_HIP(hipGetLastError());
-    DevBuf<i64> sizes(2 * (size_t)B);
+    DevBuf<i64> sizes(2 * (size_t)V);
     Phase p2("  tall: packets (sizes + fill)");
     if (dict)
-        hipLaunchKernelGGL((k_tall_build<false, true>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, (const double *)nullptr,
+        hipLaunchKernelGGL((k_tall_build<false, true>), dim3((unsigned)V), dim3(kTallT), 0, st, R, T, S, a.ncol, sorted.p, (const double *)nullptr,
                            cellptr.p, sizes.p, (const i64 *)nullptr, (const i64 *)nullptr, (TallPkt *)nullptr, (unsigned int *)nullptr,
                            (double *)nullptr);
     else
-        hipLaunchKernelGGL((k_tall_build<false, false>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, (const double *)nullptr,
+        hipLaunchKernelGGL((k_tall_build<false, false>), dim3((unsigned)V), dim3(kTallT), 0, st, R, T, S, a.ncol, sorted.p, (const double *)nullptr,
                            cellptr.p, sizes.p, (const i64 *)nullptr, (const i64 *)nullptr, (TallPkt *)nullptr, (unsigned int *)nullptr,
                            (double *)nullptr);
     SLP_HIP(hipGetLastError());
-    std::vector<i64> hs(2 * (size_t)B), hbase((size_t)B + 1), hpkt((size_t)B + 1);
+    std::vector<i64> hs(2 * (size_t)V), hbase((size_t)V + 1), hpkt((size_t)V + 1);
     sizes.download(hs.data(), hs.size());
     hbase[0] = hpkt[0] = 0;
-    for (i64 b = 0; b < B; ++b) {
+    for (i64 b = 0; b < V; ++b) {
         SLP_REQUIRE(hs[2 * b] < ((i64)1 << 28), "tall cells: a row block's payload exceeds 2 GB");
         hbase[b + 1] = hbase[b] + ((hs[2 * b] + 3) & ~(i64)3);  // 16-byte aligned row blocks
         hpkt[b + 1] = hpkt[b] + hs[2 * b + 1];
     }
     f.tall_base.upload(hbase.data(), hbase.size());
     f.tall_pkt.upload(hpkt.data(), hpkt.size());
-    f.tall_dir.alloc((size_t)hpkt[B] * 8);
-    f.tall_pay.alloc((size_t)hbase[B] + 64);
+    f.tall_dir.alloc((size_t)hpkt[V] * 8);
+    f.tall_pay.alloc((size_t)hbase[V] + 64);
     if (dict) {
-        hipLaunchKernelGGL((k_tall_build<true, true>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, (const double *)nullptr,
+        hipLaunchKernelGGL((k_tall_build<true, true>), dim3((unsigned)V), dim3(kTallT), 0, st, R, T, S, a.ncol, sorted.p, (const double *)nullptr,
                            cellptr.p, (i64 *)nullptr, f.tall_base.p, f.tall_pkt.p, reinterpret_cast<TallPkt *>(f.tall_dir.p), f.tall_pay.p,
                            (double *)nullptr);
     } else {
-        f.val.alloc((size_t)hbase[B] + 64);
-        hipLaunchKernelGGL((k_tall_build<true, false>), dim3((unsigned)B), dim3(kTallT), 0, st, R, T, a.ncol, sorted.p, svals.p, cellptr.p,
+        f.val.alloc((size_t)hbase[V] + 64);
+        hipLaunchKernelGGL((k_tall_build<true, false>), dim3((unsigned)V), dim3(kTallT), 0, st, R, T, S, a.ncol, sorted.p, svals.p, cellptr.p,
                            (i64 *)nullptr, f.tall_base.p, f.tall_pkt.p, reinterpret_cast<TallPkt *>(f.tall_dir.p), f.tall_pay.p, f.val.p);
     }
     SLP_HIP(hipGetLastError());
@@ -672,18 +692,31 @@ bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     f.dict = dict ? dict->values.p : nullptr;
     f.tall = true;
     f.tall_R = R;
-    f.S = 1;
+    f.S = S;
+    if (S > 1) f.part.alloc((size_t)S * (size_t)a.nrow);
     f.ok = true;
     return true;
 }
 
+__global__ void k_tall_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
+        double a = part[r];
+        for (int s = 1; s < S; ++s) a += part[(i64)s * nrow + r];  // strip ranges in order: deterministic
+        out[r] = a;
+    }
+}
+
 void tall_spmv(const StripJds &f, const double *x, double *out) {
+    double *dst = f.S > 1 ? f.part.p : out;
+    const unsigned grid = (unsigned)(f.B * f.S);
     if (f.D > 0)
-        hipLaunchKernelGGL((k_tall_spmv<true>), dim3((unsigned)f.B), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.tall_pkt.p,
-                           f.tall_base.p, f.tall_dir.p, f.tall_pay.p, (const double *)nullptr, f.dict, f.D, x, out);
+        hipLaunchKernelGGL((k_tall_spmv<true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_pkt.p,
+                           f.tall_base.p, f.tall_dir.p, f.tall_pay.p, (const double *)nullptr, f.dict, f.D, x, dst);
     else
-        hipLaunchKernelGGL((k_tall_spmv<false>), dim3((unsigned)f.B), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.tall_pkt.p,
-                           f.tall_base.p, f.tall_dir.p, f.tall_pay.p, f.val.p, (const double *)nullptr, 0, x, out);
+        hipLaunchKernelGGL((k_tall_spmv<false>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_pkt.p,
+                           f.tall_base.p, f.tall_dir.p, f.tall_pay.p, f.val.p, (const double *)nullptr, 0, x, dst);
+    if (f.S > 1)
+        hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
     SLP_HIP(hipGetLastError());
 }
 

@@ -168,3 +168,30 @@ def test_full_width_of_the_1e7_variable_shape_with_few_rows():
         s.close()
     finally:
         a.close()
+
+
+def test_strip_range_split_for_short_very_wide_blocks():
+    """SLP_TALL_SPLIT (opt-in): few, tall row blocks whose strips are shared by S workgroups, partial row sums added in
+    range order -- deterministic, equal to the oracle to the rounding of the re-association (1e-13 of the sum of
+    magnitudes), NOT bit for bit; without the switch the same matrix is bit-exact (the default)."""
+    from pysparselp_amd.device import DeviceMatrix
+
+    a_host = _random(3000, 600001, 2e-5, 12)         # 12 entries per row over 147 strips
+    x = np.random.RandomState(2).randn(a_host.shape[1])
+    ref = oracle.matvec(oracle.as_csr(a_host), x)
+    mag = abs(a_host).dot(np.abs(x))
+    got = {}
+    for split in ("0", "2", "-1"):
+        os.environ["SLP_TALL_SPLIT"] = split
+        try:
+            a = DeviceMatrix.from_csr(a_host)
+            assert a.spmv_kernel(False) == 6
+            got[split] = (a.matvec(x), a.matvec(x))
+            a.close()
+        finally:
+            del os.environ["SLP_TALL_SPLIT"]
+        assert np.array_equal(got[split][0], got[split][1])          # run-to-run deterministic
+    assert np.array_equal(got["0"][0], ref)
+    for split in ("2", "-1"):
+        assert np.max(np.abs(got[split][0] - ref) / (1e-300 + mag)) < 1e-13
+    assert not np.array_equal(got["2"][0], ref) or not np.array_equal(got["-1"][0], ref)  # (the split really happened)
