@@ -61,12 +61,15 @@ __device__ __forceinline__ double block_reduce(double v, double *lds /* >= kBloc
     return r;
 }
 
-// numpy evaluates |a| ** p; p == 1, 2 and 0 are exact, other p go through pow (ChambollePockPPD.py:134,144,161,172)
+// numpy evaluates |a| ** p; p == 1, 2, 0 and 0.5 (numpy's scalar-exponent fast paths: identity, square, ones, sqrt) are exact,
+// other p go through pow -- the host's libm / SIMD pow there, ocml's here: equal to rounding, not to the bit
+// (ChambollePockPPD.py:134,144,161,172)
 __device__ __forceinline__ double abs_pow(double a, double p) {
     a = fabs(a);
     if (p == 1.0) return a;
     if (p == 2.0) return a * a;
     if (p == 0.0) return 1.0;
+    if (p == 0.5) return sqrt(a);
     return pow(a, p);
 }
 

@@ -211,7 +211,9 @@ def test_randomised_shapes_all_kernel_families():
 def test_cp_preconditioners_through_the_strip_copies_match_the_oracle(monkeypatch, fmt, m_eq):
     """T and Sigma (ChambollePockPPD.py:122-179) as products with ones over the strip copies -- the dictionary copy with
     a |v|^p value table, the fp64 copy with |v|^p applied on the fly -- bit for bit the oracle's column / row sums, with
-    equality and inequality rows summed apart ((0 + s_eq) + s_ineq) and for alpha != 1 (pow)."""
+    equality and inequality rows summed apart ((0 + s_eq) + s_ineq).  alpha = 0.5: |v|^0.5 is a square root on both sides
+    (exact), |v|^1.5 is pow -- numpy's comes from the host's libm or its SIMD kernels, the device's from ocml; the two agree to
+    rounding (a few of the ~800 distinct values differ in the last bit), so T is held to 1e-14 relative there."""
     from pysparselp_amd import _lib
     from pysparselp_amd.problems import random_lp_on_device
     from pysparselp_amd.scale import DeviceCP
@@ -229,6 +231,6 @@ def test_cp_preconditioners_through_the_strip_copies_match_the_oracle(monkeypatc
         cp.close()
         ae = oracle.as_csr(s[:m_eq]) if m_eq else None
         t_ref, se_ref, si_ref = oracle.cp_setup(ae, oracle.as_csr(s[m_eq:]), alpha)
-        assert np.array_equal(t, t_ref), alpha
+        assert np.array_equal(t, t_ref) if alpha == 1.0 else np.allclose(t, t_ref, rtol=1e-14, atol=0), alpha
         assert np.array_equal(sig, np.concatenate((se_ref, si_ref)) if m_eq else si_ref), alpha
     a.close()
