@@ -164,6 +164,9 @@ int64_t slp_gs_num_levels(const slp_gs *g);
  * time (products with values that are final formed chip-wide beforehand, recent results read from an LDS ring).  All four give
  * the sequential sweep's x bit for bit.  SLP_GS_PIPELINED=0/1 and SLP_GS_WINDOW=0 override the choice (tests, timing). */
 int slp_gs_sweep_kind(const slp_gs *g);
+/* band records of the plan: runs of narrow levels cut into row ranges, one workgroup (compute unit) each; 0 = none
+ * (SLP_GS_BANDS=P forces P per run where possible, 0 forbids; default: by the plan's timing model). */
+int slp_gs_num_bands(const slp_gs *g);
 /* x[n] is updated in place (host buffer), maxiter sweeps, relaxation w;
  * lower/upper may hold -inf/+inf. */
 int slp_gs_solve(slp_gs *g, const double *b, const double *lower, const double *upper,
@@ -215,6 +218,8 @@ int slp_admm_report(slp_admm *s, double out[3]);
 int slp_admm_get_x(slp_admm *s, double *x, int64_t count); /* first `count` entries */
 int slp_admm_get_lambda(slp_admm *s, double *lam);          /* m */
 int64_t slp_admm_num_levels(const slp_admm *s);
+/* band records of M's Gauss-Seidel plan (slp_gs_num_bands) */
+int slp_admm_num_bands(const slp_admm *s);
 int slp_admm_bench(slp_admm *s, int64_t k, double *ms);
 
 /* ---- ADMM, matrix-free conjugate-gradient x-step ------------------------- *

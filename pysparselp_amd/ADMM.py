@@ -106,6 +106,10 @@ class ADMMState:
     def num_levels(self):
         return int(self._l.slp_admm_num_levels(self._h))
 
+    def num_bands(self):
+        """Workgroups sharing the runs of narrow levels of M's Gauss-Seidel plan (0: one workgroup per run)."""
+        return int(self._l.slp_admm_num_bands(self._h))
+
     def bench(self, k):
         ms = np.zeros(1)
         _lib.check(self._l.slp_admm_bench(self._h, int(k), _lib.ptr(ms)))

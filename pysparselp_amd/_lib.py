@@ -67,6 +67,7 @@ _SIGNATURES = {
     "slp_gs_destroy": (None, [c_vp]),
     "slp_gs_num_levels": (c_i64, [c_vp]),
     "slp_gs_sweep_kind": (c_int, [c_vp]),
+    "slp_gs_num_bands": (c_int, [c_vp]),
     "slp_gs_solve": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_dbl]),
     "slp_admm_create": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_admm_create_lp": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl,
@@ -82,6 +83,7 @@ _SIGNATURES = {
     "slp_admm_get_x": (c_int, [c_vp, c_vp, c_i64]),
     "slp_admm_get_lambda": (c_int, [c_vp, c_vp]),
     "slp_admm_num_levels": (c_i64, [c_vp]),
+    "slp_admm_num_bands": (c_int, [c_vp]),
     "slp_admm_bench": (c_int, [c_vp, c_i64, c_vp]),
     "slp_admm_cg_create": (c_vp, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_admm_cg_create_on": (c_vp, [c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),

@@ -250,10 +250,52 @@ static_assert(kGsOne < 0xffff, "ring indices are 16 bits");
 struct alignas(4) GsLane { unsigned short code[kGsEntries]; unsigned short info, ldsw; };
 struct alignas(16) GsDyn { double v[kGsEntries]; };     // static: x[source] * value; near / far: value; padding: -0.0
 struct alignas(8) GsRowW { double b, lo, hi, xi, invd; };  // per row position
-struct alignas(8) GsStepW { int first; unsigned meta; };  // meta: active | chain rounds << 1 | barrier << 6 | has far << 7
+struct alignas(8) GsStepW { int first; unsigned meta; };  // meta: active | chain rounds << 1 | barrier << 6 | has far << 7 | (bands) levels stored << 8
+
+// ---- bands: a run of narrow levels on several compute units -------------------------------------------------------------------
+// The dependency chain of a run cannot be shortened, but its bytes (lane, term and row records: 44 MB per Potts 256^2 sweep through
+// one CU's load path) can be split: the rows of the run are cut into P index ranges ("bands"), one workgroup each, every band with
+// level numbers of its own (1 + the deepest lower neighbour INSIDE the band).  A row's lower neighbours in lower bands are
+// "external": a fetch wave (wave 0 of the workgroup, no rows of its own) reads them from the results of the lower band's
+// workgroup kGsFetchD levels before they are needed and puts them into LDS cells next to the ring, where the compute waves pick
+// them up like any near value -- so the compute waves never wait for another compute unit.  A band publishes how many of its
+// levels are stored (`prog`, one counter per band); the fetch wave of a higher band checks the counters it needs (per level, one
+// number per lower band, cumulative) before it issues the reads, and spins only when the lower band is not far enough ahead.
+// Lower bands never wait for higher ones (higher neighbours are read as the OLD x, which k_gs_pack_terms has already folded into
+// the terms), so the workgroups cannot deadlock whatever order they are dispatched in.  On a grid-like matrix band p starts
+// (its rows' depth in band p - 1) + kGsFetchD levels behind band p - 1 and then keeps pace.  Every row's arithmetic is the
+// single-workgroup kernel's: the results are bit for bit the sequential sweep's.
+//
+// "Stored" without stalling the pipeline: a wave's vector-memory operations complete in issue order, so once the lane record of
+// wave slot k (issued in wave slot k - 4, behind a scheduling barrier) has arrived, the result store of wave slot k - 6 and all
+// before it have left the wave and reached the L2 (they are device-scope stores: written through).  The plan puts into header k
+// the number of levels whose stores that covers; the wave copies it to LDS, the fetch wave publishes the minimum over the waves.
+constexpr int kGsFetchK = 2;                       // external values per level of a band: at most kGsFetchK * 64 (else no bands)
+#ifndef SLP_GS_FETCH_D
+#define SLP_GS_FETCH_D 4
+#endif
+constexpr int kGsFetchD = SLP_GS_FETCH_D;          // levels between the read of an external value and its use
+constexpr int kGsMaxBands = 16;
+constexpr int kGsBandWaves = 15;                   // compute waves of a band's workgroup (+ the fetch wave: 1024 threads)
+constexpr int kGsExt = kGsOne + 1 + 64;            // first LDS cell of the external values (two generations: level parity)
+constexpr int kGsWinCells = kGsExt + 2 * kGsFetchK * 64;
+constexpr int kGsProgStride = 32;                  // ints between two bands' counters (a 128-byte line each)
+constexpr int kGsDone = 0x7fffffff;
+#ifndef SLP_GS_XSCOPE
+#define SLP_GS_XSCOPE __HIP_MEMORY_SCOPE_AGENT   // results another band reads, and the reads
+#endif
+#ifndef SLP_GS_FSCOPE
+#define SLP_GS_FSCOPE __HIP_MEMORY_SCOPE_AGENT   // the bands' counters
+#endif
+static_assert(kGsWinCells < 0xffff, "ring indices are 16 bits");
+// per band: first of its waves + 1 header offsets, compute waves, levels, first fetch position (per level kGsFetchK * 64, padded
+// by 3 kGsFetchD levels), first requirement row (row 0: before the first level; row l + 1: checked in level l for the reads of
+// level l + kGsFetchD; 16 ints each, padded by 2 kGsFetchD rows), first scratch cell
+struct GsBand { int hoff, waves, nlev, fsrc, freq, scratch, pad0, pad1; };
 
 __global__ void k_gs_pack_terms(i64 first, i64 count, const GsEnt *__restrict__ ents, const GsLane *__restrict__ lanes,
-                                const double *__restrict__ x, GsDyn *__restrict__ dyn) {
+                                const double *__restrict__ x, GsDyn *__restrict__ dyn, int *__restrict__ prog, int nprog) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < nprog) prog[threadIdx.x * kGsProgStride] = 0;  // (bands) nothing stored yet
     for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (i64)gridDim.x * blockDim.x) {
         const GsEnt en = ents[first + k];
         const GsLane la = lanes[first + k];
@@ -289,6 +331,15 @@ __global__ void k_gs_unpack(i64 first, i64 count, const i32 *__restrict__ rows, 
     for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (i64)gridDim.x * blockDim.x) x[rows[first + k]] = xpos[first + k];
 }
 
+// a result of another band's workgroup
+__device__ __forceinline__ double gs_read_result(double *p) {
+#ifdef SLP_GS_XRMW
+    return __longlong_as_double((long long)__hip_atomic_fetch_or((unsigned long long *)p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, SLP_GS_XSCOPE);
+#endif
+}
+
 __device__ __forceinline__ double gs_lane_up(double v) {  // lane i receives lane i - 1's v (lane 0 keeps its own)
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
@@ -301,14 +352,18 @@ __device__ __forceinline__ double gs_lane_up(double v) {  // lane i receives lan
 // lane loads its row record, every lane stores (lanes that do not finish a row: to a scratch cell), and a wave that has no
 // wave slot in a level repeats the level's first one (same inputs, same results, same addresses: harmless).  FAR = false is
 // the instantiation for plans without far entries.
-template <bool BOUNDED, bool FAR>
+template <bool BOUNDED, bool FAR, bool BANDS>
 __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *__restrict__ hoff, const GsStepW *__restrict__ hdr,
                                                                     const GsLane *__restrict__ lanes, const i32 *__restrict__ lane_row,
                                                                     const GsDyn *__restrict__ dyn, const GsEnt *__restrict__ ents,
                                                                     const GsRowW *__restrict__ rowsw, double *__restrict__ x,
-                                                                    double *__restrict__ scratch, double w) {
+                                                                    double *__restrict__ scratch, double w,
+                                                                    const GsBand *__restrict__ bands, const i32 *__restrict__ fsrc,
+                                                                    const int *__restrict__ freq, int *__restrict__ prog) {
     // (lane_row holds row POSITIONS, x is the position-ordered result buffer, far entries name positions)
-    __shared__ double win[kGsOne + 1 + 64];  // the ring, the cell that holds 1.0, one scratch cell per lane
+    // the ring, the cell that holds 1.0, one scratch cell per lane, (bands) two generations of external values
+    __shared__ double win[BANDS ? kGsWinCells : kGsOne + 1 + 64];
+    __shared__ __attribute__((aligned(16))) int progw[16];  // (bands) levels stored, per compute wave
     constexpr int RA = 6, RB = 3, RC = 2;  // ring sizes: headers + lane records (4 ahead), terms (2 ahead), row records (2 ahead)
     GsStepW rec[RA];
     GsLane la[RA];
@@ -316,11 +371,88 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
     GsDyn dv[RB];
     GsRowW rw[RC];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (BANDS) {
+        const GsBand bd = bands[blockIdx.x];
+        if (wave > bd.waves) return;         // (before any barrier: a barrier waits for the waves that are still running only)
+        hoff += bd.hoff;
+        scratch += bd.scratch;
+        if (threadIdx.x < 16) progw[threadIdx.x] = (int)threadIdx.x < bd.waves ? 0 : kGsDone;
+        if (threadIdx.x == 0) win[kGsOne] = 1.0;
+        if (wave == 0) {                     // the fetch wave
+            constexpr int K = kGsFetchK, D = kGsFetchD;
+            const int band = blockIdx.x, nlev = bd.nlev;
+            const int *rq = freq + bd.freq + (lane & 15);
+            const i32 *fs = fsrc + bd.fsrc + lane;
+            int *const mine = prog + band * kGsProgStride;
+            const int *const theirs = prog + (lane < band ? lane : band) * kGsProgStride;
+            int known = 0;                   // lane q < band: levels of band q stored, as last seen
+            auto wait_for = [&](int need) {
+                while (__any(lane < band && need > known)) {
+                    known = __hip_atomic_load(theirs, __ATOMIC_ACQUIRE, SLP_GS_FSCOPE);  // the reads below stay below
+                    if (__any(lane < band && need > known)) __builtin_amdgcn_s_sleep(4);
+                }
+            };
+            int rqv[D];
+            i32 src[D][K];
+            double val[D][K];
+            wait_for(rq[0]);                 // levels 0 .. D - 1
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int k = 0; k < K; ++k) val[d][k] = gs_read_result(x + fs[(d * K + k) * 64]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                rqv[d] = rq[(d + 1) * 16];
+#pragma unroll
+                for (int k = 0; k < K; ++k) src[d][k] = fs[((d + D) * K + k) * 64];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) win[kGsExt + k * 64 + lane] = val[0][k];
+            __syncthreads();
+            for (int l0 = 0; l0 < nlev; l0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int l = l0 + d;
+                    wait_for(rqv[d]);        // the lower bands have stored what level l + D reads
+                    rqv[d] = rq[(l + D + 1) * 16];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        val[d][k] = gs_read_result(x + src[d][k]);
+                        src[d][k] = fs[((l + 2 * D) * K + k) * 64];
+                    }
+                    // level l + 1's values (read in level l + 1 - D) into the generation the compute waves are not reading
+                    // (behind the last level the compute waves may still repeat its wave slots: nothing more goes into the cells then)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        win[l + 1 < nlev ? kGsExt + ((l + 1) & 1) * (K * 64) + k * 64 + lane : kGsOne + 1 + lane] = val[(d + 1) % D][k];
+                    // the least of the waves' counts: every lane reads all 16 (broadcast reads) -- a shuffle tree costs four dependent
+                    // trips through the LDS crossbar on the one wave every level waits for
+                    int m;
+                    {
+                        const int4 *pw = reinterpret_cast<const int4 *>(progw);
+                        const int4 a = pw[0], b = pw[1], c = pw[2], e = pw[3];
+                        m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
+                        m = min(m, min(min(min(c.x, c.y), min(c.z, c.w)), min(min(e.x, e.y), min(e.z, e.w))));
+                    }
+#ifdef SLP_GS_BANDS_ABLATE_PUBLISH
+                    if (l + 1 < nlev) m = kGsDone;   // (lab: wrong results)
+#endif
+                    __hip_atomic_store(mine, m, __ATOMIC_RELAXED, SLP_GS_FSCOPE);
+                    if (l < nlev) __syncthreads();
+                }
+            }
+            __syncthreads();                 // every compute wave has waited for its stores
+            __hip_atomic_store(mine, kGsDone, __ATOMIC_RELAXED, SLP_GS_FSCOPE);
+            return;
+        }
+        wave -= 1;
+    } else if (threadIdx.x == 0) {
+        win[kGsOne] = 1.0;
+    }
     const int h0 = hoff[wave], nsteps = hoff[wave + 1] - h0;  // this wave's headers
     const GsStepW *steps = hdr + h0;
     double *const spill = scratch + threadIdx.x;
-    if (threadIdx.x == 0) win[kGsOne] = 1.0;
     __syncthreads();
     int vzero;  // a zero the compiler cannot see through: keeps the header loads on the vector path
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
@@ -386,8 +518,23 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
                 v = w * nv + (1 - w) * r.xi;
             }
             const bool last = me.info & 16;
-            *(last ? x + lrow[j] : spill) = v;
+#ifdef SLP_GS_BANDS_ABLATE_SC1
+            if (BANDS) *(last ? x + lrow[j] : spill) = v;   // (lab: wrong results)
+#else
+            if (BANDS) __hip_atomic_store(last ? x + lrow[j] : spill, v, __ATOMIC_RELAXED, SLP_GS_XSCOPE);  // written through: other CUs read it
+#endif
+            else *(last ? x + lrow[j] : spill) = v;
             win[last && me.ldsw != 0xffff ? (int)me.ldsw : kGsOne + 1 + lane] = v;
+            if (BANDS) {
+                // this wave slot's lane record has arrived, so the stores of wave slot s - 6 and before are in the L2: `stored`
+                // (from the plan) counts the levels that completes; the empty asm keeps the write behind the record's arrival
+                int stored = (int)(meta >> 8), dep = me.info;
+#ifdef SLP_GS_BANDS_SAFE  // lab build (with SLP_GS_BANDS_LAG=0): wait for the store itself
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                asm volatile("" : "+v"(stored) : "v"(dep));
+                if (lane == 0) progw[wave] = stored;
+            }
         }
 #if !defined(SLP_GS_ABLATE) || SLP_GS_ABLATE != 1
         issue_c(jc, (j + 2) % RA);                            // rw[jc] is free again
@@ -404,9 +551,19 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
     issue_b(1, 1);
     issue_c(0, 0);
     issue_c(1, 1);
-    for (int s = 0; s < nsteps; s += RA) {
+    // The first trip is peeled off the loop: the wait at the head of a loop is the one its most demanding way in needs, and the
+    // way in from the loads above (the last of them feeds the first wave slot) needs vmcnt(0) -- as the loop's head, that wait
+    // drained the whole prefetch ring on every trip (6 wave slots).  With the peeled trip both ways in look the same.
 #pragma unroll
-        for (int j = 0; j < RA; ++j) process(s + j, j, j % RB, j % RC);  // (the plan pads every wave's list to a multiple of RA)
+    for (int j = 0; j < RA; ++j) process(j, j, j % RB, j % RC);  // (the plan pads every wave's list to a multiple of RA, at least RA)
+    for (int s = RA; s < nsteps; s += RA) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) process(s + j, j, j % RB, j % RC);
+    }
+    if (BANDS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) progw[wave] = kGsDone;
+        __syncthreads();
     }
 }
 
@@ -435,7 +592,8 @@ struct GsPlan {
     bool has_far = false;    // (windowed) some entry reads a row updated by the same kernel more than kGsWinLevels - 1 levels before
     bool windowed = false;   // ... and those runs use k_gs_sweep_windowed (entry classes, LDS ring) instead of k_gs_sweep_pipelined
     // launch: level `first` with k_gs_level; else steps [first, first + count) = lane slots [slot_first, slot_first + slot_count)
-    struct Segment { bool launch; i64 first, count, slot_first, slot_count, level_first, level_count, hoff; int waves; };
+    // bands > 0: the run is swept by `bands` workgroups (GsBand records band_first ...), `waves` = the most compute waves of one
+    struct Segment { bool launch; i64 first, count, slot_first, slot_count, level_first, level_count, hoff; int waves; int bands = 0; i64 band_first = 0; };
     std::vector<Segment> segments;
     DevBuf<GsStep> steps;
     DevBuf<GsSlot> slots;
@@ -449,6 +607,11 @@ struct GsPlan {
     mutable DevBuf<double> scratch;   // where lanes that do not finish a row store
     mutable DevBuf<double> xpos;      // the windowed kernel's results, by row position
     mutable DevBuf<GsRow> packed;     // per row position, refreshed before every sweep
+    int nbands = 0;                   // band records over all runs with bands (0: none)
+    DevBuf<GsBand> bands;
+    DevBuf<i32> fsrc;                 // the fetch waves' read positions
+    DevBuf<int> freq;                 // ... and what the lower bands must have stored before
+    mutable DevBuf<int> prog;         // levels stored, per band of the run being swept
 };
 
 static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, const double *data) {
@@ -515,7 +678,203 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         std::vector<i64> next(g.lptr.begin(), g.lptr.end() - (g.nlevels ? 1 : 0));
         for (i64 i = 0; i < n; ++i) rows[(size_t)next[(size_t)level[(size_t)i]]++] = (i32)i;
     }
-    {   // permute the matrix into level order on the host (one O(nnz) pass)
+    // a single workgroup wins while the per-level launch cost (>= ~1.5 us) exceeds the work of a level
+    g.one_block = (g.max_width <= 2048) && (g.nnz <= 200000);
+    // Runs of narrow levels: one CU with a barrier per level beats a launch per level (~5.6 us each).  Wide levels
+    // (Potts: the first level holds a third of the unknowns) and levels with a very long row keep the per-level
+    // kernel, which spreads over the chip.  The sweep is then a sequence of segments.
+    // SLP_GS_PIPELINED=0/1 overrides the choice (tests, timing): 1 = every level through the single-workgroup kernel.
+    const char *ep = getenv("SLP_GS_PIPELINED");
+    const bool forced = ep && ep[0] == '1';
+    const i64 wide = forced ? ((i64)1 << 40) : 4096;
+    const char *ew = getenv("SLP_GS_WINDOW");
+    const bool window = !(ew && ew[0] == '0') && n < ((i64)1 << 30);
+    auto row_len = [&](i64 i) { return indptr[i + 1] - indptr[i]; };
+    auto row_lanes = [&](i64 i) { return (int)std::max<i64>(1, (row_len(i) + kGsEntries - 1) / kGsEntries); };
+    std::vector<char> is_launch((size_t)g.nlevels, 0);
+    i64 narrow_levels = 0;
+    for (i64 l = 0; l < g.nlevels; ++l) {
+        const i64 beg = g.lptr[(size_t)l], end = g.lptr[(size_t)l + 1];
+        bool launch = end - beg > wide;
+        for (i64 t = beg; t < end && !launch; ++t)
+            if (row_len(rows[(size_t)t]) > (i64)kGsMaxSeg * kGsEntries) launch = true;  // a very long row
+        is_launch[(size_t)l] = launch ? 1 : 0;
+        narrow_levels += launch ? 0 : 1;
+    }
+    const bool pipeline = n > 0 && g.nnz < ((i64)1 << 31) && !(ep && ep[0] == '0') && (forced || !g.one_block) &&
+                          (forced || narrow_levels >= 16) && narrow_levels > 0;
+
+    // ---- bands (see kGsFetchK): which runs of narrow levels are cut into row ranges, one workgroup each --------------------------
+    // SLP_GS_BANDS=P forces P bands on every run they are possible on, 0 forbids them; otherwise a run gets the number of bands
+    // (4, 8, 16 or none) a small timing model of the pipeline likes best.
+    struct BandRun {
+        i64 level_first = 0, level_count = 0;
+        int P = 0;
+        std::vector<std::vector<i64>> lptr;               // per band: row positions of its levels (nlev + 1, absolute)
+        std::vector<std::vector<std::vector<i32>>> ext;   // per band and level: the external rows it reads (sorted, distinct)
+        std::vector<std::vector<i32>> need;               // per band: nlev x 16, levels of band q that must be stored (cumulative)
+    };
+    std::vector<BandRun> band_runs;
+    std::vector<i32> band_of, blev;  // per row (rows of runs with bands)
+    if (pipeline && window && n < ((i64)1 << 25)) {
+        const char *eb = getenv("SLP_GS_BANDS");
+        const int want = eb ? atoi(eb) : -1;
+        for (i64 l0 = 0; l0 < g.nlevels && want != 0;) {
+            if (is_launch[(size_t)l0]) { ++l0; continue; }
+            i64 l1 = l0;
+            while (l1 < g.nlevels && !is_launch[(size_t)l1]) ++l1;
+            const i64 t0 = g.lptr[(size_t)l0], t1 = g.lptr[(size_t)l1];
+            std::vector<i32> rr(rows.begin() + t0, rows.begin() + t1);
+            std::sort(rr.begin(), rr.end());
+            i64 lanes_total = 0;
+            for (i32 i : rr) lanes_total += row_lanes(i);
+            // the single workgroup's time: a level costs its barrier-to-barrier chain and its bytes through one CU's load path
+            // (calibrated on the Potts 256^2 run, 511 levels of 8 wave slots: one workgroup 545 us, of which 240 are the chain --
+            // a build without the loads -- and 4 / 8 / 16 bands 320 / 305 / 380 us; a band's level is known to the next band
+            // six wave slots, a counter store and a poll later)
+            const double tau1 = 0.47, tauP = 0.47, per_slot = 0.075, per_slot_band = 0.02, hop = 3.0, flag_latency = 6.0;  // us
+            double t_single = 0;
+            for (i64 l = l0; l < l1; ++l) {
+                i64 ln = 0;
+                for (i64 t = g.lptr[(size_t)l]; t < g.lptr[(size_t)l + 1]; ++t) ln += row_lanes(rows[(size_t)t]);
+                t_single += tau1 + per_slot * (double)((ln + 63) / 64);
+            }
+            BandRun best;
+            double t_best = want > 0 ? 1e300 : t_single / 1.1 - 5.0;
+            std::vector<int> cand;
+            if (want > 0) cand.push_back(std::min(want, kGsMaxBands));
+            else if (lanes_total >= 65536 && l1 - l0 >= 64) cand = {4, 8, 16};
+            if (band_of.empty() && !cand.empty()) { band_of.assign((size_t)n, -1); blev.assign((size_t)n, 0); }
+            std::vector<i32> bo_best, bl_best;
+            for (int P : cand) {
+                if ((i64)rr.size() < P) continue;
+                BandRun br;
+                br.level_first = l0; br.level_count = l1 - l0; br.P = P;
+                // index ranges with equal numbers of lane slots
+                i64 acc = 0;
+                for (i32 i : rr) {
+                    band_of[(size_t)i] = (i32)std::min<i64>(P - 1, acc * P / std::max<i64>(1, lanes_total));
+                    acc += row_lanes(i);
+                }
+                auto in_run = [&](i32 j) { return level[(size_t)j] >= l0 && level[(size_t)j] < l1; };
+                // A band sweeps its rows in the order of the GLOBAL levels (its own level numbers: the global ones it has rows in,
+                // counted up).  Every band then marches through the run at the pace of the global dependency chain, a higher band
+                // the fetch distance and a hop behind the bands it reads from -- levels of a band's own (1 + the deepest lower
+                // neighbour inside the band) would put rows whose external inputs come late into early levels, and the whole
+                // band would wait for the latest of them.
+                std::vector<i32> nlev((size_t)P, 0);
+                {
+                    std::vector<i32> ord((size_t)P * (size_t)(l1 - l0), 0);
+                    for (i32 i : rr) ord[(size_t)band_of[(size_t)i] * (size_t)(l1 - l0) + (size_t)(level[(size_t)i] - l0)] = 1;
+                    for (int p = 0; p < P; ++p) {
+                        i32 cnt = 0;
+                        for (i64 l = 0; l < l1 - l0; ++l) {
+                            i32 &o = ord[(size_t)p * (size_t)(l1 - l0) + (size_t)l];
+                            const i32 has = o;
+                            o = cnt;
+                            cnt += has;
+                        }
+                        nlev[(size_t)p] = cnt;
+                    }
+                    for (i32 i : rr) blev[(size_t)i] = ord[(size_t)band_of[(size_t)i] * (size_t)(l1 - l0) + (size_t)(level[(size_t)i] - l0)];
+                }
+                std::vector<unsigned long long> refs;  // band << 60 | level << 32 | external row
+                for (i32 i : rr) {
+                    const i32 p = band_of[(size_t)i], lv = blev[(size_t)i];
+                    for (i64 k = indptr[i]; k < indptr[i + 1]; ++k) {
+                        const i32 j = indices[k];
+                        if (j < i && in_run(j) && band_of[(size_t)j] < p)
+                            refs.push_back((unsigned long long)p << 60 | (unsigned long long)lv << 32 | (unsigned)j);
+                    }
+                }
+                bool ok = true;
+                for (int p = 0; p < P; ++p) ok = ok && nlev[(size_t)p] > 0 && nlev[(size_t)p] < (1 << 24);
+                if (!ok) continue;
+                std::sort(refs.begin(), refs.end());
+                refs.erase(std::unique(refs.begin(), refs.end()), refs.end());
+                br.ext.resize((size_t)P);
+                br.need.resize((size_t)P);
+                std::vector<std::vector<i64>> lanes_pl((size_t)P), rows_pl((size_t)P);
+                for (int p = 0; p < P; ++p) {
+                    br.ext[(size_t)p].resize((size_t)nlev[(size_t)p]);
+                    br.need[(size_t)p].assign((size_t)nlev[(size_t)p] * 16, 0);
+                    lanes_pl[(size_t)p].assign((size_t)nlev[(size_t)p], 0);
+                    rows_pl[(size_t)p].assign((size_t)nlev[(size_t)p], 0);
+                }
+                for (i32 i : rr) {
+                    lanes_pl[(size_t)band_of[(size_t)i]][(size_t)blev[(size_t)i]] += row_lanes(i);
+                    rows_pl[(size_t)band_of[(size_t)i]][(size_t)blev[(size_t)i]] += 1;
+                }
+                for (unsigned long long r : refs) {
+                    const int p = (int)(r >> 60);
+                    const i32 lv = (i32)((r >> 32) & 0x0fffffffu), j = (i32)(r & 0xffffffffu);
+                    std::vector<i32> &cell = br.ext[(size_t)p][(size_t)lv];
+                    cell.push_back(j);
+                    if (cell.size() > (size_t)kGsFetchK * 64) { ok = false; break; }
+                    i32 &nd = br.need[(size_t)p][(size_t)lv * 16 + (size_t)band_of[(size_t)j]];
+                    nd = std::max(nd, (i32)(blev[(size_t)j] + 1));
+                }
+                if (!ok) continue;
+                for (int p = 0; p < P; ++p)
+                    for (i32 lv = 1; lv < nlev[(size_t)p]; ++lv)
+                        for (int q = 0; q < 16; ++q)
+                            br.need[(size_t)p][(size_t)lv * 16 + q] = std::max(br.need[(size_t)p][(size_t)lv * 16 + q], br.need[(size_t)p][(size_t)(lv - 1) * 16 + q]);
+                // the pipeline's finish time: a band's level starts when its own previous level is done and the lower bands have
+                // stored what the reads issued in it (for kGsFetchD levels ahead) want, seen one flag latency later
+                std::vector<std::vector<double>> fin((size_t)P);
+                double t_all = 0;
+                for (int p = 0; p < P; ++p) {
+                    fin[(size_t)p].assign((size_t)nlev[(size_t)p], 0.0);
+                    double t = 0;
+                    for (i32 lv = 0; lv < nlev[(size_t)p]; ++lv) {
+                        const i32 ahead = std::min<i32>(lv + kGsFetchD, nlev[(size_t)p] - 1);
+                        for (int q = 0; q < p; ++q) {
+                            const i32 nd = br.need[(size_t)p][(size_t)ahead * 16 + q];
+                            if (nd > 0) t = std::max(t, fin[(size_t)q][(size_t)nd - 1] + flag_latency);
+                        }
+                        t += tauP + per_slot_band * (double)((lanes_pl[(size_t)p][(size_t)lv] + 63) / 64);
+                        fin[(size_t)p][(size_t)lv] = t;
+                    }
+                    t_all = std::max(t_all, t + hop);
+                }
+                if (getenv("SLP_GS_VERBOSE"))
+                    fprintf(stderr, "gauss-seidel bands: levels %lld..%lld, %lld lane slots: one workgroup %.0f us, %d bands %.0f us (levels of band 0: %d)\n",
+                            (long long)l0, (long long)l1, (long long)lanes_total, t_single, P, t_all, (int)nlev[0]);
+                if (t_all < t_best) {
+                    t_best = t_all;
+                    // positions: band after band, level after level, rows ascending inside a level
+                    br.lptr.resize((size_t)P);
+                    i64 at = t0;
+                    for (int p = 0; p < P; ++p) {
+                        br.lptr[(size_t)p].assign((size_t)nlev[(size_t)p] + 1, 0);
+                        for (i32 lv = 0; lv < nlev[(size_t)p]; ++lv) {
+                            br.lptr[(size_t)p][(size_t)lv] = at;
+                            at += rows_pl[(size_t)p][(size_t)lv];
+                        }
+                        br.lptr[(size_t)p][(size_t)nlev[(size_t)p]] = at;
+                    }
+                    best = std::move(br);
+                    bo_best.resize(rr.size());
+                    bl_best.resize(rr.size());
+                    for (size_t k = 0; k < rr.size(); ++k) { bo_best[k] = band_of[(size_t)rr[k]]; bl_best[k] = blev[(size_t)rr[k]]; }
+                }
+            }
+            if (best.P > 0) {
+                std::vector<std::vector<i64>> next = best.lptr;
+                for (size_t k = 0; k < rr.size(); ++k) {
+                    band_of[(size_t)rr[k]] = bo_best[k];
+                    blev[(size_t)rr[k]] = bl_best[k];
+                    rows[(size_t)next[(size_t)bo_best[k]][(size_t)bl_best[k]]++] = rr[k];
+                }
+                band_runs.push_back(std::move(best));
+            } else if (!band_of.empty()) {
+                for (i32 i : rr) band_of[(size_t)i] = -1;
+            }
+            l0 = l1;
+        }
+    }
+
+    {   // permute the matrix into position order on the host (one O(nnz) pass)
         std::vector<i64> p2((size_t)n + 1, 0);
         std::vector<i32> j2((size_t)g.nnz + kGsEntries, 0);   // padded: the pipelined sweep reads kGsEntries per lane unconditionally
         std::vector<double> v2((size_t)g.nnz + kGsEntries, 0.0);
@@ -542,17 +901,8 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                            g.val.p, g.invd.p, g.diag.p);
         SLP_HIP(hipGetLastError());
     }
-    // a single workgroup wins while the per-level launch cost (>= ~1.5 us) exceeds the work of a level
-    g.one_block = (g.max_width <= 2048) && (g.nnz <= 200000);
-    // Runs of narrow levels: one CU with a barrier per level beats a launch per level (~5.6 us each).  Wide levels
-    // (Potts: the first level holds a third of the unknowns) and levels with a very long row keep the per-level
-    // kernel, which spreads over the chip.  The sweep is then a sequence of segments.
-    // SLP_GS_PIPELINED=0/1 overrides the choice (tests, timing): 1 = every level through the single-workgroup kernel.
-    const char *ep = getenv("SLP_GS_PIPELINED");
-    const bool forced = ep && ep[0] == '1';
-    const i64 wide = forced ? ((i64)1 << 40) : 4096;
     g.pipelined = false;
-    if (n > 0 && g.nnz < ((i64)1 << 31) && !(ep && ep[0] == '0') && (forced || !g.one_block)) {
+    if (pipeline) {
         std::vector<GsStep> st;
         std::vector<GsSlot> slots;
         std::vector<GsPlan::Segment> segs;
@@ -565,34 +915,208 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         for (int e = 0; e < kGsEntries; ++e) { noent.idx[e] = 0; noent.val[e] = 0.0; nolane.code[e] = (unsigned short)kGsOne; }
         nolane.info = 0;  // no entries, not the last lane of a row
         nolane.ldsw = 0xffff;
+        auto pad_wave = [&]() {
+            while (slots.size() & 63) { slots.push_back(idle); ents.push_back(noent); lanes.push_back(nolane); lane_row.push_back(0); }
+        };
 
         std::vector<i64> lvs0((size_t)g.nlevels, 0), lvs1((size_t)g.nlevels, 0);  // lane slots of every narrow level
-        // windowed kernel: position of every row in level order, and the first level of the run of narrow levels being built
-        const char *ew = getenv("SLP_GS_WINDOW");
-        const bool window = !(ew && ew[0] == '0') && n < ((i64)1 << 30);
+        // windowed kernel: position of every row, and the first level of the run of narrow levels being built
         std::vector<i32> pos;
         if (window) {
             pos.resize((size_t)n);
             for (i64 t = 0; t < n; ++t) pos[(size_t)rows[(size_t)t]] = (i32)t;
         }
         i64 seg_first_level = 0;
-        std::vector<i64> kpos((size_t)n + 1, 0);  // level-ordered entry offset of every row position
-        for (i64 t = 0; t < n; ++t) kpos[(size_t)t + 1] = kpos[(size_t)t] + (indptr[rows[(size_t)t] + 1] - indptr[rows[(size_t)t]]);
-        i64 narrow_levels = 0;
+        std::vector<i64> kpos((size_t)n + 1, 0);  // position-ordered entry offset of every row position
+        for (i64 t = 0; t < n; ++t) kpos[(size_t)t + 1] = kpos[(size_t)t] + row_len(rows[(size_t)t]);
+
+        // wave-slot headers of one workgroup: a level's wave slots dealt to the waves in turn; a wave without one in a level
+        // repeats the level's first wave slot (see k_gs_sweep_windowed); a wave's last header of a level carries the barrier.
+        // As many waves as the widest level has wave slots (at most max_waves): a wave with nothing of its own in a level repeats
+        // another's wave slot, and those repeats take issue cycles from the waves on its SIMD.  with_stored: header k also says
+        // how many levels are complete with the wave's wave slot k - 6 (bands).
+        std::vector<GsStepW> hd;
+        std::vector<int> hoffs;
+        auto emit_headers = [&](const std::vector<std::pair<i64, i64>> &lv, int max_waves, bool with_stored, int *waves_out) {
+            i64 widest = 1;
+            for (const auto &r : lv) widest = std::max(widest, (r.second - r.first) / 64);
+            const int waves = (int)std::min<i64>(max_waves, widest);
+            *waves_out = waves;
+            std::vector<std::vector<GsStepW>> per((size_t)waves);
+            std::vector<std::vector<int>> done((size_t)waves);  // levels complete once the header's wave slot is stored
+            for (size_t l = 0; l < lv.size(); ++l) {
+                const i64 nw = (lv[l].second - lv[l].first) / 64;
+                for (i64 q = 0; q < nw; ++q) {
+                    const size_t q0 = (size_t)(lv[l].first + 64 * q);
+                    unsigned rounds = 1, far = 0;
+                    for (size_t k = q0; k < q0 + 64; ++k) {
+                        rounds = std::max(rounds, (unsigned)(lanes[k].info & 15) + 1u);
+                        far |= (unsigned)(lanes[k].info >> 8);
+                    }
+                    GsStepW h;
+                    h.first = (int)q0;
+                    h.meta = 1u | (rounds << 1) | (far ? 128u : 0u);
+                    if (far) g.has_far = true;
+                    per[(size_t)(q % waves)].push_back(h);
+                    done[(size_t)(q % waves)].push_back((int)l);
+                }
+                for (int wv = 0; wv < waves; ++wv) {
+                    if ((i64)wv >= nw) {  // nothing left for this wave: it repeats wave 0's
+                        per[(size_t)wv].push_back(per[0].back());
+                        done[(size_t)wv].push_back((int)l);
+                    }
+                    per[(size_t)wv].back().meta |= 64u;
+                    done[(size_t)wv].back() = (int)l + 1;
+                }
+            }
+            const int off = (int)hoffs.size();
+            for (int wv = 0; wv < waves; ++wv) {
+                // the kernel's loop is unrolled by 6 without a remainder: pad with repeats of the wave's last wave slot
+                // (after the last barrier; same inputs, same results), without the barrier flag
+                while (per[(size_t)wv].size() % 6) {
+                    GsStepW h = per[(size_t)wv].back();
+                    h.meta &= ~64u;
+                    per[(size_t)wv].push_back(h);
+                    done[(size_t)wv].push_back((int)lv.size());
+                }
+                if (with_stored) {
+                    const char *el = getenv("SLP_GS_BANDS_LAG");  // lab only (see SLP_GS_BANDS_SAFE)
+                    const size_t lag = el ? (size_t)atoi(el) : 6;
+                    for (size_t k = 0; k < per[(size_t)wv].size(); ++k)
+                        per[(size_t)wv][k].meta = (per[(size_t)wv][k].meta & 0xffu) | ((unsigned)(k >= lag ? done[(size_t)wv][k - lag] : 0) << 8);
+                }
+                hoffs.push_back((int)hd.size());
+                hd.insert(hd.end(), per[(size_t)wv].begin(), per[(size_t)wv].end());
+            }
+            hoffs.push_back((int)hd.size());
+            return off;
+        };
+        // one lane of a row: entries [j E, (j + 1) E) of row position t; cls(row, e, lane record, entry record) sets the entry's class
+        auto push_row = [&](i64 t, int ldsw, auto &&cls) {
+            const i64 len = kpos[(size_t)t + 1] - kpos[(size_t)t];
+            const int nl = (int)std::max<i64>(1, (len + kGsEntries - 1) / kGsEntries);
+            for (int j = 0; j < nl; ++j) {
+                const i64 left = len - (i64)j * kGsEntries;
+                const int cnt = (int)std::max<i64>(0, std::min<i64>(kGsEntries, left));
+                GsSlot sl;
+                sl.row = rows[(size_t)t]; sl.t = (i32)t;
+                sl.pad = ldsw;
+                sl.info = j | (nl << 8) | (cnt << 16);
+                slots.push_back(sl);
+                GsEnt en = noent;
+                GsLane cd = nolane;
+                cd.info = (unsigned short)(j | (j == nl - 1 ? 16 : 0) | (cnt << 5));
+                cd.ldsw = (unsigned short)(ldsw >= 0 ? ldsw : 0xffff);
+                lane_row.push_back((i32)t);
+                const i64 src = indptr[rows[(size_t)t]] + (i64)j * kGsEntries;  // the row's entries in storage order
+                for (int e = 0; e < cnt; ++e) {
+                    en.idx[e] = indices[src + e];
+                    en.val[e] = data[src + e];
+                    if (window) cls(indices[src + e], e, cd, en);
+                }
+                ents.push_back(en);
+                lanes.push_back(cd);
+            }
+            return nl;
+        };
+
+        std::vector<GsBand> bands;
+        std::vector<i32> fsrc;
+        std::vector<int> freq;
+        size_t next_band_run = 0;
+        i64 scratch_cells = (i64)64 * kGsWaves;
         for (i64 l = 0; l < g.nlevels; ++l) {
-            const i64 beg = g.lptr[(size_t)l], end = g.lptr[(size_t)l + 1];
-            bool launch = end - beg > wide;
-            for (i64 t = beg; t < end && !launch; ++t)
-                if (kpos[(size_t)t + 1] - kpos[(size_t)t] > (i64)kGsMaxSeg * kGsEntries) launch = true;  // a very long row
-            if (launch) {
+            if (is_launch[(size_t)l]) {
                 GsPlan::Segment sg;
                 sg.launch = true; sg.first = l; sg.count = 1; sg.slot_first = 0; sg.slot_count = 0;
                 sg.level_first = l; sg.level_count = 1; sg.hoff = 0; sg.waves = 0;
                 segs.push_back(sg);
                 continue;
             }
-            ++narrow_levels;
-            if (segs.empty() || segs.back().launch) seg_first_level = l;
+            if (next_band_run < band_runs.size() && band_runs[next_band_run].level_first == l) {
+                // ---- a run with bands: one segment, one workgroup per band ----
+                const BandRun &br = band_runs[next_band_run++];
+                const i64 L0 = br.level_first, L1 = br.level_first + br.level_count;
+                GsPlan::Segment sg;
+                sg.launch = false; sg.first = (i64)st.size(); sg.count = 0; sg.slot_first = (i64)slots.size(); sg.slot_count = 0;
+                sg.level_first = L0; sg.level_count = br.level_count; sg.hoff = 0; sg.waves = 0;
+                sg.bands = br.P; sg.band_first = (i64)bands.size();
+                for (int p = 0; p < br.P; ++p) {
+                    const std::vector<i64> &bl = br.lptr[(size_t)p];
+                    const i32 nlev = (i32)bl.size() - 1;
+                    std::vector<std::pair<i64, i64>> lv((size_t)nlev);
+                    for (i32 ll = 0; ll < nlev; ++ll) {
+                        const i64 beg = bl[(size_t)ll], end = bl[(size_t)ll + 1];
+                        const size_t slot0 = slots.size();
+                        const bool fits_ring = end - beg <= kGsWide;
+                        const std::vector<i32> &ex = br.ext[(size_t)p][(size_t)ll];
+                        for (i64 t = beg; t < end; ++t) {
+                            const i32 i = rows[(size_t)t];
+                            if ((slots.size() & 63) + (size_t)row_lanes(i) > 64) pad_wave();  // a row's lanes stay inside one wave
+                            push_row(t, fits_ring ? (int)((ll % kGsWinLevels) * kGsWide + (t - beg)) : -1,
+                                     [&](i32 js, int e, GsLane &cd, GsEnt &en) {
+                                         if (js >= i || level[(size_t)js] < L0 || level[(size_t)js] >= L1) return;  // static
+                                         if (band_of[(size_t)js] == p) {
+                                             const i32 lj = blev[(size_t)js];
+                                             if (lj > ll - kGsWinLevels && bl[(size_t)lj + 1] - bl[(size_t)lj] <= kGsWide) {
+                                                 cd.code[e] = (unsigned short)((lj % kGsWinLevels) * kGsWide + (pos[(size_t)js] - bl[(size_t)lj]));
+                                             } else {
+                                                 cd.info |= (unsigned short)(1 << (8 + e));
+                                                 en.idx[e] = pos[(size_t)js];
+                                                 g.has_far = true;
+                                             }
+                                         } else {  // a lower band's row: the fetch wave has put it into this level's generation
+                                             const size_t at = (size_t)(std::lower_bound(ex.begin(), ex.end(), js) - ex.begin());
+                                             cd.code[e] = (unsigned short)(kGsExt + (ll & 1) * (kGsFetchK * 64) + (int)at);
+                                         }
+                                     });
+                        }
+                        pad_wave();
+                        lv[(size_t)ll] = {(i64)slot0, (i64)slots.size()};
+                    }
+                    GsBand bd;
+                    bd.nlev = nlev;
+                    bd.fsrc = (int)fsrc.size();
+                    for (i32 ll = 0; ll < nlev + 3 * kGsFetchD; ++ll)
+                        for (int c = 0; c < kGsFetchK * 64; ++c) {
+                            const bool real = ll < nlev && (size_t)c < br.ext[(size_t)p][(size_t)ll].size();
+                            fsrc.push_back(real ? pos[(size_t)br.ext[(size_t)p][(size_t)ll][(size_t)c]] : (i32)bl[0]);
+                        }
+                    bd.freq = (int)freq.size();
+                    for (i32 r = 0; r < nlev + 1 + 2 * kGsFetchD; ++r) {  // row 0: levels 0 .. D - 1; row l + 1: levels up to l + D
+                        const i32 upto = std::min<i32>(nlev - 1, r == 0 ? kGsFetchD - 1 : r - 1 + kGsFetchD);
+                        for (int q = 0; q < 16; ++q) freq.push_back(q < p ? br.need[(size_t)p][(size_t)upto * 16 + q] : 0);
+                    }
+                    int waves = 1;
+                    bd.hoff = emit_headers(lv, kGsBandWaves, true, &waves);
+                    bd.waves = waves;
+                    bd.scratch = p * 1024;
+                    bd.pad0 = bd.pad1 = 0;
+                    bands.push_back(bd);
+                    if (getenv("SLP_GS_VERBOSE") && atoi(getenv("SLP_GS_VERBOSE")) > 1) {
+                        fprintf(stderr, "band %d: positions %lld..%lld, %d levels, %d waves, hoff %d, fsrc %d, freq %d; needs row 0:", p, (long long)bl[0],
+                                (long long)bl[(size_t)nlev], nlev, waves, bd.hoff, bd.fsrc, bd.freq);
+                        for (int q = 0; q < 4; ++q) fprintf(stderr, " %d", freq[(size_t)bd.freq + (size_t)q]);
+                        fprintf(stderr, "; row 1:");
+                        for (int q = 0; q < 4; ++q) fprintf(stderr, " %d", freq[(size_t)bd.freq + 16 + (size_t)q]);
+                        fprintf(stderr, "; reads of level 0:");
+                        for (int c = 0; c < 3; ++c) fprintf(stderr, " %d", fsrc[(size_t)bd.fsrc + (size_t)c]);
+                        fprintf(stderr, "; headers of wave 0: %d, first metas:", hoffs[(size_t)bd.hoff + 1] - hoffs[(size_t)bd.hoff]);
+                        for (int k = 0; k < 8 && hoffs[(size_t)bd.hoff] + k < (int)hd.size(); ++k) fprintf(stderr, " %x", hd[(size_t)hoffs[(size_t)bd.hoff] + (size_t)k].meta);
+                        fprintf(stderr, "; last metas:");
+                        for (int k = 8; k >= 1; --k) fprintf(stderr, " %x", hd[(size_t)hoffs[(size_t)bd.hoff + 1] - (size_t)k].meta);
+                        fprintf(stderr, "\n");
+                    }
+                    sg.waves = std::max(sg.waves, waves);
+                }
+                scratch_cells = std::max<i64>(scratch_cells, (i64)br.P * 1024);
+                sg.slot_count = (i64)slots.size() - sg.slot_first;
+                segs.push_back(sg);
+                l = L1 - 1;
+                continue;
+            }
+            if (segs.empty() || segs.back().launch || segs.back().bands) seg_first_level = l;
+            const i64 beg = g.lptr[(size_t)l], end = g.lptr[(size_t)l + 1];
             const size_t step0 = st.size();
             const size_t slot0 = slots.size();
             size_t first = slots.size();
@@ -610,53 +1134,33 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             };
             const bool fits_ring = end - beg <= kGsWide;  // this level's results go to the LDS ring
             for (i64 t = beg; t < end; ++t) {
-                const i64 len = kpos[(size_t)t + 1] - kpos[(size_t)t];
-                const int nl = (int)std::max<i64>(1, (len + kGsEntries - 1) / kGsEntries);
+                const int nl = row_lanes(rows[(size_t)t]);
                 size_t used = slots.size() - first;
                 if ((used & 63) + (size_t)nl > 64) {  // a row's lanes stay inside one wave
                     while ((slots.size() - first) & 63) { slots.push_back(idle); ents.push_back(noent); lanes.push_back(nolane); lane_row.push_back(0); }
                     used = slots.size() - first;
                 }
                 if (used + (size_t)nl > 1024) close_step(false);  // next step of the same level: no barrier in between
-                for (int j = 0; j < nl; ++j) {
-                    const i64 left = len - (i64)j * kGsEntries;
-                    const int cnt = (int)std::max<i64>(0, std::min<i64>(kGsEntries, left));
-                    GsSlot sl;
-                    sl.row = rows[(size_t)t]; sl.t = (i32)t;
-                    sl.pad = (window && fits_ring) ? (int)((l % kGsWinLevels) * kGsWide + (t - beg)) : -1;
-                    sl.info = j | (nl << 8) | (cnt << 16);
-                    slots.push_back(sl);
-                    GsEnt en = noent;
-                    GsLane cd = nolane;
-                    cd.info = (unsigned short)(j | (j == nl - 1 ? 16 : 0) | (cnt << 5));
-                    cd.ldsw = (unsigned short)(sl.pad >= 0 ? sl.pad : 0xffff);
-                    lane_row.push_back((i32)t);
-                    const i64 src = indptr[rows[(size_t)t]] + (i64)j * kGsEntries;  // the row's entries in storage order
-                    for (int e = 0; e < cnt; ++e) {
-                        en.idx[e] = indices[src + e];
-                        en.val[e] = data[src + e];
-                        if (!window) continue;
-                        const i64 js = indices[src + e], lj = level[(size_t)js];
-                        if (lj < seg_first_level || lj >= l) {
-                            cd.code[e] = (unsigned short)kGsOne;  // static: final before this run starts, or not touched before this row's step
-                        } else if (lj > l - kGsWinLevels && g.lptr[(size_t)lj + 1] - g.lptr[(size_t)lj] <= kGsWide) {
-                            cd.code[e] = (unsigned short)((lj % kGsWinLevels) * kGsWide + (pos[(size_t)js] - g.lptr[(size_t)lj]));  // near
-                        } else {
-                            cd.code[e] = (unsigned short)kGsOne;  // far: gathered from the results; the position is read from the entry record
-                            cd.info |= (unsigned short)(1 << (8 + e));
-                            en.idx[e] = pos[(size_t)js];
-                            has_far = true;
-                        }
-                    }
-                    ents.push_back(en);
-                    lanes.push_back(cd);
-                }
+                push_row(t, (window && fits_ring) ? (int)((l % kGsWinLevels) * kGsWide + (t - beg)) : -1,
+                         [&](i32 js, int e, GsLane &cd, GsEnt &en) {
+                             const i64 lj = level[(size_t)js];
+                             if (lj < seg_first_level || lj >= l) {
+                                 cd.code[e] = (unsigned short)kGsOne;  // static: final before this run starts, or not touched before this row's step
+                             } else if (lj > l - kGsWinLevels && g.lptr[(size_t)lj + 1] - g.lptr[(size_t)lj] <= kGsWide) {
+                                 cd.code[e] = (unsigned short)((lj % kGsWinLevels) * kGsWide + (pos[(size_t)js] - g.lptr[(size_t)lj]));  // near
+                             } else {
+                                 cd.code[e] = (unsigned short)kGsOne;  // far: gathered from the results; the position is read from the entry record
+                                 cd.info |= (unsigned short)(1 << (8 + e));
+                                 en.idx[e] = pos[(size_t)js];
+                                 has_far = true;
+                             }
+                         });
                 maxseg = std::max(maxseg, nl);
             }
             close_step(true);
             lvs0[(size_t)l] = (i64)slot0;
             lvs1[(size_t)l] = (i64)slots.size();
-            if (!segs.empty() && !segs.back().launch) {
+            if (!segs.empty() && !segs.back().launch && !segs.back().bands) {
                 segs.back().count += (i64)(st.size() - step0);
                 segs.back().slot_count += (i64)(slots.size() - slot0);
                 segs.back().level_count += 1;
@@ -668,7 +1172,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                 segs.push_back(sg);
             }
         }
-        if ((forced || narrow_levels >= 16) && !st.empty() && slots.size() < ((size_t)1 << 31)) {
+        if (!slots.empty() && slots.size() < ((size_t)1 << 31)) {
             g.pipelined = true;
             g.one_block = false;
             g.steps.upload(st.data(), st.size());
@@ -678,53 +1182,13 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             g.segments = segs;
             g.windowed = window;
             if (window) {
-                // wave-slot headers: a level's wave slots dealt to the waves in turn; a wave without one in a level repeats the
-                // level's first wave slot (see k_gs_sweep_windowed); a wave's last header of a level carries the barrier
-                std::vector<GsStepW> hd;
-                std::vector<int> hoffs;
                 for (GsPlan::Segment &sg : segs) {
-                    if (sg.launch) continue;
-                    // as many waves as the widest level of the run has wave slots (at most kGsWaves): a wave with nothing of its
-                    // own in a level repeats another's wave slot, and those repeats take issue cycles from the waves on its SIMD
-                    i64 widest = 1;
-                    for (i64 l = sg.level_first; l < sg.level_first + sg.level_count; ++l)
-                        widest = std::max(widest, (lvs1[(size_t)l] - lvs0[(size_t)l]) / 64);
-                    const int waves = (int)std::min<i64>(kGsWaves, widest);
+                    if (sg.launch || sg.bands) continue;
+                    std::vector<std::pair<i64, i64>> lv;
+                    for (i64 l = sg.level_first; l < sg.level_first + sg.level_count; ++l) lv.push_back({lvs0[(size_t)l], lvs1[(size_t)l]});
+                    int waves = 1;
+                    sg.hoff = emit_headers(lv, kGsWaves, false, &waves);
                     sg.waves = waves;
-                    std::vector<std::vector<GsStepW>> per((size_t)waves);
-                    for (i64 l = sg.level_first; l < sg.level_first + sg.level_count; ++l) {
-                        const i64 nw = (lvs1[(size_t)l] - lvs0[(size_t)l]) / 64;
-                        for (i64 q = 0; q < nw; ++q) {
-                            const size_t q0 = (size_t)(lvs0[(size_t)l] + 64 * q);
-                            unsigned rounds = 1, far = 0;
-                            for (size_t k = q0; k < q0 + 64; ++k) {
-                                rounds = std::max(rounds, (unsigned)(lanes[k].info & 15) + 1u);
-                                far |= (unsigned)(lanes[k].info >> 8);
-                            }
-                            GsStepW h;
-                            h.first = (int)q0;
-                            h.meta = 1u | (rounds << 1) | (far ? 128u : 0u);
-                            if (far) g.has_far = true;
-                            per[(size_t)(q % waves)].push_back(h);
-                        }
-                        for (int wv = 0; wv < waves; ++wv) {
-                            if ((i64)wv >= nw) per[(size_t)wv].push_back(per[0].back());  // nothing left for this wave: it repeats wave 0's
-                            per[(size_t)wv].back().meta |= 64u;
-                        }
-                    }
-                    sg.hoff = (i64)hoffs.size();
-                    for (int wv = 0; wv < waves; ++wv) {
-                        // the kernel's loop is unrolled by 6 without a remainder: pad with repeats of the wave's last wave slot
-                        // (after the last barrier; same inputs, same results), without the barrier flag
-                        while (per[(size_t)wv].size() % 6) {
-                            GsStepW h = per[(size_t)wv].back();
-                            h.meta &= ~64u;
-                            per[(size_t)wv].push_back(h);
-                        }
-                        hoffs.push_back((int)hd.size());
-                        hd.insert(hd.end(), per[(size_t)wv].begin(), per[(size_t)wv].end());
-                    }
-                    hoffs.push_back((int)hd.size());
                 }
                 g.segments = segs;
                 g.stepsw.upload(hd.data(), hd.size());
@@ -733,8 +1197,15 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                 g.lane_row.upload(lane_row.data(), lane_row.size());
                 g.dyn.alloc(lanes.size());
                 g.rowsw.alloc((size_t)n);
-                g.scratch.alloc((size_t)64 * kGsWaves);
+                g.scratch.alloc((size_t)scratch_cells);
                 g.xpos.alloc((size_t)n);
+                if (!bands.empty()) {
+                    g.nbands = (int)bands.size();
+                    g.bands.upload(bands.data(), bands.size());
+                    g.fsrc.upload(fsrc.data(), fsrc.size());
+                    g.freq.upload(freq.data(), freq.size());
+                    g.prog.alloc((size_t)kGsMaxBands * kGsProgStride);
+                }
             }
         }
     }
@@ -785,17 +1256,24 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
                     level_launch(sg.first);
                 } else if (g.windowed) {
                     hipLaunchKernelGGL(k_gs_pack_terms, dim3(grid_for(sg.slot_count, kBlock)), dim3(kBlock), 0, st, sg.slot_first,
-                                       sg.slot_count, g.ents.p, g.lanes.p, x, g.dyn.p);
+                                       sg.slot_count, g.ents.p, g.lanes.p, x, g.dyn.p, g.prog.p, sg.bands);
                     auto run = [&](auto kernel) {
-                        hipLaunchKernelGGL(kernel, dim3(1), dim3(64 * sg.waves), 0, st, g.hoffs.p + sg.hoff, g.stepsw.p, g.lanes.p,
-                                           g.lane_row.p, g.dyn.p, g.ents.p, g.rowsw.p, g.xpos.p, g.scratch.p, w);
+                        // bands: one workgroup per band (its compute waves + the fetch wave); else one workgroup
+                        hipLaunchKernelGGL(kernel, dim3(sg.bands ? sg.bands : 1), dim3(64 * (sg.waves + (sg.bands ? 1 : 0))), 0, st,
+                                           g.hoffs.p + sg.hoff, g.stepsw.p, g.lanes.p, g.lane_row.p, g.dyn.p, g.ents.p, g.rowsw.p, g.xpos.p,
+                                           g.scratch.p, w, g.bands.p + sg.band_first, g.fsrc.p, g.freq.p, g.prog.p);
                         const i64 t0 = g.lptr[(size_t)sg.level_first], t1 = g.lptr[(size_t)(sg.level_first + sg.level_count)];
                         hipLaunchKernelGGL(k_gs_unpack, dim3(grid_for(t1 - t0, kBlock)), dim3(kBlock), 0, st, t0, t1 - t0, g.rows.p, g.xpos.p, x);
                     };
-                    if (bounded && g.has_far) run(k_gs_sweep_windowed<true, true>);
-                    else if (bounded) run(k_gs_sweep_windowed<true, false>);
-                    else if (g.has_far) run(k_gs_sweep_windowed<false, true>);
-                    else run(k_gs_sweep_windowed<false, false>);
+                    if (sg.bands) {
+                        if (bounded && g.has_far) run(k_gs_sweep_windowed<true, true, true>);
+                        else if (bounded) run(k_gs_sweep_windowed<true, false, true>);
+                        else if (g.has_far) run(k_gs_sweep_windowed<false, true, true>);
+                        else run(k_gs_sweep_windowed<false, false, true>);
+                    } else if (bounded && g.has_far) run(k_gs_sweep_windowed<true, true, false>);
+                    else if (bounded) run(k_gs_sweep_windowed<true, false, false>);
+                    else if (g.has_far) run(k_gs_sweep_windowed<false, true, false>);
+                    else run(k_gs_sweep_windowed<false, false, false>);
                 } else if (bounded) {
                     hipLaunchKernelGGL(k_gs_sweep_pipelined<true>, dim3(1), dim3(1024), 0, st, (int)sg.count, g.steps.p + sg.first,
                                        g.slots.p, g.ents.p, g.invd.p, g.packed.p, x, w);
@@ -1047,6 +1525,8 @@ int slp_gs_sweep_kind(const slp_gs *g) {
     return g->plan.one_block ? 1 : (g->plan.pipelined ? (g->plan.windowed ? 3 : 2) : 0);
 }
 
+int slp_gs_num_bands(const slp_gs *g) { return g ? g->plan.nbands : -1; }
+
 int slp_gs_solve(slp_gs *g, const double *b, const double *lower, const double *upper, double *x, int maxiter, double w) {
     SLP_API_INT({
         SLP_REQUIRE(g && b && lower && upper && x, "slp_gs_solve: NULL argument");
@@ -1258,6 +1738,8 @@ int slp_admm_get_lambda(slp_admm *s, double *lam) {
 }
 
 int64_t slp_admm_num_levels(const slp_admm *s) { return s ? s->plan.nlevels : -1; }
+
+int slp_admm_num_bands(const slp_admm *s) { return s ? s->plan.nbands : -1; }
 
 int slp_admm_bench(slp_admm *s, int64_t k, double *ms) {
     SLP_API_INT({

@@ -38,6 +38,11 @@ class boundedGaussSeidelClass:  # noqa: N801  (name kept from the reference)
         """0 launch per level, 1 one workgroup, 2 pipelined runs of narrow levels, 3 the same with the LDS window (slp_hip.h)."""
         return int(self._l.slp_gs_sweep_kind(self._h))
 
+    @property
+    def num_bands(self):
+        """Workgroups that share the runs of narrow levels (bands of rows, slp_admm.hip); 0: every run on one workgroup."""
+        return int(self._l.slp_gs_num_bands(self._h))
+
     def solve(self, b, lower_bounds, upper_bounds, x, maxiter=3, w=1, order=None):
         """``maxiter`` sweeps of ``x_i <- clamp(x_i + w (b_i - M_i x) / M_ii, lower_i, upper_i)``
         in natural row order (the reference accepts ``order`` and ignores it, :132-134)."""

@@ -70,6 +70,11 @@ def run(cases, seed, verbose=False):
             os.environ["SLP_GS_SINKS"] = "0"  # earliest levels for every row (no last level of rows nothing waits for)
         else:
             os.environ.pop("SLP_GS_SINKS", None)
+        bands = rng.choice(["auto", "auto", "0", "2", "3", "8", "16"])  # rows of a run of narrow levels over several workgroups
+        if bands == "auto":
+            os.environ.pop("SLP_GS_BANDS", None)
+        else:
+            os.environ["SLP_GS_BANDS"] = bands
         rhs = rng.randn(n)
         lo = np.where(rng.rand(n) < 0.3, -np.inf, -rng.rand(n))
         hi = np.where(rng.rand(n) < 0.3, np.inf, rng.rand(n))
@@ -82,11 +87,12 @@ def run(cases, seed, verbose=False):
         g.solve(rhs, lo, hi, xg, maxiter=sweeps, w=w)
         if verbose:
             print("case", case, kind, n, m.nnz, "levels", g.num_levels, "pipelined", force, "sweep kind", g.sweep_kind, flush=True)
-        tally[(kind, force, g.sweep_kind)] = tally.get((kind, force, g.sweep_kind), 0) + 1
+        tally[(kind, force, g.sweep_kind, "bands" if g.num_bands else "")] = tally.get((kind, force, g.sweep_kind, "bands" if g.num_bands else ""), 0) + 1
         if not np.array_equal(xg, xo):
-            raise AssertionError(f"Gauss-Seidel mismatch: case {case} {kind} n={n} nnz={m.nnz} pipelined={force} kind={g.sweep_kind} "
+            raise AssertionError(f"Gauss-Seidel mismatch: case {case} {kind} n={n} nnz={m.nnz} pipelined={force} kind={g.sweep_kind} bands={bands}/{g.num_bands} "
                                  f"max diff {np.max(np.abs(xg - xo))}")
     os.environ.pop("SLP_GS_SINKS", None)
+    os.environ.pop("SLP_GS_BANDS", None)
     for name, old in (("SLP_GS_PIPELINED", saved), ("SLP_GS_WINDOW", saved_w)):
         if old is None:
             os.environ.pop(name, None)
@@ -102,7 +108,7 @@ def main():
     p.add_argument("--verbose", action="store_true")
     args = p.parse_args()
     tally = run(args.cases, args.seed, args.verbose)
-    print("ok:", args.cases, "cases", {f"{k[0]}/{k[1]}/kind{k[2]}": v for k, v in sorted(tally.items())})
+    print("ok:", args.cases, "cases", {f"{k[0]}/{k[1]}/kind{k[2]}{k[3]}": v for k, v in sorted(tally.items())})
 
 
 if __name__ == "__main__":
