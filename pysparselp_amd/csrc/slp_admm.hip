@@ -340,10 +340,13 @@ __device__ __forceinline__ double gs_read_result(double *p) {
 #endif
 }
 
-__device__ __forceinline__ double gs_lane_up(double v) {  // lane i receives lane i - 1's v (lane 0 keeps its own)
+// lane i receives lane i - 1's v inside its group of 16 lanes (the first lane of a group keeps its own): the plan keeps a row's
+// lanes inside one group.  row_shr is the cross-lane path inside a DPP row; the shift over the whole wave (wave_shr) takes
+// ~20 ns per dependent step against 3.4 for an add (tools/lab/chain_latency.cpp) -- once per chain round of every level.
+__device__ __forceinline__ double gs_lane_up(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false);  // row_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -414,6 +417,10 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     const int l = l0 + d;
+#ifdef SLP_GS_BANDS_ABLATE_FETCH  // (lab: wrong results) the fetch wave only keeps the barriers company
+                    if (l < nlev) __syncthreads();
+                    continue;
+#endif
                     wait_for(rqv[d]);        // the lower bands have stored what level l + D reads
                     rqv[d] = rq[(l + D + 1) * 16];
 #pragma unroll
@@ -465,6 +472,16 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
         const unsigned meta = __builtin_amdgcn_readfirstlane(rec[j].meta);
         const size_t slot = slot_of(j);
         const size_t slot_a = slot_of((j + 4) % RA), slot_b = slot_of((j + 2) % RA);
+        // First what the level's chain waits for: the ring reads of this wave slot (their addresses come from the lane record that
+        // arrived four wave slots ago).  The prefetches of later wave slots are issued behind them, into the LDS latency.
+        __builtin_amdgcn_sched_barrier(0);
+        const GsLane me = la[j];
+        double xv[kGsEntries];
+#pragma unroll
+        for (int e = 0; e < kGsEntries; ++e) xv[e] = win[me.code[e]];
+#if defined(SLP_GS_ABLATE) && SLP_GS_ABLATE == 4
+        for (int e = 0; e < kGsEntries; ++e) xv[e] = 1.0 + me.code[e];
+#endif
         // (the scheduler must not issue the load into rec[j] above the reads of its old value: the two would then be live
         // together, in two registers, and the copy between them lands right behind the load and waits for it)
         __builtin_amdgcn_sched_barrier(0);
@@ -475,13 +492,6 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
         dv[(jb + 2) % RB] = dyn[slot_b];
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        const GsLane me = la[j];
-        double xv[kGsEntries];
-#pragma unroll
-        for (int e = 0; e < kGsEntries; ++e) xv[e] = win[me.code[e]];
-#if defined(SLP_GS_ABLATE) && SLP_GS_ABLATE == 4
-        for (int e = 0; e < kGsEntries; ++e) xv[e] = 1.0 + me.code[e];
-#endif
         if (FAR) {
             if (meta & 128u) {  // uniform over the wave
                 const GsEnt en = ents[slot];
@@ -729,10 +739,10 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             i64 lanes_total = 0;
             for (i32 i : rr) lanes_total += row_lanes(i);
             // the single workgroup's time: a level costs its barrier-to-barrier chain and its bytes through one CU's load path
-            // (calibrated on the Potts 256^2 run, 511 levels of 8 wave slots: one workgroup 545 us, of which 240 are the chain --
-            // a build without the loads -- and 4 / 8 / 16 bands 320 / 305 / 380 us; a band's level is known to the next band
-            // six wave slots, a counter store and a poll later)
-            const double tau1 = 0.47, tauP = 0.47, per_slot = 0.075, per_slot_band = 0.02, hop = 3.0, flag_latency = 6.0;  // us
+            // (calibrated on the Potts 256^2 run, 511 levels of 8 wave slots: one workgroup 530 us, of which 240 are the chain --
+            // a build without the loads -- and 4 / 8 / 16 bands 287 / 265 / 327 us: a band's level costs 0.32 us + 0.09 per wave
+            // slot, and a band's level is known to the next band ~6 us later: six wave slots, a counter store, a poll)
+            const double tau1 = 0.47, tauP = 0.32, per_slot = 0.075, per_slot_band = 0.09, hop = 3.0, flag_latency = 6.0;  // us
             double t_single = 0;
             for (i64 l = l0; l < l1; ++l) {
                 i64 ln = 0;
@@ -918,6 +928,9 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         auto pad_wave = [&]() {
             while (slots.size() & 63) { slots.push_back(idle); ents.push_back(noent); lanes.push_back(nolane); lane_row.push_back(0); }
         };
+        auto pad_group = [&]() {  // (gs_lane_up hands a row's sum on inside groups of 16 lanes)
+            while (slots.size() & 15) { slots.push_back(idle); ents.push_back(noent); lanes.push_back(nolane); lane_row.push_back(0); }
+        };
 
         std::vector<i64> lvs0((size_t)g.nlevels, 0), lvs1((size_t)g.nlevels, 0);  // lane slots of every narrow level
         // windowed kernel: position of every row, and the first level of the run of narrow levels being built
@@ -1052,7 +1065,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                         const std::vector<i32> &ex = br.ext[(size_t)p][(size_t)ll];
                         for (i64 t = beg; t < end; ++t) {
                             const i32 i = rows[(size_t)t];
-                            if ((slots.size() & 63) + (size_t)row_lanes(i) > 64) pad_wave();  // a row's lanes stay inside one wave
+                            if ((slots.size() & 15) + (size_t)row_lanes(i) > 16) pad_group();  // a row's lanes stay inside one group of 16
                             push_row(t, fits_ring ? (int)((ll % kGsWinLevels) * kGsWide + (t - beg)) : -1,
                                      [&](i32 js, int e, GsLane &cd, GsEnt &en) {
                                          if (js >= i || level[(size_t)js] < L0 || level[(size_t)js] >= L1) return;  // static
@@ -1136,8 +1149,8 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             for (i64 t = beg; t < end; ++t) {
                 const int nl = row_lanes(rows[(size_t)t]);
                 size_t used = slots.size() - first;
-                if ((used & 63) + (size_t)nl > 64) {  // a row's lanes stay inside one wave
-                    while ((slots.size() - first) & 63) { slots.push_back(idle); ents.push_back(noent); lanes.push_back(nolane); lane_row.push_back(0); }
+                if ((used & 15) + (size_t)nl > 16) {  // a row's lanes stay inside one group of 16 lanes (of the step's lane slots)
+                    while ((slots.size() - first) & 15) { slots.push_back(idle); ents.push_back(noent); lanes.push_back(nolane); lane_row.push_back(0); }
                     used = slots.size() - first;
                 }
                 if (used + (size_t)nl > 1024) close_step(false);  // next step of the same level: no barrier in between
