@@ -9,6 +9,7 @@
 // run one kernel after the other on the stream.  Every row is summed by one
 // thread in storage order, so x is bit-identical to the sequential sweep.
 #include <algorithm>
+#include <chrono>
 
 #include "slp_common.h"
 #include "slp_kernels.h"
@@ -629,6 +630,9 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
     SLP_REQUIRE(n < (i64)1 << 31, "gauss-seidel: dimension must fit int32");
     g.n = n;
     g.nnz = indptr[n];
+    const auto plan_t0 = std::chrono::steady_clock::now();
+    auto plan_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - plan_t0).count(); };
+    double ms_levels = 0, ms_bands = 0;
     // dependency levels over the symmetrised pattern, lower part only
     std::vector<i32> level((size_t)n, 0);
     // need(j): the largest level among rows i < j that READ x[j] (anti-dependence: j must wait for i)
@@ -714,6 +718,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
     const bool pipeline = n > 0 && g.nnz < ((i64)1 << 31) && !(ep && ep[0] == '0') && (forced || !g.one_block) &&
                           (forced || narrow_levels >= 16) && narrow_levels > 0;
 
+    ms_levels = plan_ms();
     // ---- bands (see kGsFetchK): which runs of narrow levels are cut into row ranges, one workgroup each --------------------------
     // SLP_GS_BANDS=P forces P bands on every run they are possible on, 0 forbids them; otherwise a run gets the number of bands
     // (4, 8, 16 or none) a small timing model of the pipeline likes best.
@@ -884,6 +889,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         }
     }
 
+    ms_bands = plan_ms() - ms_levels;
     {   // permute the matrix into position order on the host (one O(nnz) pass)
         std::vector<i64> p2((size_t)n + 1, 0);
         std::vector<i32> j2((size_t)g.nnz + kGsEntries, 0);   // padded: the pipelined sweep reads kGsEntries per lane unconditionally
@@ -1222,6 +1228,9 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             }
         }
     }
+    if (getenv("SLP_GS_VERBOSE"))
+        fprintf(stderr, "gauss-seidel plan: n %lld, %lld entries, %lld levels: levels %.1f ms, bands %.1f ms, all %.1f ms (host)\n", (long long)n,
+                (long long)g.nnz, (long long)g.nlevels, ms_levels, ms_bands, plan_ms());
 }
 
 // bounded = false: plain SOR sweep (no bounds); the kernels then read the diagonal through the `lo` argument
