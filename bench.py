@@ -276,6 +276,8 @@ def main():
     a = DeviceMatrix.random(rows, args.n, args.density, args.seed, r0)
     xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed, r0)
     nnz_local = a.nnz
+    _lib.check(lib.slp_synchronize())
+    t_generate = time.perf_counter() - t_gen  # the synthetic LP itself (randomLP.py's part); the rest of setup_seconds is the solver's
     if args.format:
         _lib.check(lib.slp_matrix_set_format(a._h, args.format))
     from pysparselp_amd.scale import make_solver
@@ -375,6 +377,7 @@ def main():
             "roofline": roofline,
             "objective_after_run": obj,
             "setup_seconds": t_gen,
+            "setup_breakdown": {"generate_lp_seconds": t_generate, "solver_setup_seconds": t_gen - t_generate},
             "device_memory": mem,
         }
         solver.close()

@@ -67,6 +67,54 @@ __global__ void k_random_rows(i64 nrow, i64 ncol, double inv_log1mp, uint64_t se
     }
 }
 
+// The same rows, one WAVE per row (rows of many entries): every random number is a function of (row, event), so the 64 events
+// of a chunk are drawn by the 64 lanes at once, the columns are a prefix sum of the gaps over the wave, and the kept entries
+// are written side by side -- with a thread per row every lane wrote 4 + 8 bytes into a line of its own per event, and each
+// line went to memory several times before it was full (PMC: 164 GB written for the 24 GB of config 3).
+// The sequential loop stops at the first event whose column is past the end; columns grow with the event number, so that
+// is the first lane (of the first chunk) with column >= ncol.  Gaps are clamped to ncol before they are added: no overflow.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_random_rows_wave(i64 nrow, i64 ncol, double inv_log1mp, uint64_t seed, i64 row_offset,
+                                                             i64 *__restrict__ len, const i64 *__restrict__ ptr, i32 *__restrict__ idx,
+                                                             double *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 r = wave; r < nrow; r += waves) {
+        const uint64_t grow = (uint64_t)(r + row_offset);
+        i64 col = -1, kept = 0;                      // (uniform over the wave)
+        i64 out = FILL ? ptr[r] : 0;
+        for (uint64_t e0 = 0;; e0 += 64) {
+            const uint64_t e = e0 + (uint64_t)lane;
+            const double ug = u01(seed, STREAM_A, grow, 3 * e);
+            double gap = floor(log(ug) * inv_log1mp);
+            gap = gap < (double)ncol ? gap : (double)ncol;
+            i64 step = 1 + (i64)gap;                 // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const i64 up = __shfl_up(step, d);
+                if (lane >= d) step += up;
+            }
+            const i64 c = col + step;
+            const bool inside = c < ncol;
+            double v = 0.0;
+            if (inside) v = round2(gauss(u01(seed, STREAM_A, grow, 3 * e + 1), u01(seed, STREAM_A, grow, 3 * e + 2)));
+            const bool keep = inside && v != 0.0;
+            const unsigned long long mask = __ballot(keep);
+            if (FILL && keep) {
+                const i64 o = out + __popcll(mask & ((1ull << lane) - 1ull));
+                idx[o] = (i32)c;
+                val[o] = v;
+            }
+            const int n = __popcll(mask);
+            out += n;
+            kept += n;
+            if (__ballot(!inside) != 0ull) break;     // the row ends inside this chunk
+            col = __shfl(c, 63);
+        }
+        if (!FILL && lane == 0) len[r] = kept;
+    }
+}
+
 __global__ void k_random_cols(i64 n, uint64_t seed, double *__restrict__ xf, double *__restrict__ c, double *__restrict__ lb,
                               double *__restrict__ ub) {
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
@@ -115,7 +163,15 @@ slp_matrix *slp_matrix_random(int64_t nrow, int64_t ncol, double density, uint64
             DevBuf<i64> len((size_t)nrow + 1);
             len.zero();
             const int grid = grid_for(nrow, kBlock, 16);
-            if (nrow) {
+            // rows of 48 entries and more (expected): a wave per row, coalesced writes; SLP_RANDOM_WAVE=0/1 overrides (tests)
+            const char *ew = getenv("SLP_RANDOM_WAVE");
+            const bool by_wave = ew ? ew[0] == '1' : density * (double)ncol >= 48.0;
+            const int wgrid = grid_for(nrow * 64, kBlock, 16);
+            if (nrow && by_wave) {
+                hipLaunchKernelGGL((k_random_rows_wave<false>), dim3(wgrid), dim3(kBlock), 0, st, nrow, ncol, inv, seed, row_offset, len.p,
+                                   nullptr, nullptr, nullptr);
+                SLP_HIP(hipGetLastError());
+            } else if (nrow) {
                 hipLaunchKernelGGL((k_random_rows<false>), dim3(grid), dim3(kBlock), 0, st, nrow, ncol, inv, seed, row_offset, len.p,
                                    nullptr, nullptr, nullptr);
                 SLP_HIP(hipGetLastError());
@@ -130,7 +186,11 @@ slp_matrix *slp_matrix_random(int64_t nrow, int64_t ncol, double density, uint64
             a.nnz = nnz;
             a.idx.alloc((size_t)nnz);
             a.val.alloc((size_t)nnz);
-            if (nrow) {
+            if (nrow && by_wave) {
+                hipLaunchKernelGGL((k_random_rows_wave<true>), dim3(wgrid), dim3(kBlock), 0, st, nrow, ncol, inv, seed, row_offset, nullptr,
+                                   a.ptr.p, a.idx.p, a.val.p);
+                SLP_HIP(hipGetLastError());
+            } else if (nrow) {
                 hipLaunchKernelGGL((k_random_rows<true>), dim3(grid), dim3(kBlock), 0, st, nrow, ncol, inv, seed, row_offset, nullptr,
                                    a.ptr.p, a.idx.p, a.val.p);
                 SLP_HIP(hipGetLastError());

@@ -102,31 +102,122 @@ __global__ __launch_bounds__(kBlock) void k_value_set(i64 nnz, const double *__r
 }
 
 // ---- conversion -------------------------------------------------------------
+// A thread's view of its row's entries: one aligned chunk of N of them in registers, refilled (16-byte loads) when the row's
+// cursor leaves it; an entry is picked with a compare-select chain (static register indices).  The conversion walks 2048-4096
+// rows per workgroup strip by strip, a handful of entries per row and strip: read straight from memory, every 64-byte sector
+// of a row's stream came in again for each of its pieces -- the strips in between push it out of the L2 (PMC: 14-15 x the
+// matrix fetched, the kernels running at the speed of that traffic).
+template <class V, int N>
+struct EntryWindow {
+    static_assert((N & (N - 1)) == 0 && N * sizeof(V) >= 16, "a power of two, at least one 16-byte load");
+    V v[N];
+    i64 w;
+    __device__ __forceinline__ V get(const V *__restrict__ base, i64 k, i64 total, bool aligned) {
+        const i64 c = k / N;
+        if (c != w) {
+            w = c;
+            const i64 k0 = c * N;
+            if (aligned && k0 + N <= total) {
+                constexpr int PER = 16 / (int)sizeof(V);
+                const uint4 *p4 = reinterpret_cast<const uint4 *>(base + k0);
+#pragma unroll
+                for (int q = 0; q < N / PER; ++q) {
+                    const uint4 u = p4[q];
+                    if (sizeof(V) == 4) {
+                        v[q * PER + 0] = (V)__builtin_bit_cast(int, u.x);
+                        v[q * PER + 1] = (V)__builtin_bit_cast(int, u.y);
+                        v[q * PER + 2] = (V)__builtin_bit_cast(int, u.z);
+                        v[q * PER + 3] = (V)__builtin_bit_cast(int, u.w);
+                    } else {
+                        v[q * PER + 0] = (V)__hiloint2double((int)u.y, (int)u.x);
+                        v[q * PER + 1] = (V)__hiloint2double((int)u.w, (int)u.z);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < N; ++q) v[q] = k0 + q < total ? base[k0 + q] : V(0);
+            }
+        }
+        const int i = (int)(k & (N - 1));
+        V r = v[0];
+#pragma unroll
+        for (int q = 1; q < N; ++q) r = (i == q) ? v[q] : r;
+        return r;
+    }
+};
+
+// From the rows-per-count histogram of a cell: start[l] = rows with more than l entries (= first sorted position of count l,
+// = entries of slot l), offs[s] = where slot s begins (slots padded to a multiple of RPL entries); returns the padded cell
+// size.  Run by the first wave, four counts per lane and two scans over the wave (one thread walked the 256 counts twice).
+template <int RPL>
+__device__ __forceinline__ unsigned int strip_slot_scan(const unsigned int *hist, unsigned int *start, unsigned int *offs) {
+    static_assert(kStripSL == 256, "four counts per lane of one wave");
+    const int lane = threadIdx.x;  // (called with threadIdx.x < 64)
+    const uint4 h = reinterpret_cast<const uint4 *>(hist)[lane];
+    const unsigned int mine = h.x + h.y + h.z + h.w;
+    unsigned int suf = mine;       // counts of this lane and all higher ones
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int o = __shfl_down(suf, d);
+        if (lane + d < 64) suf += o;
+    }
+    uint4 st;
+    st.w = suf - mine;
+    st.z = st.w + h.w;
+    st.y = st.z + h.z;
+    st.x = st.y + h.y;
+    const uint4 pd = make_uint4((st.x + (RPL - 1u)) & ~(RPL - 1u), (st.y + (RPL - 1u)) & ~(RPL - 1u), (st.z + (RPL - 1u)) & ~(RPL - 1u),
+                                (st.w + (RPL - 1u)) & ~(RPL - 1u));
+    const unsigned int padded = pd.x + pd.y + pd.z + pd.w;
+    unsigned int pre = padded;     // padded slots of this lane and all lower ones
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int o = __shfl_up(pre, d);
+        if (lane >= d) pre += o;
+    }
+    if (start) reinterpret_cast<uint4 *>(start)[lane] = st;
+    if (offs) {
+        uint4 of;
+        of.x = pre - padded;
+        of.y = of.x + pd.x;
+        of.z = of.y + pd.y;
+        of.w = of.z + pd.z;
+        reinterpret_cast<uint4 *>(offs)[lane] = of;
+    }
+    return __shfl(pre, 63);
+}
+
 // pass 1: per (block, strip): every row's entry count (uint8) and the padded cell size
 //         sum_s even(cnt[s]),  cnt[s] = rows of the cell with more than s entries
 template <int C, int RPL>
 __global__ __launch_bounds__(kStripT) void k_strip_count(i64 nrow, i64 T, const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
                                                          unsigned char *__restrict__ len, unsigned long long *__restrict__ total,
                                                          int *__restrict__ bad) {
-    __shared__ unsigned int hist[kStripSL];
+    __shared__ __attribute__((aligned(16))) unsigned int hist[kStripSL];
     constexpr int R = RPL * kStripT;  // rows per block, RPL per thread
     const i64 b = blockIdx.x;
     i64 k[RPL], e[RPL];
     i32 prev[RPL];
+    EntryWindow<i32, 16> wi[RPL];
+    const i64 nnz = ptr[nrow];
+    const bool aligned = (reinterpret_cast<uintptr_t>(idx) & 15) == 0;
+#pragma unroll
     for (int h = 0; h < RPL; ++h) {
         const i64 row = b * R + h * kStripT + threadIdx.x;
         k[h] = e[h] = 0;
         prev[h] = -1;
+        wi[h].w = -1;
         if (row < nrow) { k[h] = ptr[row]; e[h] = ptr[row + 1]; }
     }
     for (i64 t = 0; t < T; ++t) {
         if (threadIdx.x < kStripSL) hist[threadIdx.x] = 0;
         __syncthreads();
         const i64 hi = (t + 1) * (i64)C;
+#pragma unroll
         for (int h = 0; h < RPL; ++h) {
             i64 c = 0;
             while (k[h] < e[h]) {
-                const i32 j = idx[k[h]];
+                const i32 j = wi[h].get(idx, k[h], nnz, aligned);
                 if (j >= hi) break;
                 if (j <= prev[h]) atomicOr(bad, 1);  // rows must be strictly increasing in column
                 prev[h] = j;
@@ -137,14 +228,9 @@ __global__ __launch_bounds__(kStripT) void k_strip_count(i64 nrow, i64 T, const 
             atomicAdd(&hist[c], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int above = 0;  // rows with a count > l
-            unsigned long long sum = 0;
-            for (int l = kStripSL - 1; l >= 0; --l) {
-                sum += (above + (RPL - 1u)) & ~(RPL - 1u);  // slot l holds `above` entries, padded to a multiple of RPL
-                above += hist[l];
-            }
-            total[b * T + t] = sum;
+        if (threadIdx.x < 64) {  // slot l holds (rows with a count > l) entries, padded to a multiple of RPL
+            const unsigned int sum = strip_slot_scan<RPL>(hist, nullptr, nullptr);
+            if (threadIdx.x == 0) total[b * T + t] = sum;
         }
         __syncthreads();
     }
@@ -166,17 +252,25 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
                                                         double *__restrict__ oval, unsigned short *__restrict__ ocol, int D,
                                                         const unsigned long long *__restrict__ keys,
                                                         unsigned short *__restrict__ oent) {
-    __shared__ unsigned int hist[kStripSL];   // rows with exactly this count, then the per-count cursor
-    __shared__ unsigned int start[kStripSL];  // rows with a larger count  (= first sorted position of this count)
-    __shared__ unsigned int offs[kStripSL];   // slot offsets
+    __shared__ __attribute__((aligned(16))) unsigned int hist[kStripSL];   // rows with exactly this count, then the per-count cursor
+    __shared__ __attribute__((aligned(16))) unsigned int start[kStripSL];  // rows with a larger count  (= first sorted position of this count)
+    __shared__ __attribute__((aligned(16))) unsigned int offs[kStripSL];   // slot offsets
     __shared__ unsigned long long skey[kDictMax];
     for (int q = threadIdx.x; q < D; q += kStripT) skey[q] = keys[q];
     constexpr int R = RPL * kStripT;
     const i64 b = blockIdx.x;
     i64 k[RPL];
+    // (64 registers of windows: 64-byte chunks of both streams with two rows per thread, 32-byte chunks with four)
+    EntryWindow<i32, RPL == 2 ? 16 : 8> wi[RPL];
+    EntryWindow<double, RPL == 2 ? 8 : 4> wv[RPL];
+    const i64 nnz = ptr[nrow];
+    const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(val)) & 15) == 0;
+#pragma unroll
     for (int h = 0; h < RPL; ++h) {
         const i64 row = b * R + h * kStripT + threadIdx.x;
         k[h] = (row < nrow) ? ptr[row] : 0;
+        wi[h].w = -1;
+        wv[h].w = -1;
     }
     for (i64 t = 0; t < T; ++t) {
         const i64 cell = b * T + t;
@@ -188,12 +282,7 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
             atomicAdd(&hist[c[h]], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int above = 0;
-            for (int l = kStripSL - 1; l >= 0; --l) { start[l] = above; above += hist[l]; }
-            unsigned int o = 0;  // cnt[s] = start[s]; slot s occupies even(cnt[s]) entries
-            for (int s = 0; s < kStripSL; ++s) { offs[s] = o; o += (start[s] + (RPL - 1u)) & ~(RPL - 1u); }
-        }
+        if (threadIdx.x < 64) strip_slot_scan<RPL>(hist, start, offs);  // cnt[s] = start[s]; slot s occupies cnt[s] padded to RPL
         __syncthreads();
         if (threadIdx.x < kStripSL) {
             soff[cell * kStripSL + threadIdx.x] = offs[threadIdx.x];
@@ -202,16 +291,18 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
         __syncthreads();
         const i64 bs = base[cell];
         const i32 col0 = (i32)(t * (i64)C);
+#pragma unroll
         for (int h = 0; h < RPL; ++h) {
             const unsigned int pos = start[c[h]] + atomicAdd(&hist[c[h]], 1u);
             perm[cell * R + pos] = (unsigned short)(h * kStripT + threadIdx.x);
             slen[cell * R + pos] = (unsigned char)c[h];
             for (unsigned int s = 0; s < c[h]; ++s) {
                 const i64 o = bs + offs[s] + pos;
-                const unsigned int jw = (unsigned int)(idx[k[h] + s] - col0);
+                const unsigned int jw = (unsigned int)(wi[h].get(idx, k[h] + s, nnz, aligned) - col0);
                 const unsigned short jc = (unsigned short)jw;
+                const double vv = wv[h].get(val, k[h] + s, nnz, aligned);
                 if (D > 0) {
-                    const unsigned long long key = value_key((unsigned long long)__double_as_longlong(val[k[h] + s]));
+                    const unsigned long long key = value_key((unsigned long long)__double_as_longlong(vv));
                     int lo = 0, hi = D - 1;  // the value is in the dictionary: plain binary search
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
@@ -231,10 +322,10 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
                         oent[(o >> 1) * 4 + 2 + (o & 1)] = jc;
                     }
                 } else if (WIDE) {
-                    oval[o] = val[k[h] + s];
+                    oval[o] = vv;
                     reinterpret_cast<unsigned int *>(ocol)[o] = jw;
                 } else {
-                    oval[o] = val[k[h] + s];
+                    oval[o] = vv;
                     ocol[o] = jc;
                 }
             }

@@ -285,6 +285,24 @@ def test_random_lp_generator_properties():
     assert (other != s[:10]).nnz > 0
 
 
+@pytest.mark.parametrize("n,m,p", [(4000, 900, 0.01), (300000, 700, 0.002), (70, 500, 0.5), (100000, 64, 0.00001)])
+def test_random_lp_generator_wave_per_row_draws_the_same_matrix(monkeypatch, n, m, p):
+    """The generator's two forms -- a thread per row, a wave per row (rows of many entries: coalesced writes) -- draw every
+    number from (row, event) and must give the same arrays, whatever the row length (empty rows, several 64-event chunks,
+    a chunk that ends exactly at the last column)."""
+    from pysparselp_amd.device import DeviceMatrix
+
+    out = []
+    for wave in ("0", "1"):
+        monkeypatch.setenv("SLP_RANDOM_WAVE", wave)
+        a = DeviceMatrix.random(m, n, p, 9, 3)
+        s = a.download()
+        a.close()
+        out.append(s)
+    assert np.array_equal(out[0].indptr, out[1].indptr) and np.array_equal(out[0].indices, out[1].indices)
+    assert np.array_equal(out[0].data, out[1].data) and out[0].nnz > 0
+
+
 def test_cp_on_device_generated_lp_matches_oracle():
     """Long rows (TREE order, 64 lanes per row): iterates vs the oracle on the downloaded matrix,
     objective within 1e-6 relative (north_star's tolerance)."""
