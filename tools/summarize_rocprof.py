@@ -80,6 +80,9 @@ def db_pmc(fetch_path, write_path):
     print(json.dumps({"correction": "FETCH_SIZE x2 (gfx950, coalesced streaming reads), KiB -> bytes x1024", "kernels": keep}, indent=1))
 
 
+SQ_KERNELS = ("strip_spmv", "tall_spmv", "strip_fill", "strip_count", "random_rows", "value_set", "gs_sweep")
+
+
 def db_sq(path):
     """Per-kernel launch means of whatever SQ_* counters one --pmc pass collected, plus the ratios quoted in DESIGN.md."""
     import sqlite3
@@ -90,7 +93,7 @@ def db_sq(path):
         agg[short(name)][counter].append(float(value))
     out = {}
     for k, d in agg.items():
-        if not k.startswith("slp::k_") or ("strip_spmv" not in k and "tall_spmv" not in k):
+        if not k.startswith("slp::k_") or not any(w in k for w in SQ_KERNELS):
             continue
         r = {c: sum(v) / len(v) for c, v in d.items()}
         r["launches"] = len(next(iter(d.values())))
