@@ -148,6 +148,34 @@ def test_gpu_row_block_solver_matches_oracle(monkeypatch, min_nnz, m_eq):
 
 
 @pytest.mark.gpu
+def test_gpu_short_very_wide_row_block_with_the_strip_range_split(monkeypatch):
+    """Config 5's shape in small (few rows, very many columns): `A x` runs on tall cells whose strips are shared by several
+    workgroups (SLP_TALL_SPLIT, what `bench.py --method admm_blocks` switches on) -- partial row sums added in a fixed order, not
+    the single chain; the block solver's projections carry a CG tolerance, so the iterates agree with the oracle's LU form as
+    without the split, and two runs agree bit for bit."""
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceBlocks
+
+    monkeypatch.setenv("SLP_STRIP_MIN_NNZ", "1")
+    monkeypatch.setenv("SLP_TALL_SPLIT", "3")
+    n, m, p = 400001, 1500, 3e-5   # 12 entries per row over 98 strips of 4096 columns
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=11)
+    assert a.spmv_kernel(False) == 6
+    s = a.download()
+    xo = oracle.lp_admm_block_decomposition(c, None, None, s, None, b, lb, ub, nb_iter=11, nb_iter_plot=10 ** 9, blocks_eq=[(0, m - 1)],
+                                            blocks_ineq=[])
+    out = []
+    for _ in range(2):
+        sol = DeviceBlocks(a, b, c, lb, ub)
+        sol.iterate(12)
+        out.append(sol.x())
+        sol.close()
+    a.close()
+    assert np.array_equal(out[0], out[1])
+    assert np.max(np.abs(out[0] - xo) / (1 + np.abs(xo))) < 1e-8
+
+
+@pytest.mark.gpu
 def test_several_row_blocks_on_one_rank_match_the_reference_block_decomposition():
     """DeviceBlocksGroup: three uneven row blocks of a device-resident LP, each its own copy of the variables; against the
     oracle's restatement of lp_admm_block_decomposition (sparse LU per block) with the same row ranges as blocks."""
