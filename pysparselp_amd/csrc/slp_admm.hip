@@ -760,7 +760,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
             // (a band's fetch lists and requirement rows are indexed with ints: runs of more than 2^20 levels keep one workgroup)
             if (l1 - l0 >= ((i64)1 << 20)) cand.clear();
             else if (want > 0) cand.push_back(std::min(want, kGsMaxBands));
-            else if (lanes_total >= 65536 && l1 - l0 >= 64) cand = {4, 8, 16};
+            else if (lanes_total >= 32768 && l1 - l0 >= 64) cand = {4, 8, 16};
             if (band_of.empty() && !cand.empty()) { band_of.assign((size_t)n, -1); blev.assign((size_t)n, 0); }
             std::vector<i32> bo_best, bl_best;
             for (int P : cand) {
