@@ -15,14 +15,17 @@ pytestmark = pytest.mark.gpu
 CASES = ["sc50a", "sc105", "potts8", "potts50", "random0", "random1", "random2"]
 
 
-@pytest.fixture(params=["window", "gather"])
+@pytest.fixture(params=["window", "gather", "bands"])
 def pipelined(monkeypatch, request):
     monkeypatch.setenv("SLP_GS_PIPELINED", "1")
     if request.param == "gather":
         monkeypatch.setenv("SLP_GS_WINDOW", "0")
-    yield 3 if request.param == "window" else 2
+    if request.param == "bands":  # the windowed kernel on three workgroups wherever a run allows it (tests/test_gpu_gs_bands.py)
+        monkeypatch.setenv("SLP_GS_BANDS", "3")
+    yield 2 if request.param == "gather" else 3
     monkeypatch.delenv("SLP_GS_PIPELINED", raising=False)
     monkeypatch.delenv("SLP_GS_WINDOW", raising=False)
+    monkeypatch.delenv("SLP_GS_BANDS", raising=False)
 
 
 @pytest.mark.parametrize("n,density", [(1, 1.0), (700, 0.004), (700, 0.03), (700, 0.25), (5000, 0.0008), (40000, 0.00005), (3000, 0.4)])
