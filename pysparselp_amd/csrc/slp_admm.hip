@@ -294,9 +294,32 @@ static_assert(kGsWinCells < 0xffff, "ring indices are 16 bits");
 // level l + kGsFetchD; 16 ints each, padded by 2 kGsFetchD rows), first scratch cell
 struct GsBand { int hoff, waves, nlev, fsrc, freq, scratch, pad0, pad1; };
 
+// right-hand side, bounds and own x of every row, by position (x[row] only changes in the row's own step)
+template <bool BOUNDED>
+__device__ __forceinline__ void gs_pack_rows(i64 n, const i32 *__restrict__ rows, const double *__restrict__ b, const double *__restrict__ lo,
+                                             const double *__restrict__ hi, const double *__restrict__ x, const double *__restrict__ invd,
+                                             GsRowW *__restrict__ out) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i32 i = rows[t];
+        GsRowW r;
+        r.b = b[i];
+        r.lo = BOUNDED ? lo[i] : lo[t];  // unbounded: the level-ordered diagonal
+        r.hi = BOUNDED ? hi[i] : 0.0;
+        r.xi = x[i];
+        r.invd = invd[t];
+        out[t] = r;
+    }
+}
+
+// ROWS != 0: the sweep's first windowed segment also packs the row records of ALL rows (a launch of its own before; a row's
+// record holds the row's own old x, which no earlier segment of the sweep touches): 1 bounded, 2 plain
+template <int ROWS>
 __global__ void k_gs_pack_terms(i64 first, i64 count, const GsEnt *__restrict__ ents, const GsLane *__restrict__ lanes,
-                                const double *__restrict__ x, GsDyn *__restrict__ dyn, int *__restrict__ prog, int nprog) {
+                                const double *__restrict__ x, GsDyn *__restrict__ dyn, int *__restrict__ prog, int nprog, i64 n,
+                                const i32 *__restrict__ rows, const double *__restrict__ b, const double *__restrict__ lo,
+                                const double *__restrict__ hi, const double *__restrict__ invd, GsRowW *__restrict__ rowsw) {
     if (blockIdx.x == 0 && (int)threadIdx.x < nprog) prog[threadIdx.x * kGsProgStride] = 0;  // (bands) nothing stored yet
+    if (ROWS) gs_pack_rows<ROWS == 1>(n, rows, b, lo, hi, x, invd, rowsw);
     for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (i64)gridDim.x * blockDim.x) {
         const GsEnt en = ents[first + k];
         const GsLane la = lanes[first + k];
@@ -308,22 +331,6 @@ __global__ void k_gs_pack_terms(i64 first, i64 count, const GsEnt *__restrict__ 
             d.v[e] = e >= cnt ? -0.0 : (fixed ? x[en.idx[e]] * en.val[e] : en.val[e]);
         }
         dyn[first + k] = d;
-    }
-}
-
-template <bool BOUNDED>
-__global__ void k_gs_pack_rows(i64 n, const i32 *__restrict__ rows, const double *__restrict__ b, const double *__restrict__ lo,
-                               const double *__restrict__ hi, const double *__restrict__ x, const double *__restrict__ invd,
-                               GsRowW *__restrict__ out) {
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
-        const i32 i = rows[t];
-        GsRowW r;
-        r.b = b[i];
-        r.lo = BOUNDED ? lo[i] : lo[t];  // unbounded: the level-ordered diagonal
-        r.hi = BOUNDED ? hi[i] : 0.0;
-        r.xi = x[i];
-        r.invd = invd[t];
-        out[t] = r;
     }
 }
 
@@ -1264,23 +1271,28 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
     };
     if (g.pipelined) {
         for (int s = 0; s < sweeps; ++s) {
-            // right-hand side, bounds and own x of every row, in level order (x[row] only changes in the row's own step)
-            if (g.windowed && bounded)
-                hipLaunchKernelGGL(k_gs_pack_rows<true>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.invd.p,
-                                   g.rowsw.p);
-            else if (g.windowed)
-                hipLaunchKernelGGL(k_gs_pack_rows<false>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.invd.p,
-                                   g.rowsw.p);
-            else if (bounded)
+            // (non-windowed kernel) right-hand side, bounds and own x of every row, in level order; the windowed kernel's row records
+            // are packed by the first windowed segment's k_gs_pack_terms
+            if (!g.windowed && bounded)
                 hipLaunchKernelGGL(k_gs_pack<true>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.packed.p);
-            else
+            else if (!g.windowed)
                 hipLaunchKernelGGL(k_gs_pack<false>, dim3(grid_for(g.n, kBlock)), dim3(kBlock), 0, st, g.n, g.rows.p, b, lo, hi, x, g.packed.p);
+            bool rows_packed = false;
             for (const GsPlan::Segment &sg : g.segments) {
                 if (sg.launch) {
                     level_launch(sg.first);
                 } else if (g.windowed) {
-                    hipLaunchKernelGGL(k_gs_pack_terms, dim3(grid_for(sg.slot_count, kBlock)), dim3(kBlock), 0, st, sg.slot_first,
-                                       sg.slot_count, g.ents.p, g.lanes.p, x, g.dyn.p, g.prog.p, sg.bands);
+                    {
+                        const int pgrid = rows_packed ? grid_for(sg.slot_count, kBlock) : grid_for(std::max<i64>(sg.slot_count, g.n), kBlock);
+                        auto pack = [&](auto kernel) {
+                            hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(kBlock), 0, st, sg.slot_first, sg.slot_count, g.ents.p, g.lanes.p, x,
+                                               g.dyn.p, g.prog.p, sg.bands, g.n, g.rows.p, b, lo, hi, g.invd.p, g.rowsw.p);
+                        };
+                        if (rows_packed) pack(k_gs_pack_terms<0>);
+                        else if (bounded) pack(k_gs_pack_terms<1>);
+                        else pack(k_gs_pack_terms<2>);
+                        rows_packed = true;
+                    }
                     auto run = [&](auto kernel) {
                         // bands: one workgroup per band (its compute waves + the fetch wave); else one workgroup
                         hipLaunchKernelGGL(kernel, dim3(sg.bands ? sg.bands : 1), dim3(64 * (sg.waves + (sg.bands ? 1 : 0))), 0, st,
