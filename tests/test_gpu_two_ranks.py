@@ -32,6 +32,21 @@ def _rank(rank, world, conn, n, m, p, seed, iters, q):
         def allreduce(buf, count, op, user):
             mine = np.ctypeslib.as_array(buf, shape=(count,))
             sizes.append(int(count))
+            if world > 2:  # a star: rank 0 adds the ranks' terms in rank order and hands the result back (conn: list / one pipe)
+                if rank == 0:
+                    res = mine.copy()
+                    for c in conn:
+                        other = np.frombuffer(c.recv_bytes(), dtype=np.float64)
+                        assert other.size == count, (other.size, count)
+                        res = np.maximum(res, other) if op == 1 else res + other
+                    for c in conn:
+                        c.send_bytes(res.tobytes())
+                else:
+                    conn.send_bytes(mine.tobytes())
+                    res = np.frombuffer(conn.recv_bytes(), dtype=np.float64)
+                    assert res.size == count, (res.size, count)
+                mine[:] = res
+                return 0
             if rank == 0:  # one side sends first, the other receives first: no deadlock on large buffers
                 conn.send_bytes(mine.tobytes())
                 other = np.frombuffer(conn.recv_bytes(), dtype=np.float64)
@@ -73,13 +88,18 @@ def _rank(rank, world, conn, n, m, p, seed, iters, q):
 def _run(world, n, m, p, seed, iters):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ends = ctx.Pipe(duplex=True) if world == 2 else (None, None)
-    procs = [ctx.Process(target=_rank, args=(r, world, ends[r] if world == 2 else None, n, m, p, seed, iters, q)) for r in range(world)]
+    if world > 2:
+        pipes = [ctx.Pipe(duplex=True) for _ in range(world - 1)]
+        conns = [[a for a, _ in pipes]] + [b for _, b in pipes]
+    else:
+        ends = ctx.Pipe(duplex=True) if world == 2 else (None, None)
+        conns = [ends[r] if world == 2 else None for r in range(world)]
+    procs = [ctx.Process(target=_rank, args=(r, world, conns[r], n, m, p, seed, iters, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     res = {}
     for _ in range(world):
-        rank, out = q.get(timeout=600)
+        rank, out = q.get(timeout=900)
         assert "error" not in out, out["error"]
         res[rank] = out
     for pr in procs:
@@ -106,3 +126,23 @@ def test_two_ranks_on_one_gpu_match_the_single_process_run(n, m, iters, p):
         assert err < 1e-9, (key, err)
     assert np.allclose(two[0]["admm_report"], two[1]["admm_report"], rtol=0, atol=0)
     assert np.allclose(two[0]["admm_report"], one["admm_report"], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_on_one_gpu_match_the_single_process_run():
+    """The partition the driver's 8-GPU run uses, on one GPU through the host transport: m = 40003 rows in eight unequal blocks
+    (5001 x 3 + 5000 x 5), strip kernels and value dictionary on every block, 70 iterations across the level-4 refresh: the
+    eight replicas stay bit-identical, issue the same collectives, and match the single-process run."""
+    n, m, iters, p, seed = 30000, 40003, 70, 0.001, 3
+    one = _run(1, n, m, p, seed, iters)[0]
+    eight = _run(8, n, m, p, seed, iters)
+    assert sum(eight[r]["rows"] for r in range(8)) == m and len({eight[r]["rows"] for r in range(8)}) == 2
+    for r in range(1, 8):
+        assert eight[r]["sizes"] == eight[0]["sizes"]
+        for key in ("cp_x", "admm_x"):
+            assert np.array_equal(eight[0][key], eight[r][key]), (key, r)
+        assert np.array_equal(eight[0]["admm_report"], eight[r]["admm_report"])
+    for key in ("cp_x", "admm_x"):
+        err = float(np.max(np.abs(eight[0][key] - one[key]) / (1 + np.abs(one[key]))))
+        assert err < 1e-9, (key, err)
+    assert np.allclose(eight[0]["admm_report"], one["admm_report"], rtol=1e-8, atol=1e-9)
