@@ -117,3 +117,17 @@ def test_bench_under_the_launcher_two_ranks_on_one_gpu():
     one = _launch(1, {"SLP_STRIP_MIN_NNZ": "1"}, 29651)
     assert two["config"]["nnz"] == one["config"]["nnz"]
     assert abs(two["objective_after_run"] - one["objective_after_run"]) <= 1e-9 * (1 + abs(one["objective_after_run"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_bench_under_the_launcher_eight_ranks_on_one_gpu():
+    """The driver's 8-GPU launch line (`torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`) with all eight ranks on
+    ONE device through the host transport: eight row blocks, one line from rank 0, the single-process objective."""
+    eight = _launch(8, {"SLP_DEVICE": "0", "SLP_COMM_TRANSPORT": "host", "SLP_STRIP_MIN_NNZ": "1"}, 29661)
+    check_line(eight, need_cpu_baseline=False)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["collectives_per_iteration"] == 2.0
+    one = _launch(1, {"SLP_STRIP_MIN_NNZ": "1"}, 29671)
+    assert eight["config"]["nnz"] == one["config"]["nnz"]
+    assert abs(eight["objective_after_run"] - one["objective_after_run"]) <= 1e-9 * (1 + abs(one["objective_after_run"]))
+
