@@ -115,6 +115,24 @@ int slp_device_memory(int64_t *free_bytes, int64_t *total_bytes);
  * i.e. the matrix part of the HBM traffic one launch must generate; -1 = error. */
 int64_t slp_matrix_format_bytes(slp_matrix *a, int transposed);
 
+/* ---- chunked matrix: an LP larger than one CSR copy of itself ------------ *
+ * No counterpart in the reference (its operands are whole scipy matrices: ChambollePockPPD.py:206-240, ADMM.py:148,262).
+ * The constraint matrix is handed over (slp_matrix_create) or generated (slp_matrix_random) in ROW CHUNKS, in row order;
+ * slp_matrix_chunked_append converts a chunk into its product copies for both orientations -- the copy of the chunk's
+ * transpose comes straight from the chunk's CSR, no transposed CSR is formed -- keeps the per-row sums the ADMM row
+ * scaling needs, releases the chunk's CSR and TAKES OWNERSHIP of the chunk (do not destroy or use it afterwards).  The
+ * chunked matrix then serves slp_matrix_spmv / _spmv_t / _bench_spmv / _format_bytes / _spmv_kernel, slp_cp_create_on and
+ * slp_admm_cg_create_on* (value-dictionary copies) like any other slp_matrix; whatever needs CSR entries fails with an
+ * error.  A x: every chunk writes its rows.  A^T y: chunk k continues the column sums chunk k - 1 left, so every column
+ * is one chain of additions in row order -- the unchunked product and scipy's csc_matvec bit for bit, for any chunking.
+ * Every chunk but the last needs an even number of rows; a chunk must qualify for strip copies (>= 3e7 entries, sorted
+ * rows).  BASELINE config 4 at density 1e-4 (1e7 x 2e7, 2e10 entries: 240 GB of CSR per orientation) is resident on one
+ * 288 GB GPU this way (208 GB of tall cells for both orientations). */
+slp_matrix *slp_matrix_chunked_create(int64_t ncol);
+int slp_matrix_chunked_append(slp_matrix *chunked, slp_matrix *chunk);
+/* Chunks appended so far; 0 for an ordinary matrix, -1 for NULL. */
+int64_t slp_matrix_chunks(const slp_matrix *a);
+
 /* ---- Chambolle-Pock: replaces chambolle_pock_ppd's loop ----------------- *
  * ChambollePockPPD.py:122-179 (preconditioners T, Sigma) and :195-343 (loop).
  * K = [A_eq; A_ineq] stacked by rows (m_eq rows first), b = [b_eq; b_ineq]

@@ -420,10 +420,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_scale_rows(i64 m, i64 m_eq, const
 // distinct values and runs on the value-dictionary strips (slp_strip.hip): scaling the entries would
 // make every row's values unique.  Differs from the in-place form by the rounding of rs_i * sum versus
 // sum of (rs_i * a_ij) terms only.
+// In two steps: the sums over a row's entries (k_cg_row_sq: all that is ever needed of the CSR -- a chunked matrix takes
+// them chunk by chunk while a chunk's CSR exists, slp_chunked.hip), then an elementwise pass (k_cg_row_scales_from).
 template <int L>
-__global__ __launch_bounds__(kBlock) void k_cg_row_scales(i64 m, i64 m_eq, const i64 *__restrict__ ptr, const double *__restrict__ val,
-                                                          double *__restrict__ bu, double *__restrict__ sc, double *__restrict__ rs,
-                                                          double *__restrict__ bl) {
+__global__ __launch_bounds__(kBlock) void k_cg_row_sq(i64 m, const i64 *__restrict__ ptr, const double *__restrict__ val,
+                                                      double *__restrict__ sq) {
     const int sub = threadIdx.x & (L - 1);
     const i64 group = ((i64)blockIdx.x * kBlock + threadIdx.x) / L;
     const i64 ngroups = (i64)gridDim.x * kBlock / L;
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_row_scales(i64 m, i64 m_eq, const
         double acc = 0.0;
         for (i64 k = s + sub; k < e; k += L) acc += (val[k] * val[k]) * 1.0;
         acc = group_sum<L>(acc);
+        const double sq1 = acc;
         double nrm = sqrt(acc);
         if (nrm == 0.0) nrm = 1.0;
         const double inv1 = 1.0 / nrm;
@@ -441,15 +443,24 @@ __global__ __launch_bounds__(kBlock) void k_cg_row_scales(i64 m, i64 m_eq, const
             acc += (v * v) * 1.0;
         }
         acc = group_sum<L>(acc);
+        if (sub == 0) { sq[2 * i] = sq1; sq[2 * i + 1] = acc; }
+    }
+}
+
+__global__ void k_cg_row_scales_from(i64 m, i64 m_eq, const double *__restrict__ sq, double *__restrict__ bu, double *__restrict__ sc,
+                                     double *__restrict__ rs, double *__restrict__ bl) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        double nrm = sqrt(sq[2 * i]);
+        if (nrm == 0.0) nrm = 1.0;
+        const double inv1 = 1.0 / nrm;
+        double acc = sq[2 * i + 1];
         if (i >= m_eq) acc = acc + 1.0;
         nrm = sqrt(acc);
         if (nrm == 0.0) nrm = 1.0;
         const double inv2 = 1.0 / nrm;
-        if (sub == 0) {
-            rs[i] = inv2 * inv1;
-            if (i >= m_eq) { sc[i] = inv2 * -1.0; bu[i] = inv1 * bu[i]; if (bl) bl[i] = inv1 * bl[i]; }
-            else { sc[i] = 0.0; bu[i] = inv2 * (inv1 * bu[i]); }
-        }
+        rs[i] = inv2 * inv1;
+        if (i >= m_eq) { sc[i] = inv2 * -1.0; bu[i] = inv1 * bu[i]; if (bl) bl[i] = inv1 * bl[i]; }
+        else { sc[i] = 0.0; bu[i] = inv2 * (inv1 * bu[i]); }
     }
 }
 
@@ -512,6 +523,14 @@ __global__ void k_cg_add_slack(i64 m, const double *__restrict__ rs, const doubl
 
 __global__ void k_cg_row_scaled(i64 m, const double *__restrict__ rs, const double *__restrict__ w, double *__restrict__ out) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) out[i] = rs[i] * w[i];
+}
+
+void matrix_row_squares(const CsrDev &a, double *sq) {
+    if (a.nrow == 0) return;
+    const int lanes = lanes_for(a, SLP_ORDER_TREE);
+    SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_row_sq<L>), dim3(grid_for(a.nrow * lanes, kBlock)), dim3(kBlock), 0, ctx().stream,
+                                                 a.nrow, a.ptr.p, a.val.p, sq));
+    SLP_HIP(hipGetLastError());
 }
 
 static void cg_finish_rows(slp_admm_cg *s, const double *v, double *w) {
@@ -813,7 +832,7 @@ slp_admm_cg *slp_admm_cg_create(int64_t N, int64_t m, const int64_t *indptr, con
             s->a = slp_matrix_create(m, N, indptr, indices, data);
             if (!s->a) throw Error(slp_last_error());
             s->owns_a = true;
-            build_transpose(s->a);
+            ensure_transposed(s->a);
             s->n_o = N; s->m = m; s->ns = 0; s->N = N;
             s->gamma_eq = gamma_eq; s->gamma_ineq = gamma_ineq; s->order = order;
             s->b.upload(b, (size_t)m); s->c.upload(c, (size_t)N); s->lb.upload(lb, (size_t)N); s->ub.upload(ub, (size_t)N);
@@ -847,7 +866,8 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
     SLP_API_PTR({
         SLP_REQUIRE(a_ineq && b_upper && c && lb && ub, "slp_admm_cg_create_on: NULL argument");
         SLP_REQUIRE(m_eq >= 0 && m_eq <= a_ineq->a.nrow, "slp_admm_cg_create_on_mixed: m_eq out of range");
-        require_csr(a_ineq, "slp_admm_cg_create_on");  // the row norms are taken over the CSR entries
+        const bool chunked = !a_ineq->chunks.empty();
+        if (!chunked) require_csr(a_ineq, "slp_admm_cg_create_on");  // the row norms are taken over the CSR entries
         Phase ph("slp_admm_cg_create_on");
         auto *s = new slp_admm_cg();
         try {
@@ -870,8 +890,15 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
             SLP_REQUIRE(!a_ineq->scaled, "slp_admm_cg_create_on: this matrix was already row-normalised in place by an earlier ADMM "
                                          "setup; scaling it again would solve a different problem -- build the solver on a fresh matrix");
             bool deferred = false;
-            if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1) || strip_wanted(a, 3) || tall_wanted(a)) && matrix_dictionary(a_ineq)) {
-                build_transpose(a_ineq);
+            if (chunked) {
+                // a chunked matrix holds no CSR: only the deferred form exists, from the row sums its chunks kept
+                const StripJds *f0 = fast_format(a_ineq, false), *f1 = fast_format(a_ineq, true);
+                deferred = f0->D > 0 && f1->D > 0;
+                for (const slp_matrix *ch : a_ineq->chunks) deferred = deferred && ch->rowsq.n == 2 * (size_t)ch->a.nrow;
+                SLP_REQUIRE(deferred, "slp_admm_cg_create_on: a chunked matrix runs the matrix-free ADMM on value-dictionary copies only "
+                                      "(its rows cannot be scaled in place: no CSR is held)");
+            } else if (m && n && (strip_wanted(a, 2) || strip_wanted(a, 1) || strip_wanted(a, 3) || tall_wanted(a.nrow, a.ncol, a.nnz)) &&
+                       matrix_dictionary(a_ineq)) {
                 const StripJds *f0 = fast_format(a_ineq, false), *f1 = fast_format(a_ineq, true);
                 deferred = f0 && f1 && f0->D > 0 && f1->D > 0;
             }
@@ -879,10 +906,20 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
                 s->rs.alloc((size_t)m);
                 s->wsw.alloc((size_t)m);
                 s->wsv1.alloc((size_t)m);
-                const int lanes = lanes_for(a, SLP_ORDER_TREE);
-                SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cg_row_scales<L>), dim3(grid_for(m * lanes, kBlock)), dim3(kBlock), 0, st,
-                                                             m, (i64)m_eq, a.ptr.p, a.val.p, bu.p, s->sc.p, s->rs.p, bl.p));
+                DevBuf<double> sq(2 * (size_t)m);
+                if (chunked) {
+                    for (size_t k = 0; k < a_ineq->chunks.size(); ++k) {
+                        const slp_matrix *ch = a_ineq->chunks[k];
+                        SLP_HIP(hipMemcpyAsync(sq.p + 2 * a_ineq->chunk_row0[k], ch->rowsq.p, 2 * (size_t)ch->a.nrow * sizeof(double),
+                                               hipMemcpyDeviceToDevice, st));
+                    }
+                } else {
+                    matrix_row_squares(a, sq.p);
+                }
+                hipLaunchKernelGGL(k_cg_row_scales_from, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, st, m, (i64)m_eq, sq.p, bu.p, s->sc.p,
+                                   s->rs.p, bl.p);
                 SLP_HIP(hipGetLastError());
+                SLP_HIP(hipStreamSynchronize(st));
             } else if (m) {
                 // in place: the matrix then holds the row-normalised values and every derived copy is rebuilt -- refuse when
                 // that would pull the data from under another solver
@@ -897,7 +934,7 @@ slp_admm_cg *slp_admm_cg_create_on_two_sided(slp_matrix *a_ineq, int64_t m_eq, c
                     SLP_HIP(hipGetLastError());
                 }
             }
-            if (!deferred) build_transpose(a_ineq);
+            if (!deferred) ensure_transposed(a_ineq);
             // c2 = [c; 0]  lb2 = [lb; -inf]  ub2 = [ub; bu']  b = 0  x0 = 0   (equality rows: b = b_eq'', slack pinned to 0)
             const size_t N = (size_t)s->N;
             s->c.alloc(N); s->lb.alloc(N); s->ub.alloc(N); s->x.alloc(N); s->b.alloc((size_t)m);

@@ -1,0 +1,108 @@
+// slp_chunked.hip -- a constraint matrix assembled from ROW CHUNKS whose CSR never coexists: the way an LP larger than
+// one CSR copy of itself gets resident on one GPU (BASELINE config 4's 1e7 x 2e7 matrix at density 1e-4: 2e10 stored
+// entries = 240 GB of CSR per orientation, but 104 GB per orientation as tall cells).
+//
+//   g = slp_matrix_chunked_create(ncol)
+//   for every chunk of rows, in order:  c = slp_matrix_create(...) or slp_matrix_random(...);  slp_matrix_chunked_append(g, c)
+//
+// append converts the chunk into its product copies for BOTH orientations (tall cells of A_k and, straight from the same
+// CSR, of A_k^T; LDS strips where those serve the shape), keeps the two per-row sums of squares the ADMM row scaling needs
+// (tools.py:272-290), and releases the chunk's CSR: what stays is 5-10 bytes per entry instead of 24.  The group then
+// behaves like any slp_matrix in the products and the at-scale solvers (slp_cp_create_on, slp_admm_cg_create_on*,
+// slp_random_lp_vectors chunk by chunk):
+//   A x    = the chunks' products, one row range each
+//   A^T y  = chunk k multiplies its slice of y and CONTINUES the column sums chunk k - 1 left in the output (the kernels'
+//            `accum` entry): every column is still one chain of additions in row order -- bit for bit the unchunked
+//            product and scipy's csc_matvec (ChambollePockPPD.py:206,216 ; ADMM.py:148), for ANY chunking.
+// It is the 8-rank row partition of DESIGN.md section 5 minus the wire: rank k's block = chunk k.
+#include "slp_common.h"
+#include "slp_kernels.h"
+
+slp_matrix::~slp_matrix() {
+    for (slp_matrix *c : chunks) delete c;
+}
+
+namespace slp {
+
+static void refresh_composites(slp_matrix *g) {
+    for (int t = 0; t < 2; ++t) {
+        StripJds &f = t ? g->fat : g->fa;
+        f.parts.clear();
+        f.part_off.clear();
+        f.parts_cols = t != 0;
+        f.ok = !g->chunks.empty();
+        f.nrow = t ? g->a.ncol : g->a.nrow;
+        f.ncol = t ? g->a.nrow : g->a.ncol;
+        f.nnz = g->a.nnz;
+        f.D = 0;
+        f.tall = true;
+        bool first = true;
+        for (size_t k = 0; k < g->chunks.size(); ++k) {
+            const StripJds *p = t ? &g->chunks[k]->fat : &g->chunks[k]->fa;
+            f.parts.push_back(p);
+            f.part_off.push_back(g->chunk_row0[k]);
+            f.D = first ? p->D : (p->D > 0 && f.D > 0 ? std::max(f.D, p->D) : 0);  // > 0: every chunk runs on a value dictionary
+            f.tall = f.tall && p->tall;
+            first = false;
+        }
+    }
+    g->at.nrow = g->a.ncol;
+    g->at.ncol = g->a.nrow;
+    g->at.nnz = g->a.nnz;
+}
+
+}  // namespace slp
+
+using namespace slp;
+
+extern "C" {
+
+slp_matrix *slp_matrix_chunked_create(int64_t ncol) {
+    SLP_API_PTR({
+        SLP_REQUIRE(ncol > 0 && ncol < ((i64)1 << 31), "slp_matrix_chunked_create: bad column count");
+        ctx();
+        auto *g = new slp_matrix();
+        g->a.ncol = ncol;
+        g->tried_fa = g->tried_fat = true;
+        g->have_at = true;  // nothing may ask for the transposed CSR of a chunked matrix
+        g->csr_released = true;
+        return g;
+    })
+}
+
+int slp_matrix_chunked_append(slp_matrix *g, slp_matrix *c) {
+    SLP_API_INT({
+        SLP_REQUIRE(g && c && g != c, "slp_matrix_chunked_append: NULL argument");
+        SLP_REQUIRE(g->csr_released && g->a.ptr.p == nullptr && (g->a.nrow == 0 || !g->chunks.empty()),
+                    "slp_matrix_chunked_append: the first argument is not a chunked matrix (slp_matrix_chunked_create)");
+        SLP_REQUIRE(c->chunks.empty() && !c->csr_released, "slp_matrix_chunked_append: the chunk must be a plain matrix with its CSR");
+        SLP_REQUIRE(c->a.ncol == g->a.ncol, "slp_matrix_chunked_append: the chunk has another column count");
+        SLP_REQUIRE(c->a.nrow > 0 && c->a.nnz > 0, "slp_matrix_chunked_append: empty chunk");
+        SLP_REQUIRE(g->borrowers == 0, "slp_matrix_chunked_append: a solver created on the chunked matrix is alive");
+        SLP_REQUIRE(c->borrowers == 0 && !c->scaled, "slp_matrix_chunked_append: the chunk is in use by a solver (or was scaled in place)");
+        // sub-vectors of y start at the chunk's first row: the strip kernels stage x with 16-byte loads
+        SLP_REQUIRE(g->a.nrow % 2 == 0, "slp_matrix_chunked_append: every chunk but the last must have an even number of rows");
+        Phase ph("slp_matrix_chunked_append");
+        // both product copies straight from the chunk's CSR
+        const StripJds *f0 = fast_format(c, false), *f1 = fast_format(c, true);
+        SLP_REQUIRE(f0 && f1, "slp_matrix_chunked_append: the chunk does not qualify for strip copies in both orientations (too small or "
+                              "unsorted rows): use an ordinary matrix for problems of that size");
+        if (f0->D > 0 && f1->D > 0) {  // what a later ADMM set-up needs of the entries (deferred row scaling)
+            c->rowsq.alloc(2 * (size_t)c->a.nrow);
+            matrix_row_squares(c->a, c->rowsq.p);
+        }
+        SLP_REQUIRE(slp_matrix_release_csr(c) == 0, slp_last_error());
+        c->a.ptr.release();   // (a plain release keeps the row pointers for diagnostics; a chunk needs nothing of them)
+        c->at.ptr.release();
+        g->chunks.push_back(c);
+        g->chunk_row0.push_back(g->a.nrow);
+        g->a.nrow += c->a.nrow;
+        g->a.nnz += c->a.nnz;
+        g->a.max_row_len = std::max(g->a.max_row_len, c->a.max_row_len);
+        refresh_composites(g);
+    })
+}
+
+int64_t slp_matrix_chunks(const slp_matrix *g) { return g ? (int64_t)g->chunks.size() : -1; }
+
+}  // extern "C"

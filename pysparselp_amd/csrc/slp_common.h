@@ -202,6 +202,15 @@ struct CsrDev {
     double mean_row_len() const { return nrow ? (double)nnz / (double)nrow : 0.0; }
 };
 
+// tall cells: the packet stream of one workgroup (row block, strip range) -- absolute device addresses, because the
+// streams are written in several build passes, each into buffers of its own (slp_tall.hip)
+struct TallWg {
+    const unsigned int *dir;   // packet headers (8 dwords each)
+    const unsigned int *pay;   // payload words
+    const double *val;         // fp64 entries (NULL with a value dictionary)
+    i64 npk;                   // packets, including the 2 x depth that are only ever prefetched
+};
+
 // strip-JDS copy of a CSR matrix for the LDS-tiled SpMV (slp_strip.hip)
 struct StripJds {
     bool ok = false;
@@ -226,10 +235,15 @@ struct StripJds {
     // tall cells (slp_tall.hip): row blocks of tall_R rows x strips of 4096 columns, packets of <= 1024 non-empty rows
     bool tall = false;
     int tall_R = 0;
-    DevBuf<i64> tall_base;            // [B + 1] first payload word of every row block
-    DevBuf<i64> tall_pkt;             // [B + 1] first packet of every row block
-    DevBuf<unsigned int> tall_dir;    // [packets * 8] 32-byte packet headers
-    DevBuf<unsigned int> tall_pay;    // payload words
+    DevBuf<TallWg> tall_wg;                          // [B * S] where every workgroup's packet stream lies
+    std::vector<DevBuf<unsigned int>> tall_dir;      // 32-byte packet headers, one buffer per build pass
+    std::vector<DevBuf<unsigned int>> tall_pay;      // payload words, one buffer per build pass
+    std::vector<DevBuf<double>> tall_val;            // fp64 entries: the values at the payload offsets
+    size_t tall_bytes = 0;                           // bytes of all of the above (what a product streams)
+    // composite of the row chunks of a chunked matrix (slp_chunked.hip): this orientation's copy of every chunk, in order
+    std::vector<const StripJds *> parts;
+    std::vector<i64> part_off;        // first row of chunk k inside the chunked matrix
+    bool parts_cols = false;          // the copy of A^T: the chunks cut its COLUMNS (x is sliced, the sums of a row continue)
 };
 constexpr int kTallRmax = 9984;       // most rows of a tall-cell row block (their running sums: 78 KB of LDS)
 // sorted distinct stored values of a matrix, when there are at most kDictMax of them
@@ -246,9 +260,14 @@ void strip_spmv(const StripJds &f, const double *x, double *out);
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1);  // one pass, two vectors
 void strip_spmv_with_dict(const StripJds &f, const double *table, const double *x, double *out);     // values table[id] instead of dict[id]
 void strip_spmv_pow(const StripJds &f, double pw, const double *x, double *out);                      // fp64 strips: values |v|^pw
-bool tall_wanted(const CsrDev &a);   // long rows that are sparse inside every LDS-sized window (slp_tall.hip)
-bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict);
-void tall_spmv(const StripJds &f, const double *x, double *out);
+bool strip_abs_pow_supported(const StripJds &f);
+void strip_spmv_abs_pow(const StripJds &f, double pw, const double *x, double *out);                  // values |v|^pw * 1.0, any copy that supports it
+// long rows that are sparse inside every LDS-sized window (slp_tall.hip); transposed: the question / the copy for A^T, taken
+// straight from the CSR of A (no transposed CSR is ever formed)
+bool tall_wanted(i64 nrow, i64 ncol, i64 nnz);
+bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict);
+void tall_spmv(const StripJds &f, const double *x, double *out, int accum);
+size_t strip_format_bytes(const StripJds &f);   // bytes of the copy a product streams (composites: all chunks)
 
 }  // namespace slp
 
@@ -265,11 +284,21 @@ struct slp_matrix {
     int borrowers = 0;           // live solvers created *_on this matrix (they hold raw pointers into its copies)
     int csr_bound = 0;           // those of them whose iterations walk the CSR arrays (slp_matrix_release_csr refuses while > 0)
     bool csr_released = false;   // slp_matrix_release_csr: entries only live in the strip copies (row pointers are kept)
+    // chunked matrix (slp_chunked.hip): row chunks whose CSR was dropped as soon as their strip copies stood; `a` / `at` then only
+    // carry the dimensions and the entry count, fa / fat are composites over the chunks' copies
+    std::vector<slp_matrix *> chunks;
+    std::vector<slp::i64> chunk_row0;      // first row of every chunk
+    slp::DevBuf<double> rowsq;             // a chunk: [2 * rows] the two sums of squares behind the ADMM row scaling (tools.py:272-290)
+    ~slp_matrix();
 };
 
 namespace slp {
 void finish_stats(CsrDev &a);          // max row length of a freshly built CSR
 void build_transpose(slp_matrix *m);   // stable: rows increasing inside every column
+void ensure_transposed(slp_matrix *m); // a strip copy of A^T if the matrix qualifies (tall cells need no transposed CSR), else build_transpose
+// per row i of the CSR: sq[2 i] = sum a_ij^2, sq[2 i + 1] = sum (a_ij / ||a_i||)^2 in the lane order of the ADMM row scaling
+// (slp_admm_cg.hip) -- what a chunked matrix keeps of a chunk's CSR for a later ADMM set-up
+void matrix_row_squares(const CsrDev &a, double *sq);
 int lanes_for(const CsrDev &a, int order);
 void launch_spmv(const CsrDev &a, const double *x, double *y, int order);
 // The strip copy of one orientation (built lazily), or NULL when the matrix does not qualify.

@@ -39,9 +39,6 @@ __global__ void k_cp_colsum(i64 n, const i64 *__restrict__ ptr, const i32 *__res
 }
 
 // |dict|^p for the strip copies' value table; fill; T from the two partial column sums
-__global__ void k_cp_dict_pow(int D, const double *__restrict__ dict, double p, double *__restrict__ out) {
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < D; q += gridDim.x * blockDim.x) out[q] = abs_pow(dict[q], p) * 1.0;
-}
 __global__ void k_cp_indicator(i64 m, i64 lo, i64 hi, double *__restrict__ y) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) y[i] = (i >= lo && i < hi) ? 1.0 : 0.0;
 }
@@ -409,16 +406,17 @@ static const StripJds *cp_primal_strips(slp_cp *s) {
 
 static void cp_setup(slp_cp *s) {
     hipStream_t st = ctx().stream;
-    build_transpose(s->k);
-    // derived formats are settled here, never lazily inside a (possibly captured) iteration
-    fast_format(s->k, true);
+    // derived formats are settled here, never lazily inside a (possibly captured) iteration; the transposed CSR is formed only
+    // when something walks it (no strip copy of K^T, or the (c + s_eq) + s_ineq order of cp_primal_strips)
+    ensure_transposed(s->k);
+    s->distributed = comm_active();
+    if (!cp_primal_strips(s) && s->k->chunks.empty()) build_transpose(s->k);
     if (fast_format(s->k, false)) s->kz.alloc((size_t)s->m);
     const CsrDev &a = s->k->a, &at = s->k->at;
     s->lanes_rows = lanes_for(a, s->order);
     s->lanes_cols = lanes_for(at, s->order);
     s->t.alloc((size_t)s->n);
     s->sigma.alloc((size_t)s->m);
-    s->distributed = comm_active();
     // short rows in both orientations, one lane per row, single GPU: ELL copies (SLP_CP_ELL=0 keeps the CSR walk)
     {
         const char *ee = getenv("SLP_CP_ELL");
@@ -449,26 +447,20 @@ static void cp_setup(slp_cp *s) {
     // through one thread per row (17-19 x the matrix in HBM traffic at config 3, profiles/r02_c3_pmc_hbm.json) -- and they
     // need no CSR arrays.  Equality and inequality rows are summed apart ((0 + s_eq) + s_ineq, :134,144): two products.
     const StripJds *ft = fast_format(s->k, true), *fr = fast_format(s->k, false);
-    auto plain_fp64 = [](const StripJds *f) { return f && f->D == 0 && !f->wide && !f->tall; };  // fp64 LDS strips: |v|^p on the fly
-    auto powered = [&](const StripJds *f, const double *table, double pw, const double *v, double *out) {
-        if (f->D > 0) strip_spmv_with_dict(*f, table, v, out);
-        else strip_spmv_pow(*f, pw, v, out);
-    };
     if (s->n) {
-        if (ft && (ft->D > 0 || plain_fp64(ft))) {
-            DevBuf<double> table((size_t)std::max(ft->D, 1)), ones((size_t)std::max<i64>(s->m, 1));
-            if (ft->D > 0) hipLaunchKernelGGL(k_cp_dict_pow, dim3(8), dim3(kBlock), 0, st, ft->D, ft->dict, 2.0 - s->alpha, table.p);
+        if (ft && strip_abs_pow_supported(*ft)) {
+            DevBuf<double> ones((size_t)std::max<i64>(s->m, 1));
             if (s->m_eq > 0 && s->m_ineq > 0) {
                 DevBuf<double> se((size_t)s->n), si((size_t)s->n);
                 hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, (i64)0, s->m_eq, ones.p);
-                powered(ft, table.p, 2.0 - s->alpha, ones.p, se.p);
+                strip_spmv_abs_pow(*ft, 2.0 - s->alpha, ones.p, se.p);
                 hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, s->m_eq, s->m, ones.p);
-                powered(ft, table.p, 2.0 - s->alpha, ones.p, si.p);
+                strip_spmv_abs_pow(*ft, 2.0 - s->alpha, ones.p, si.p);
                 hipLaunchKernelGGL(k_cp_join_sums, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, se.p, si.p, s->t.p);
                 SLP_HIP(hipStreamSynchronize(st));
             } else {
                 hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, (i64)0, s->m, ones.p);
-                powered(ft, table.p, 2.0 - s->alpha, ones.p, s->t.p);
+                strip_spmv_abs_pow(*ft, 2.0 - s->alpha, ones.p, s->t.p);
                 SLP_HIP(hipStreamSynchronize(st));
             }
             SLP_HIP(hipGetLastError());
@@ -477,6 +469,7 @@ static void cp_setup(slp_cp *s) {
             SLP_HIP(hipGetLastError());
         } else {
             require_csr(s->k, "Chambolle-Pock preconditioner T (CSR walk)");
+            build_transpose(s->k);
             hipLaunchKernelGGL(k_cp_colsum, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p, at.val.p,
                                (i32)s->m_eq, s->m_ineq, 2.0 - s->alpha, s->t.p, s->distributed ? 0 : 1);
             SLP_HIP(hipGetLastError());
@@ -488,11 +481,10 @@ static void cp_setup(slp_cp *s) {
         }
     }
     if (s->m) {
-        if (fr && (fr->D > 0 || plain_fp64(fr))) {
-            DevBuf<double> table((size_t)std::max(fr->D, 1)), ones((size_t)std::max<i64>(s->n, 1));
-            if (fr->D > 0) hipLaunchKernelGGL(k_cp_dict_pow, dim3(8), dim3(kBlock), 0, st, fr->D, fr->dict, s->alpha, table.p);
+        if (fr && strip_abs_pow_supported(*fr)) {
+            DevBuf<double> ones((size_t)std::max<i64>(s->n, 1));
             hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, (i64)0, s->n, ones.p);
-            powered(fr, table.p, s->alpha, ones.p, s->sigma.p);
+            strip_spmv_abs_pow(*fr, s->alpha, ones.p, s->sigma.p);
             hipLaunchKernelGGL(k_invert_or_one, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, s->sigma.p);
             SLP_HIP(hipGetLastError());
             SLP_HIP(hipStreamSynchronize(st));

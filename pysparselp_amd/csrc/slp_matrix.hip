@@ -171,15 +171,27 @@ void launch_spmv(const CsrDev &a, const double *x, double *y, int order) {
 
 bool comm_active();  // slp_comm.hip
 
+// Shape of A^T without its arrays (the transposed CSR is only formed when something walks it)
+static void transposed_shape(slp_matrix *m) {
+    if (m->have_at) return;
+    m->at.nrow = m->a.ncol;
+    m->at.ncol = m->a.nrow;
+    m->at.nnz = m->a.nnz;
+}
+
 const StripJds *fast_format(slp_matrix *m, bool transposed) {
-    if (transposed) build_transpose(m);
-    const CsrDev &a = transposed ? m->at : m->a;
+    if (!m->chunks.empty()) return transposed ? &m->fat : &m->fa;  // chunked matrix: the composites of the chunks' copies
     StripJds &f = transposed ? m->fat : m->fa;
     bool &tried = transposed ? m->tried_fat : m->tried_fa;
     if (!tried) {
         require_csr(m, "building a strip copy");
         tried = true;
+        transposed_shape(m);
         if (m->format_policy == 2) return nullptr;  // CSR kernels only
+        CsrDev shape;  // this orientation's dimensions (what the format choices look at)
+        shape.nrow = transposed ? m->a.ncol : m->a.nrow;
+        shape.ncol = transposed ? m->a.nrow : m->a.ncol;
+        shape.nnz = m->a.nnz;
         // few distinct stored values (rounded coefficients, +-1 patterns): 4-byte entries, values looked up in LDS
         // quads (4096-row blocks, 3-byte entries) when that still leaves enough row blocks to fill the chip without
         // splitting strips -- a split changes the association of the row sums, and on one GPU every product is the
@@ -189,22 +201,38 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
         // (10-13 % faster per iteration on the row blocks of 2 / 4 / 8 ranks, tools/variant_rule.py).
         // SLP_DICT_VARIANT=1|2 forces a geometry.
         const char *ev = getenv("SLP_DICT_VARIANT");
-        int variant = ((a.nrow + 4095) / 4096 >= 384 || comm_active()) ? 2 : 1;
+        int variant = ((shape.nrow + 4095) / 4096 >= 384 || comm_active()) ? 2 : 1;
         if (ev && (ev[0] == '1' || ev[0] == '2')) variant = ev[0] - '0';
-        else if (variant == 2 && !strip_wanted(a, 2) && strip_wanted(a, 1)) variant = 1;  // too sparse for the narrower quad strips
-        const bool dict = strip_wanted(a, variant) && matrix_dictionary(m);
-        // long rows that are sparse inside every LDS-sized window (the slice of a 1e7-variable LP): tall cells
-        if (!dict && tall_wanted(a) && matrix_dictionary(m) && tall_build(a, f, &m->vdict)) return &f;
+        else if (variant == 2 && !strip_wanted(shape, 2) && strip_wanted(shape, 1)) variant = 1;  // too sparse for the narrower quad strips
+        const bool dict = strip_wanted(shape, variant) && matrix_dictionary(m);
+        // long rows that are sparse inside every LDS-sized window (the slice of a 1e7-variable LP): tall cells -- for A^T taken
+        // straight from the CSR of A, no transposed CSR is formed
+        const bool tall = tall_wanted(shape.nrow, shape.ncol, shape.nnz);
+        if (!dict && tall && matrix_dictionary(m) && tall_build(m->a, transposed, f, &m->vdict)) return &f;
+        if (!dict && !strip_wanted(shape, 0) && tall && tall_build(m->a, transposed, f, nullptr)) return &f;  // arbitrary values: fp64 entries
+        if (transposed) build_transpose(m);  // the other copies are converted from the orientation's own CSR
+        const CsrDev &a = transposed ? m->at : m->a;
         if (dict) strip_build(a, f, &m->vdict, variant);
         else if (strip_wanted(a, 0)) strip_build(a, f, nullptr, 0);
-        else if (tall_wanted(a) && tall_build(a, f, nullptr)) return &f;  // the same shape with arbitrary values: fp64 entries
         else if (strip_wanted(a, 3))  // long rows over a width far beyond an L2: wide strips, x gathered from L2
             strip_build(a, f, matrix_dictionary(m) ? &m->vdict : nullptr, 3);
     }
     return f.ok ? &f : nullptr;
 }
 
+// Makes products with A^T possible: a strip copy of A^T when the matrix qualifies for one (tall cells come straight from the
+// CSR of A), else the transposed CSR.
+void ensure_transposed(slp_matrix *m) {
+    if (!m->chunks.empty() || m->have_at) return;
+    if (m->csr_released) return;  // (the copies were settled before the release)
+    if (fast_format(m, true)) return;
+    build_transpose(m);
+}
+
 void require_csr(const slp_matrix *m, const char *what) {
+    if (!m->chunks.empty())
+        throw Error(std::string(what) + ": a chunked matrix never holds the CSR of the whole problem (slp_matrix_chunked_append keeps "
+                                        "only the strip copies of every row chunk)");
     if (m->csr_released)
         throw Error(std::string(what) + ": the CSR entries of this matrix were released (slp_matrix_release_csr); only the products "
                                         "over its strip copies remain");
@@ -219,6 +247,7 @@ void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int
         return;
     }
     require_csr(m, "CSR product");
+    if (transposed) build_transpose(m);
     launch_spmv(transposed ? m->at : m->a, x, y, order);
 }
 
@@ -494,7 +523,6 @@ int slp_matrix_spmv(slp_matrix *m, const double *x, double *y, int order) {
 int slp_matrix_spmv_t(slp_matrix *m, const double *y, double *out, int order) {
     SLP_API_INT({
         SLP_REQUIRE(m && y && out, "slp_matrix_spmv_t: NULL argument");
-        build_transpose(m);
         DevBuf<double> vy((size_t)m->a.nrow), vo((size_t)m->a.ncol);
         vy.upload(y, (size_t)m->a.nrow);
         matrix_spmv(m, true, vy.p, vo.p, order);
@@ -538,7 +566,7 @@ int slp_matrix_download_rows(slp_matrix *m, int transposed, int64_t row0, int64_
 int slp_matrix_release_csr(slp_matrix *m) {
     SLP_API_INT({
         SLP_REQUIRE(m, "slp_matrix_release_csr: NULL matrix");
-        if (m->csr_released) return 0;
+        if (m->csr_released || !m->chunks.empty()) return 0;
         const StripJds *f0 = fast_format(m, false), *f1 = fast_format(m, true);
         SLP_REQUIRE(f0 && f1, "slp_matrix_release_csr: the matrix does not run on strip copies in both orientations; its CSR arrays "
                               "are the only copy of the entries");
@@ -581,6 +609,7 @@ int slp_matrix_spmv_kernel(slp_matrix *m, int transposed) {
         SLP_REQUIRE(m, "slp_matrix_spmv_kernel: NULL matrix");
         const StripJds *f = fast_format(m, transposed != 0);
         if (!f) return 0;
+        if (!f->parts.empty()) f = f->parts[0];  // chunked matrix: the kernel of its first chunk (all chunks of one shape share it)
         if (f->tall) return f->D > 0 ? 6 : 7;
         if (f->wide) return f->D > 0 ? 4 : 5;
         return f->D > 0 ? (f->rpl == 4 ? 3 : 2) : 1;
@@ -594,15 +623,8 @@ int64_t slp_matrix_format_bytes(slp_matrix *m, int transposed) {
     try {
         SLP_REQUIRE(m, "slp_matrix_format_bytes: NULL matrix");
         const StripJds *f = fast_format(m, transposed != 0);
-        const CsrDev &a = transposed ? m->at : m->a;
-        if (!f) return (int64_t)(12 * a.nnz + 8 * (a.nrow + 1));
-        if (f->tall)
-            return (int64_t)((f->tall_pay.n + f->tall_dir.n) * sizeof(unsigned int) + (f->tall_base.n + f->tall_pkt.n) * sizeof(i64) +
-                             (size_t)f->D * sizeof(double) + (f->D > 0 ? 0 : f->val.n * sizeof(double)));
-        const size_t entries = f->D > 0 ? f->ent.n * sizeof(unsigned short) + (size_t)f->D * sizeof(double)
-                                        : f->val.n * sizeof(double) + f->col.n * sizeof(unsigned short);
-        return (int64_t)(entries + f->perm.n * sizeof(unsigned short) + f->slen.n + f->soff.n * sizeof(unsigned int) +
-                         f->base.n * sizeof(i64));
+        if (!f) return (int64_t)(12 * m->a.nnz + 8 * ((transposed ? m->a.ncol : m->a.nrow) + 1));
+        return (int64_t)strip_format_bytes(*f);
     } catch (const std::exception &e) {
         set_error(e.what());
         return -1;
@@ -612,8 +634,10 @@ int64_t slp_matrix_format_bytes(slp_matrix *m, int transposed) {
 int slp_matrix_bench_spmv(slp_matrix *m, int transposed, int order, int reps, double *ms) {
     SLP_API_INT({
         SLP_REQUIRE(m && reps > 0 && ms, "slp_matrix_bench_spmv: bad arguments");
-        if (transposed) build_transpose(m);
-        const CsrDev &a = transposed ? m->at : m->a;
+        if (transposed) ensure_transposed(m);
+        CsrDev a;  // dimensions of the orientation
+        a.nrow = transposed ? m->a.ncol : m->a.nrow;
+        a.ncol = transposed ? m->a.nrow : m->a.ncol;
         DevBuf<double> vx((size_t)a.ncol), vy((size_t)a.nrow);
         std::vector<double> h((size_t)a.ncol);
         for (size_t i = 0; i < h.size(); ++i) h[i] = 1.0 + 1e-3 * (double)(i % 1000);

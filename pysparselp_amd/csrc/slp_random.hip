@@ -209,13 +209,14 @@ int slp_random_lp_vectors(slp_matrix *m, double density, uint64_t seed, int64_t 
                           double *lb, double *ub, double *b_upper) {
     SLP_API_INT({
         SLP_REQUIRE(m, "slp_random_lp_vectors: NULL matrix");
+        if (m->a.nrow && b_upper) require_csr(m, "slp_random_lp_vectors (b_upper = ceil(A x_f + ...): take it chunk by chunk, before the append)");
         Phase ph("slp_random_lp_vectors");
         hipStream_t st = ctx().stream;
         const i64 n = m->a.ncol, rows = m->a.nrow;
         DevBuf<double> xf((size_t)n), dc((size_t)n), dl((size_t)n), du((size_t)n), ax((size_t)rows), db((size_t)rows);
         hipLaunchKernelGGL(k_random_cols, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, n, seed, xf.p, dc.p, dl.p, du.p);
         SLP_HIP(hipGetLastError());
-        if (rows) {
+        if (rows && b_upper) {
             launch_spmv(m->a, xf.p, ax.p, SLP_ORDER_AUTO);
             hipLaunchKernelGGL(k_random_bupper, dim3(grid_for(rows, kBlock)), dim3(kBlock), 0, st, rows, seed, row_offset, density,
                                ax.p, db.p);

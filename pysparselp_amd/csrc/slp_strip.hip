@@ -370,14 +370,17 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
                                                            const unsigned char *__restrict__ slen,
                                                            const unsigned int *__restrict__ soff, const double *__restrict__ val,
                                                            const unsigned short *__restrict__ col, const double *__restrict__ x,
-                                                           double *__restrict__ out, double pw) {
+                                                           double *__restrict__ out, double pw, int accum) {
     __shared__ double xt[kStripC];
     __shared__ double acc[kStripR];
     __shared__ unsigned int offs[kStripSL];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
-    acc[p] = 0.0;
-    acc[p + kStripT] = 0.0;
+    // accum: the running sums start from what `out` holds (a row chunk of a chunked matrix continuing the column sums of
+    // the chunks before it: the chain of additions of the unchunked product); partial-sum mode takes it in the combine
+    const bool cont = accum && gridDim.y == 1;
+    acc[p] = (cont && b * kStripR + p < nrow) ? out[b * kStripR + p] : 0.0;
+    acc[p + kStripT] = (cont && b * kStripR + kStripT + p < nrow) ? out[b * kStripR + kStripT + p] : 0.0;
     // gridDim.y > 1: this workgroup covers only its share of the strips and writes partial sums
     const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
     for (i64 t = t_begin; t < t_end; ++t) {
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(kStripT, 4) void k_strip_spmv2(i64 nrow, i64 ncol, 
                                                             const unsigned int *__restrict__ soff, const double *__restrict__ val,
                                                             const unsigned short *__restrict__ col, const double *__restrict__ x0,
                                                             const double *__restrict__ x1, double *__restrict__ out0,
-                                                            double *__restrict__ out1) {
+                                                            double *__restrict__ out1, int accum) {
     __shared__ double xt0[kStripC];
     __shared__ double xt1[kStripC];
     __shared__ double acc0[kStripR];
@@ -459,8 +462,13 @@ __global__ __launch_bounds__(kStripT, 4) void k_strip_spmv2(i64 nrow, i64 ncol, 
     __shared__ unsigned int offs[kStripSL];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
-    acc0[p] = 0.0; acc0[p + kStripT] = 0.0;
-    acc1[p] = 0.0; acc1[p + kStripT] = 0.0;
+    const bool cont = accum && gridDim.y == 1;  // as in k_strip_spmv
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + p;
+        acc0[h * kStripT + p] = (cont && row < nrow) ? out0[row] : 0.0;
+        acc1[h * kStripT + p] = (cont && row < nrow) ? out1[row] : 0.0;
+    }
     const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
     for (i64 t = t_begin; t < t_end; ++t) {
         const i64 cell = b * T + t;
@@ -536,14 +544,19 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
                                                                          const unsigned short *__restrict__ ent,
                                                                          const double *__restrict__ dict, int D,
                                                                          const double *__restrict__ x0, const double *__restrict__ x1,
-                                                                         double *__restrict__ out0, double *__restrict__ out1) {
+                                                                         double *__restrict__ out0, double *__restrict__ out1, int accum) {
     __shared__ double xt[NV][kDictC];
     __shared__ double acc[NV][kStripR];
     __shared__ double dv[kDictMax];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
+    const bool cont = accum && gridDim.y == 1;  // as in k_strip_spmv
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { acc[v][p] = 0.0; acc[v][p + kStripT] = 0.0; }
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + p;
+        acc[0][h * kStripT + p] = (cont && row < nrow) ? out0[row] : 0.0;
+        if (NV == 2) acc[NV - 1][h * kStripT + p] = (cont && row < nrow) ? out1[row] : 0.0;
+    }
     for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
     const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
     // Software pipeline: the x-tile and the per-strip row metadata of strip t + 1 are loaded into registers
@@ -665,16 +678,19 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstri
                                                                          const unsigned short *__restrict__ ent,
                                                                          const double *__restrict__ dict, int D,
                                                                          const double *__restrict__ x0, const double *__restrict__ x1,
-                                                                         double *__restrict__ out0, double *__restrict__ out1) {
+                                                                         double *__restrict__ out0, double *__restrict__ out1, int accum) {
     __shared__ double xt[NV][kQuadC];
     __shared__ double acc[NV][kQuadR];
     __shared__ double dv[kDictMax];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
+    const bool cont = accum && gridDim.y == 1;  // as in k_strip_spmv
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int h = 0; h < 4; ++h) acc[v][p + h * kStripT] = 0.0;
+    for (int h = 0; h < 4; ++h) {
+        const i64 row = b * kQuadR + h * kStripT + p;
+        acc[0][p + h * kStripT] = (cont && row < nrow) ? out0[row] : 0.0;
+        if (NV == 2) acc[NV - 1][p + h * kStripT] = (cont && row < nrow) ? out1[row] : 0.0;
+    }
     for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
     const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
     constexpr int kTileQ = (kQuadC / 2 + kStripT - 1) / kStripT;
@@ -814,7 +830,7 @@ __global__ __launch_bounds__(kStripT, 8) void k_wstrip_spmv(i64 nrow, i64 ncol, 
                                                             const double *__restrict__ val, const unsigned int *__restrict__ col,
                                                             const double *__restrict__ dict, int D, const double *__restrict__ x0,
                                                             const double *__restrict__ x1, double *__restrict__ out0,
-                                                            double *__restrict__ out1) {
+                                                            double *__restrict__ out1, int accum) {
     // one right-hand side per pass: two strips of x would compete for the L2 (a two-vector version measured 50 ms for the
     // pair against 2 x 12.5 ms on the 2.5e6 x 1e7 slice)
     constexpr int NV = 1;
@@ -822,8 +838,12 @@ __global__ __launch_bounds__(kStripT, 8) void k_wstrip_spmv(i64 nrow, i64 ncol, 
     __shared__ double dv[DICT ? kDictMax : 1];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
+    const bool cont = accum && gridDim.y == 1;  // as in k_strip_spmv
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { acc[v][p] = 0.0; acc[v][p + kStripT] = 0.0; }
+    for (int h = 0; h < 2; ++h) {
+        const i64 row = b * kStripR + h * kStripT + p;
+        acc[0][h * kStripT + p] = (cont && row < nrow) ? out0[row] : 0.0;
+    }
     if (DICT)
         for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
     constexpr int kU = DICT ? 6 : 4;  // entry pairs in flight per lane; each brings two gathers per right-hand side
@@ -896,13 +916,17 @@ __global__ __launch_bounds__(kStripT, 8) void k_wstrip_spmv(i64 nrow, i64 ncol, 
     }
 }
 
-// out[row] = ((part[0][row] + part[1][row]) + ...) in strip order (deterministic)
-__global__ void k_strip_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out) {
+// out[row] = ((part[0][row] + part[1][row]) + ...) in strip order (deterministic); accum: continuing from out[row]
+__global__ void k_strip_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out, int accum) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
-        double a = part[r];
+        double a = accum ? out[r] + part[r] : part[r];
         for (int s = 1; s < S; ++s) a += part[(i64)s * nrow + r];
         out[r] = a;
     }
+}
+
+__global__ void k_dict_pow(int D, const double *__restrict__ dict, double p, double *__restrict__ out) {
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < D; q += gridDim.x * blockDim.x) out[q] = abs_pow(dict[q], p) * 1.0;
 }
 
 // ---- host side ------------------------------------------------------------------
@@ -1034,28 +1058,32 @@ static bool nt_loads() {  // SLP_NT_LOADS=0 / 1: plain / non-temporal entry load
     return v != 0;
 }
 
-static void wide_launch(const StripJds &f, int nv, const double *x0, const double *x1, double *o0, double *o1) {
+static void wide_launch(const StripJds &f, int nv, const double *x0, const double *x1, double *o0, double *o1, int accum) {
     const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
     hipStream_t st = ctx().stream;
     const unsigned int *ent = reinterpret_cast<const unsigned int *>(f.ent.p), *col = reinterpret_cast<const unsigned int *>(f.col.p);
 #define SLP_WIDE(DICT)                                                                                                          \
     hipLaunchKernelGGL((k_wstrip_spmv<DICT>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, ent, \
-                       f.val.p, col, f.dict, f.D, x0, x1, o0, o1)
+                       f.val.p, col, f.dict, f.D, x0, x1, o0, o1, accum)
     (void)nv;
     if (f.D > 0) SLP_WIDE(true);
     else SLP_WIDE(false);
 #undef SLP_WIDE
 }
 
-void strip_spmv(const StripJds &f, const double *x, double *out) {
+static void strip_combine(const StripJds &f, const double *part, double *out, int accum) {
+    hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, part, out, accum);
+}
+
+// One copy (not a composite).  accum: the sums continue from what `out` holds (see k_strip_spmv).
+static void strip_spmv_one(const StripJds &f, const double *x, double *out, int accum) {
     if (f.tall) {
-        tall_spmv(f, x, out);
+        tall_spmv(f, x, out, accum);
         return;
     }
     if (f.wide) {
-        wide_launch(f, 1, x, x, f.S > 1 ? f.part.p : out, nullptr);
-        if (f.S > 1)
-            hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
+        wide_launch(f, 1, x, x, f.S > 1 ? f.part.p : out, nullptr, accum);
+        if (f.S > 1) strip_combine(f, f.part.p, out, accum);
         SLP_HIP(hipGetLastError());
         return;
     }
@@ -1065,7 +1093,7 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
             const int ab = atoi(getenv("SLP_QSTRIP_ABLATE"));
 #define SLP_QABL(A)                                                                                                              \
     hipLaunchKernelGGL((k_qstrip_spmv<1, false, A>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, \
-                       f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out, (double *)nullptr)
+                       f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out, (double *)nullptr, accum)
             if (ab == 1) SLP_QABL(1);
             else if (ab == 2) SLP_QABL(2);
             else SLP_QABL(3);
@@ -1075,27 +1103,26 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
         if (f.rpl == 4 && nt_quads())
             hipLaunchKernelGGL((k_qstrip_spmv<1, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
                                f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                               (double *)nullptr);
+                               (double *)nullptr, accum);
         else if (f.rpl == 4)
             hipLaunchKernelGGL((k_qstrip_spmv<1, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
                                f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                               (double *)nullptr);
+                               (double *)nullptr, accum);
         else if (nt_level() == 1)  // 8-byte non-temporal loads measured SLOWER than plain ones (2.33 vs 2.23 ms): explicit only
             hipLaunchKernelGGL((k_dstrip_spmv<1, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
                                f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                               (double *)nullptr);
+                               (double *)nullptr, accum);
         else
             hipLaunchKernelGGL((k_dstrip_spmv<1, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
                                f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                               (double *)nullptr);
-        if (f.S > 1)
-            hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
+                               (double *)nullptr, accum);
+        if (f.S > 1) strip_combine(f, f.part.p, out, accum);
         SLP_HIP(hipGetLastError());
         return;
     }
 #define SLP_STRIP_LAUNCH(A)                                                                                                        \
     hipLaunchKernelGGL((k_strip_spmv<A, NTF>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, \
-                       f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, 0.0)
+                       f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, 0.0, accum)
     const bool nt = nt_loads();
 #ifdef SLP_ABLATION  // `make ablation` (tools/ablate_strip.py) only: the ablated kernels return WRONG sums; not in libslp_hip.so
     const char *e = getenv("SLP_STRIP_ABLATE");
@@ -1107,34 +1134,51 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
 #endif
     if (nt && nt_level() == 2)
         hipLaunchKernelGGL((k_strip_spmv<0, true, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                           f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, 0.0);
+                           f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, 0.0, accum);
     else if (nt) { constexpr bool NTF = true; SLP_STRIP_LAUNCH(0); }
     else { constexpr bool NTF = false; SLP_STRIP_LAUNCH(0); }
 #undef SLP_STRIP_LAUNCH
-    if (f.S > 1)
-        hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
+    if (f.S > 1) strip_combine(f, f.part.p, out, accum);
+    SLP_HIP(hipGetLastError());
+}
+
+// Composite copies (a chunked matrix, slp_chunked.hip): the row chunks' copies one after the other.  Rows orientation: chunk k
+// writes its own rows of `out`.  Columns orientation (the copy of A^T: chunk k holds columns part_off[k].. of it): chunk k reads
+// its slice of x and CONTINUES the sums chunk k - 1 left in `out` -- every sum is the single chain of the unchunked product.
+template <class F>
+static void for_parts(const StripJds &f, F call) {
+    for (size_t k = 0; k < f.parts.size(); ++k) call(*f.parts[k], f.parts_cols ? f.part_off[k] : 0, f.parts_cols ? 0 : f.part_off[k],
+                                                     (f.parts_cols && k > 0) ? 1 : 0);
+}
+
+void strip_spmv(const StripJds &f, const double *x, double *out) {
+    if (f.parts.empty()) { strip_spmv_one(f, x, out, 0); return; }
+    for_parts(f, [&](const StripJds &g, i64 xo, i64 oo, int accum) { strip_spmv_one(g, x + xo, out + oo, accum); });
+}
+
+static void strip_spmv_pow_one(const StripJds &f, double pw, const double *x, double *out, int accum) {
+    SLP_REQUIRE(f.ok && !f.wide && !f.tall && f.D == 0, "strip_spmv_pow: not an fp64 strip copy");
+    hipLaunchKernelGGL((k_strip_spmv<0, true, false, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
+                       f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, pw, accum);
+    if (f.S > 1) strip_combine(f, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());
 }
 
 // y = |A|^pw x over the fp64 strip copy: every row the same chain of additions as the CSR walk with |v|^pw * 1.0 terms.
 void strip_spmv_pow(const StripJds &f, double pw, const double *x, double *out) {
-    SLP_REQUIRE(f.ok && !f.wide && !f.tall && f.D == 0, "strip_spmv_pow: not an fp64 strip copy");
-    hipLaunchKernelGGL((k_strip_spmv<0, true, false, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                       f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, pw);
-    if (f.S > 1)
-        hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
-    SLP_HIP(hipGetLastError());
+    if (f.parts.empty()) { strip_spmv_pow_one(f, pw, x, out, 0); return; }
+    for_parts(f, [&](const StripJds &g, i64 xo, i64 oo, int accum) { strip_spmv_pow_one(g, pw, x + xo, out + oo, accum); });
 }
 
 // The same product with another value table behind the same ids: the copy of the matrix whose stored values are
 // table[id] instead of dict[id] (e.g. |value|^p for the Chambolle-Pock preconditioners) -- valid for dictionary copies.
-void strip_spmv_with_dict(const StripJds &f, const double *table, const double *x, double *out) {
+static void strip_spmv_with_dict_one(const StripJds &f, const double *table, const double *x, double *out, int accum) {
     SLP_REQUIRE(f.D > 0 && table, "strip_spmv_with_dict: the copy has no value dictionary");
     StripJds &g = const_cast<StripJds &>(f);
     const double *saved = g.dict;
     g.dict = table;  // (kernel arguments are taken at launch; the launch order on the stream does the rest)
     try {
-        strip_spmv(f, x, out);
+        strip_spmv_one(f, x, out, accum);
     } catch (...) {
         g.dict = saved;
         throw;
@@ -1142,11 +1186,43 @@ void strip_spmv_with_dict(const StripJds &f, const double *table, const double *
     g.dict = saved;
 }
 
-void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1) {
+void strip_spmv_with_dict(const StripJds &f, const double *table, const double *x, double *out) {
+    SLP_REQUIRE(f.parts.empty(), "strip_spmv_with_dict: composite copies carry one dictionary per chunk (use strip_spmv_abs_pow)");
+    strip_spmv_with_dict_one(f, table, x, out, 0);
+}
+
+// Can strip_spmv_abs_pow run on this copy?  Dictionary copies of every kind, and fp64 LDS strips.
+bool strip_abs_pow_supported(const StripJds &f) {
+    if (!f.parts.empty()) {
+        for (const StripJds *g : f.parts)
+            if (!strip_abs_pow_supported(*g)) return false;
+        return true;
+    }
+    return f.ok && (f.D > 0 || (!f.wide && !f.tall));
+}
+
+// out = |A|^pw x: every stored value v enters as |v|^pw * 1.0 (the sums behind the Chambolle-Pock preconditioners,
+// ChambollePockPPD.py:134,144,161,172) -- dictionary copies through a |v|^pw table, fp64 LDS strips on the fly; the
+// same chain of additions per row as the CSR walk.
+void strip_spmv_abs_pow(const StripJds &f, double pw, const double *x, double *out) {
+    auto one = [&](const StripJds &g, const double *gx, double *gout, int accum) {
+        if (g.D > 0) {
+            DevBuf<double> table((size_t)g.D);  // (stream-ordered release: the launch below is enqueued before the block is reused)
+            hipLaunchKernelGGL(k_dict_pow, dim3(8), dim3(kBlock), 0, ctx().stream, g.D, g.dict, pw, table.p);
+            strip_spmv_with_dict_one(g, table.p, gx, gout, accum);
+        } else {
+            strip_spmv_pow_one(g, pw, gx, gout, accum);
+        }
+    };
+    if (f.parts.empty()) { one(f, x, out, 0); return; }
+    for_parts(f, [&](const StripJds &g, i64 xo, i64 oo, int accum) { one(g, x + xo, out + oo, accum); });
+}
+
+static void strip_spmv2_one(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1, int accum) {
     if (f.wide || f.tall) {
         // two strips of x would compete for the L2: two passes
-        strip_spmv(f, x0, out0);
-        strip_spmv(f, x1, out1);
+        strip_spmv_one(f, x0, out0, accum);
+        strip_spmv_one(f, x1, out1, accum);
         return;
     }
     hipStream_t st = ctx().stream;
@@ -1158,18 +1234,35 @@ void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *
     }
     if (f.D > 0 && f.rpl == 4)
         hipLaunchKernelGGL((k_qstrip_spmv<2>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
-                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1);
+                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1, accum);
     else if (f.D > 0)
         hipLaunchKernelGGL((k_dstrip_spmv<2, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
-                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1);
+                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1, accum);
     else
         hipLaunchKernelGGL(k_strip_spmv2, dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
-                           f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x0, x1, o0, o1);
+                           f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x0, x1, o0, o1, accum);
     if (f.S > 1) {
-        hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, st, f.nrow, f.S, o0, out0);
-        hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, st, f.nrow, f.S, o1, out1);
+        strip_combine(f, o0, out0, accum);
+        strip_combine(f, o1, out1, accum);
     }
     SLP_HIP(hipGetLastError());
+}
+
+void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1) {
+    if (f.parts.empty()) { strip_spmv2_one(f, x0, x1, out0, out1, 0); return; }
+    for_parts(f, [&](const StripJds &g, i64 xo, i64 oo, int accum) { strip_spmv2_one(g, x0 + xo, x1 + xo, out0 + oo, out1 + oo, accum); });
+}
+
+size_t strip_format_bytes(const StripJds &f) {
+    if (!f.parts.empty()) {
+        size_t b = 0;
+        for (const StripJds *g : f.parts) b += strip_format_bytes(*g);
+        return b;
+    }
+    if (f.tall) return f.tall_bytes;
+    const size_t entries = f.D > 0 ? f.ent.n * sizeof(unsigned short) + (size_t)f.D * sizeof(double)
+                                   : f.val.n * sizeof(double) + f.col.n * sizeof(unsigned short);
+    return entries + f.perm.n * sizeof(unsigned short) + f.slen.n + f.soff.n * sizeof(unsigned int) + f.base.n * sizeof(i64);
 }
 
 // Does the format pay?  Long rows (the gather-bound regime) and enough entries per (row, strip) to amortise

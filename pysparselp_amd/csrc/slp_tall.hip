@@ -70,38 +70,85 @@ __host__ __device__ inline unsigned long long tall_value_key(unsigned long long 
     return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
 }
 
-// ---- build, step 1: one 64-bit key per stored entry, in CSR order ---------------------------------------------------
-// key = cell (row block * T + strip) << 37 | local row << 23 | column inside the strip << 11 | value id.
-// A stable sort by the cell bits alone then leaves every cell's entries in (row, storage) order.
-__global__ __launch_bounds__(kBlock) void k_tall_keys(i64 nrow, int R, i64 T, int D, const unsigned long long *__restrict__ dkeys,
+// ---- build, step 1: one 64-bit key per stored entry of the pass, in CSR order ------------------------------------------
+// The copy is built in PASSES over ranges of its row blocks, so that the temporaries (keys, sorted keys, sort scratch) are a
+// fraction of the matrix (SLP_TALL_PASS_NNZ entries per pass).  TR = false: the copy of A -- a pass is a range of rows of the
+// CSR, its entries are contiguous.  TR = true: the copy of A^T taken STRAIGHT from the CSR of A (no transposed CSR is formed):
+// row of the copy = column of A, column of the copy = row of A; a pass is a range [c0, c1) of A's columns, and because the
+// rows of A are sorted by column its entries are one segment per row (k_tall_range), written at the scanned offsets `opos`.
+//   key = cell ((row block - b0) * T + strip) << 37 | local row << 23 | column inside the strip << 11 | value id.
+// TR = false: a stable sort by the cell bits leaves every cell's entries in (row, storage) order.  TR = true: the keys come in
+// A's order (rows of A = columns of the copy, increasing), so a stable sort by (cell, local row) leaves the entries of a row
+// of the copy in increasing column = the storage order of A^T as a stable transposition builds it (csc_matvec's order).
+__global__ void k_tall_range(i64 nrow, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, i64 c0, i64 c1,
+                             i64 *__restrict__ lo, i64 *__restrict__ len) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
+        const i64 s = ptr[r], e = ptr[r + 1];
+        auto lower = [&](i64 c) {
+            i64 a = s, b = e;
+            while (a < b) {
+                const i64 mid = (a + b) >> 1;
+                if ((i64)idx[mid] < c) a = mid + 1;
+                else b = mid;
+            }
+            return a;
+        };
+        const i64 l = lower(c0), h = lower(c1);
+        lo[r] = l;
+        len[r] = h - l;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) len[nrow] = 0;
+}
+
+// rows strictly increasing in column?  (the binary searches of k_tall_range rely on it)
+__global__ __launch_bounds__(kBlock) void k_tall_sorted(i64 nnz, const i32 *__restrict__ idx, i64 nrow, const i64 *__restrict__ ptr,
+                                                        int *__restrict__ bad) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const i64 wave = ((i64)blockIdx.x * kBlock + threadIdx.x) / kWave, nwaves = (i64)gridDim.x * kBlock / kWave;
+    for (i64 r = wave; r < nrow; r += nwaves) {
+        const i64 s = ptr[r], e = ptr[r + 1];
+        for (i64 k = s + 1 + lane; k < e; k += kWave)
+            if (idx[k - 1] >= idx[k]) atomicOr(bad, 1);
+    }
+    (void)nnz;
+}
+
+template <bool TR>
+__global__ __launch_bounds__(kBlock) void k_tall_keys(i64 r0, i64 nrow, int R, i64 T, i64 b0, int D, const unsigned long long *__restrict__ dkeys,
                                                       const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
-                                                      const double *__restrict__ val, unsigned long long *__restrict__ keys,
-                                                      int *__restrict__ bad) {
+                                                      const double *__restrict__ val, const i64 *__restrict__ lo,
+                                                      const i64 *__restrict__ opos, i64 obase, unsigned long long *__restrict__ keys,
+                                                      double *__restrict__ kvals, int *__restrict__ bad) {
     __shared__ unsigned long long skey[kTallDictMax];
     for (int q = threadIdx.x; q < D; q += kBlock) skey[q] = dkeys[q];
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
     const i64 wave = ((i64)blockIdx.x * kBlock + threadIdx.x) / kWave, nwaves = (i64)gridDim.x * kBlock / kWave;
-    for (i64 r = wave; r < nrow; r += nwaves) {
-        const i64 s = ptr[r], e = ptr[r + 1];
-        const unsigned long long b = (unsigned long long)(r / R), rl = (unsigned long long)(r % R);
+    for (i64 rr = wave; rr < nrow; rr += nwaves) {
+        const i64 r = r0 + rr;                                   // row of the CSR
+        const i64 s = TR ? lo[rr] : ptr[r];
+        const i64 e = TR ? s + (opos[rr + 1] - opos[rr]) : ptr[r + 1];
+        const i64 o = TR ? opos[rr] : s - obase;                 // where the row's keys go
         for (i64 k = s + lane; k < e; k += kWave) {
             const i32 j = idx[k];
-            if (k > s && idx[k - 1] >= j) atomicOr(bad, 1);  // rows must be strictly increasing in column
-            int lo = 0;
+            if (!TR && k > s && idx[k - 1] >= j) atomicOr(bad, 1);  // rows must be strictly increasing in column
+            int id = 0;
             if (D > 0) {  // (D == 0: fp64 entries, the value travels beside the key)
                 const unsigned long long key = tall_value_key((unsigned long long)__double_as_longlong(val[k]));
                 int hi = D - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (skey[mid] < key) lo = mid + 1;
+                while (id < hi) {
+                    const int mid = (id + hi) >> 1;
+                    if (skey[mid] < key) id = mid + 1;
                     else hi = mid;
                 }
-                if (skey[lo] != key) atomicOr(bad, 2);
+                if (skey[id] != key) atomicOr(bad, 2);
             }
-            const unsigned long long t = (unsigned long long)(j / kTallC), cl = (unsigned long long)(j % kTallC);
-            keys[k] = ((b * (unsigned long long)T + t) << kTallCellShift) | (rl << (kTallIdBits + kTallColBits)) | (cl << kTallIdBits) |
-                      (unsigned long long)lo;
+            const i64 trow = TR ? (i64)j : r, tcol = TR ? r : (i64)j;  // row / column of the copy
+            const unsigned long long b = (unsigned long long)(trow / R - b0), rl = (unsigned long long)(trow % R);
+            const unsigned long long t = (unsigned long long)(tcol / kTallC), cl = (unsigned long long)(tcol % kTallC);
+            keys[o + (k - s)] = ((b * (unsigned long long)T + t) << kTallCellShift) | (rl << (kTallIdBits + kTallColBits)) | (cl << kTallIdBits) |
+                                (unsigned long long)id;
+            if (kvals) kvals[o + (k - s)] = val[k];
         }
     }
 }
@@ -440,11 +487,9 @@ struct TallRegs {
 
 // DICT: depth 4 (20 KB of payload per packet); fp64 entries: depth 2 (48 KB per packet, 16 more registers per packet)
 template <bool DICT>
-__global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, int S, const i64 *__restrict__ pkt_ptr,
-                                                      const i64 *__restrict__ blk_base, const unsigned int *__restrict__ dirw,
-                                                      const unsigned int *__restrict__ payload, const double *__restrict__ pvals,
+__global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, int S, const TallWg *__restrict__ wgs,
                                                       const double *__restrict__ dict, int D, const double *__restrict__ x,
-                                                      double *__restrict__ out) {
+                                                      double *__restrict__ out, int accum) {
     constexpr int kDepth = DICT ? kTallDepth : 2;
     __shared__ double acc[kTallRmax];
     __shared__ double dv[kTallDictMax];
@@ -452,18 +497,21 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     const int p = threadIdx.x;
     const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
     const i64 v = blockIdx.x, b = v / S;  // workgroup v walks the strips of range v % S of row block b
-    for (int r = p; r < R; r += kTallT) acc[r] = 0.0;
+    // accum (S == 1): the sums continue from what `out` holds -- a row chunk of a chunked matrix carrying on the column sums of
+    // the chunks before it, the chain of additions of the unchunked product (S > 1: taken in k_tall_combine)
+    for (int r = p; r < R; r += kTallT) acc[r] = (accum && S == 1 && b * (i64)R + r < nrow) ? out[b * (i64)R + r] : 0.0;
     if (DICT)
         for (int q = p; q < D; q += kTallT) dv[q] = dict[q];
-    const unsigned int *__restrict__ hd = dirw + pkt_ptr[v] * 8 + (p & 7);  // this lane's dword of every header
-    const int npk = (int)(pkt_ptr[v + 1] - pkt_ptr[v]) - 2 * kTallDepth;      // the last 2 x depth packets are prefetch targets only
+    const TallWg wg = wgs[v];
+    const unsigned int *__restrict__ hd = wg.dir + (p & 7);                   // this lane's dword of every header
+    const int npk = (int)wg.npk - 2 * kTallDepth;                             // the last 2 x depth packets are prefetch targets only
     // buffer descriptors: lanes without work address past num_records (the load returns 0 without a memory request)
     const __amdgpu_buffer_rsrc_t rs_pay =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(payload + blk_base[v]), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(wg.pay), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)(ncol * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : pvals + blk_base[v]), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : wg.val), 0, 0x7fffffff, 0x00020000);
     int cur = 0;
 
     TallRegs<DICT> regs[kDepth];
@@ -499,10 +547,12 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
             so += c[0] * 4u;
             g.hi[DICT ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4] ? mine : kOob, so, 2);
         }
-        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 4u * (unsigned int)p) * 8u;  // columns past ncol read 0
+        // columns past ncol read 0: the displacement of each double is part of the voffset, which the descriptor's range check
+        // covers (an soffset is not checked on gfx9 raw buffers)
+        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 4u * (unsigned int)p) * 8u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo, 8 * i, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)i, 0, 0);
             g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
         }
     };
@@ -609,125 +659,204 @@ static void tall_geometry(i64 nrow, i64 T, int *R_out, int *S_out) {
     *R_out = (int)std::min<i64>(R, kTallRmax);
 }
 
-bool tall_build(const CsrDev &a, StripJds &f, const ValueDict *dict) {
-    Phase ph("tall_build");
+// Entries per build pass (SLP_TALL_PASS_NNZ): the temporaries of a pass are ~ 24 bytes per entry (keys, sorted keys, sort
+// scratch; 40 with fp64 entries), so a pass of 5e8 entries needs ~ 12 GB whatever the size of the matrix.
+static i64 tall_pass_nnz() {
+    const char *e = getenv("SLP_TALL_PASS_NNZ");
+    const i64 v = e ? atoll(e) : 500000000ll;
+    return v > 0 ? v : 500000000ll;
+}
+
+template <bool DICT>
+static void tall_launch_build(bool write, unsigned V, int R, i64 T, int S, i64 ncol, const unsigned long long *sorted, const double *svals,
+                              const i64 *cellptr, i64 *sizes, const i64 *base, const i64 *pkt, TallPkt *dir, unsigned int *pay, double *vals) {
+    hipStream_t st = ctx().stream;
+    if (write)
+        hipLaunchKernelGGL((k_tall_build<true, DICT>), dim3(V), dim3(kTallT), 0, st, R, T, S, ncol, sorted, svals, cellptr, sizes, base, pkt, dir,
+                           pay, vals);
+    else
+        hipLaunchKernelGGL((k_tall_build<false, DICT>), dim3(V), dim3(kTallT), 0, st, R, T, S, ncol, sorted, svals, cellptr, sizes, base, pkt, dir,
+                           pay, vals);
+    SLP_HIP(hipGetLastError());
+}
+
+// The tall-cell copy of `a` (transposed: of a^T) straight from the CSR of `a`, in passes over ranges of the copy's row blocks.
+bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict) {
+    Phase ph(transposed ? "tall_build (A^T from the CSR of A)" : "tall_build");
     hipStream_t st = ctx().stream;
     f = StripJds();
-    if ((dict && (dict->D <= 0 || dict->D > kTallDictMax)) || a.nrow == 0 || a.nnz == 0) return false;
-    if (a.ncol * 8 >= ((i64)1 << 31)) return false;  // x is addressed through a buffer descriptor with 32-bit byte offsets
-    const i64 T = (a.ncol + kTallC - 1) / kTallC;
+    if ((dict && (dict->D <= 0 || dict->D > kTallDictMax)) || a.nrow == 0 || a.ncol == 0 || a.nnz == 0) return false;
+    const i64 nrowF = transposed ? a.ncol : a.nrow, ncolF = transposed ? a.nrow : a.ncol;
+    if (ncolF * 8 >= ((i64)1 << 31)) return false;  // x is addressed through a buffer descriptor with 32-bit byte offsets
+    const i64 T = (ncolF + kTallC - 1) / kTallC;
     int R = 0, S = 1;
-    tall_geometry(a.nrow, T, &R, &S);
-    const i64 B = (a.nrow + R - 1) / R, ncell = B * T, V = B * S;  // V workgroups: (row block, strip range)
-    unsigned int cellbits = 1;
-    while (((i64)1 << cellbits) < ncell) ++cellbits;
-    if (kTallCellShift + cellbits > 64) return false;
-    DevBuf<i64> cellptr((size_t)ncell + 1);
-    DevBuf<unsigned long long> sorted((size_t)a.nnz);
-    DevBuf<double> svals;  // fp64 entries: the values in the sorted order
+    tall_geometry(nrowF, T, &R, &S);
+    const i64 B = (nrowF + R - 1) / R, V = B * S;  // V workgroups: (row block, strip range)
+    i64 P = (a.nnz + tall_pass_nnz() - 1) / tall_pass_nnz();
+    P = std::max<i64>(1, std::min<i64>(P, B));
     {
-        Phase p1("  tall: keys + sort");
-        DevBuf<unsigned long long> keys((size_t)a.nnz);
-        DevBuf<int> bad(1);
-        bad.zero();
-        hipLaunchKernelGGL(k_tall_keys, dim3(grid_for(a.nrow * kWave, kBlock)), dim3(kBlock), 0, st, a.nrow, R, T, dict ? dict->D : 0,
-                           dict ? dict->keys.p : (const unsigned long long *)nullptr, a.ptr.p, a.idx.p, a.val.p, keys.p, bad.p);
+        unsigned int cellbits = 1;
+        while (((i64)1 << cellbits) < ((B + P - 1) / P) * T) ++cellbits;
+        if (kTallCellShift + cellbits > 64) return false;
+    }
+    DevBuf<int> bad(1);
+    bad.zero();
+    if (transposed) {  // the per-row column ranges of the passes are binary searches: the rows must be sorted
+        hipLaunchKernelGGL(k_tall_sorted, dim3(grid_for(a.nrow * kWave, kBlock)), dim3(kBlock), 0, st, a.nnz, a.idx.p, a.nrow, a.ptr.p, bad.p);
         SLP_HIP(hipGetLastError());
         int hbad = 0;
         bad.download(&hbad, 1);
-        if (hbad) return false;  // unsorted rows (or a value outside the dictionary)
-        size_t bytes = 0;
-        const unsigned b0 = (unsigned)kTallCellShift, b1 = (unsigned)kTallCellShift + cellbits;
-        if (dict) {
-            SLP_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys.p, sorted.p, (size_t)a.nnz, b0, b1, st));
-            DevBuf<char> tmp(bytes);
-            SLP_HIP(rocprim::radix_sort_keys(tmp.p, bytes, keys.p, sorted.p, (size_t)a.nnz, b0, b1, st));
+        if (hbad) return false;
+    }
+    std::vector<TallWg> wg((size_t)V);
+    const i64 limit = dict ? ((i64)1 << 28) : ((i64)1 << 27);  // payload words of one workgroup (32-bit byte offsets; fp64: 2 x)
+    DevBuf<i64> lo, len, opos;
+    if (transposed) { lo.alloc((size_t)a.nrow); len.alloc((size_t)a.nrow + 1); opos.alloc((size_t)a.nrow + 1); }
+    for (i64 pass = 0; pass < P; ++pass) {
+        const i64 bb0 = B * pass / P, bb1 = B * (pass + 1) / P, nb = bb1 - bb0;
+        if (nb == 0) continue;
+        const i64 ncell = nb * T, Vp = nb * S;
+        const i64 f0 = bb0 * (i64)R, f1 = std::min<i64>(bb1 * (i64)R, nrowF);  // rows of the copy in this pass
+        // entries of the pass and where each row's keys go
+        i64 n_p = 0, obase = 0;
+        if (!transposed) {
+            i64 ends[2];
+            SLP_HIP(hipMemcpyAsync(&ends[0], a.ptr.p + f0, sizeof(i64), hipMemcpyDeviceToHost, st));
+            SLP_HIP(hipMemcpyAsync(&ends[1], a.ptr.p + f1, sizeof(i64), hipMemcpyDeviceToHost, st));
             SLP_HIP(hipStreamSynchronize(st));
+            obase = ends[0];
+            n_p = ends[1] - ends[0];
         } else {
-            svals.alloc((size_t)a.nnz);
-            SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, sorted.p, a.val.p, svals.p, (size_t)a.nnz, b0, b1, st));
+            hipLaunchKernelGGL(k_tall_range, dim3(grid_for(a.nrow, kBlock)), dim3(kBlock), 0, st, a.nrow, a.ptr.p, a.idx.p, f0, f1, lo.p, len.p);
+            SLP_HIP(hipGetLastError());
+            size_t bytes = 0;
+            SLP_HIP(rocprim::exclusive_scan(nullptr, bytes, len.p, opos.p, (i64)0, (size_t)a.nrow + 1, rocprim::plus<i64>(), st));
             DevBuf<char> tmp(bytes);
-            SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.p, sorted.p, a.val.p, svals.p, (size_t)a.nnz, b0, b1, st));
+            SLP_HIP(rocprim::exclusive_scan(tmp.p, bytes, len.p, opos.p, (i64)0, (size_t)a.nrow + 1, rocprim::plus<i64>(), st));
+            SLP_HIP(hipMemcpyAsync(&n_p, opos.p + a.nrow, sizeof(i64), hipMemcpyDeviceToHost, st));
             SLP_HIP(hipStreamSynchronize(st));
         }
+        DevBuf<i64> cellptr((size_t)ncell + 1);
+        DevBuf<unsigned long long> sorted((size_t)std::max<i64>(n_p, 1));
+        DevBuf<double> svals;  // fp64 entries: the values in the sorted order
+        if (n_p > 0) {
+            Phase p1("  tall: keys + sort");
+            DevBuf<unsigned long long> keys((size_t)n_p);
+            DevBuf<double> kvals;
+            if (!dict && transposed) kvals.alloc((size_t)n_p);
+            const i64 scan_rows = transposed ? a.nrow : f1 - f0, r0 = transposed ? 0 : f0;
+            const int D = dict ? dict->D : 0;
+            const unsigned long long *dk = dict ? dict->keys.p : (const unsigned long long *)nullptr;
+            if (transposed)
+                hipLaunchKernelGGL((k_tall_keys<true>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, bb0, D, dk,
+                                   a.ptr.p, a.idx.p, a.val.p, lo.p, opos.p, obase, keys.p, kvals.p, bad.p);
+            else
+                hipLaunchKernelGGL((k_tall_keys<false>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, bb0, D, dk,
+                                   a.ptr.p, a.idx.p, a.val.p, (const i64 *)nullptr, (const i64 *)nullptr, obase, keys.p, (double *)nullptr, bad.p);
+            SLP_HIP(hipGetLastError());
+            int hbad = 0;
+            bad.download(&hbad, 1);
+            if (hbad) { f = StripJds(); return false; }  // unsorted rows (or a value outside the dictionary)
+            unsigned int cellbits = 1;
+            while (((i64)1 << cellbits) < ncell) ++cellbits;
+            size_t bytes = 0;
+            // TR: by (cell, local row) -- see k_tall_keys
+            const unsigned b0 = transposed ? (unsigned)(kTallIdBits + kTallColBits) : (unsigned)kTallCellShift, b1 = (unsigned)kTallCellShift + cellbits;
+            if (dict) {
+                SLP_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys.p, sorted.p, (size_t)n_p, b0, b1, st));
+                DevBuf<char> tmp(bytes);
+                SLP_HIP(rocprim::radix_sort_keys(tmp.p, bytes, keys.p, sorted.p, (size_t)n_p, b0, b1, st));
+                SLP_HIP(hipStreamSynchronize(st));
+            } else {
+                svals.alloc((size_t)n_p);
+                const double *vin = transposed ? kvals.p : a.val.p + obase;
+                SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, sorted.p, vin, svals.p, (size_t)n_p, b0, b1, st));
+                DevBuf<char> tmp(bytes);
+                SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.p, sorted.p, vin, svals.p, (size_t)n_p, b0, b1, st));
+                SLP_HIP(hipStreamSynchronize(st));
+            }
+            hipLaunchKernelGGL(k_tall_cellptr, dim3(grid_for(n_p, kBlock)), dim3(kBlock), 0, st, n_p, ncell, sorted.p, cellptr.p);
+            SLP_HIP(hipGetLastError());
+        } else {
+            cellptr.zero();  // no entries in these row blocks: every cell is empty
+        }
+        Phase p2("  tall: packets (sizes + fill)");
+        DevBuf<i64> sizes(2 * (size_t)Vp);
+        if (dict) tall_launch_build<true>(false, (unsigned)Vp, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, sizes.p, nullptr, nullptr, nullptr, nullptr, nullptr);
+        else tall_launch_build<false>(false, (unsigned)Vp, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, sizes.p, nullptr, nullptr, nullptr, nullptr, nullptr);
+        std::vector<i64> hs(2 * (size_t)Vp), hbase((size_t)Vp + 1), hpkt((size_t)Vp + 1);
+        sizes.download(hs.data(), hs.size());
+        hbase[0] = hpkt[0] = 0;
+        for (i64 v = 0; v < Vp; ++v) {
+            if (hs[2 * v] >= limit) { f = StripJds(); return false; }  // a workgroup's payload outgrows its 32-bit byte offsets: another format
+            hbase[v + 1] = hbase[v] + ((hs[2 * v] + 3) & ~(i64)3);  // 16-byte aligned streams
+            hpkt[v + 1] = hpkt[v] + hs[2 * v + 1];
+        }
+        DevBuf<i64> dbase, dpkt;
+        dbase.upload(hbase.data(), hbase.size());
+        dpkt.upload(hpkt.data(), hpkt.size());
+        f.tall_dir.emplace_back((size_t)hpkt[Vp] * 8);
+        f.tall_pay.emplace_back((size_t)hbase[Vp] + 64);
+        DevBuf<unsigned int> &dir = f.tall_dir.back(), &pay = f.tall_pay.back();
+        double *vals = nullptr;
+        if (!dict) { f.tall_val.emplace_back((size_t)hbase[Vp] + 64); vals = f.tall_val.back().p; }
+        f.tall_bytes += (dir.n + pay.n) * sizeof(unsigned int) + (vals ? (pay.n * sizeof(double)) : 0);
+        if (dict) tall_launch_build<true>(true, (unsigned)Vp, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, nullptr, dbase.p, dpkt.p,
+                                          reinterpret_cast<TallPkt *>(dir.p), pay.p, nullptr);
+        else tall_launch_build<false>(true, (unsigned)Vp, R, T, S, ncolF, sorted.p, svals.p, cellptr.p, nullptr, dbase.p, dpkt.p,
+                                      reinterpret_cast<TallPkt *>(dir.p), pay.p, vals);
+        for (i64 v = 0; v < Vp; ++v) {
+            TallWg &w = wg[(size_t)(bb0 * S + v)];
+            w.dir = dir.p + hpkt[v] * 8;
+            w.pay = pay.p + hbase[v];
+            w.val = vals ? vals + hbase[v] : nullptr;
+            w.npk = hpkt[v + 1] - hpkt[v];
+        }
+        SLP_HIP(hipStreamSynchronize(st));  // the pass's temporaries go back to the allocator
     }
-    hipLaunchKernelGGL(k_tall_cellptr, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, ncell, sorted.p, cellptr.p);
-    SLP_HIP(hipGetLastError());
-    DevBuf<i64> sizes(2 * (size_t)V);
-    Phase p2("  tall: packets (sizes + fill)");
-    if (dict)
-        hipLaunchKernelGGL((k_tall_build<false, true>), dim3((unsigned)V), dim3(kTallT), 0, st, R, T, S, a.ncol, sorted.p, (const double *)nullptr,
-                           cellptr.p, sizes.p, (const i64 *)nullptr, (const i64 *)nullptr, (TallPkt *)nullptr, (unsigned int *)nullptr,
-                           (double *)nullptr);
-    else
-        hipLaunchKernelGGL((k_tall_build<false, false>), dim3((unsigned)V), dim3(kTallT), 0, st, R, T, S, a.ncol, sorted.p, (const double *)nullptr,
-                           cellptr.p, sizes.p, (const i64 *)nullptr, (const i64 *)nullptr, (TallPkt *)nullptr, (unsigned int *)nullptr,
-                           (double *)nullptr);
-    SLP_HIP(hipGetLastError());
-    std::vector<i64> hs(2 * (size_t)V), hbase((size_t)V + 1), hpkt((size_t)V + 1);
-    sizes.download(hs.data(), hs.size());
-    hbase[0] = hpkt[0] = 0;
-    for (i64 b = 0; b < V; ++b) {
-        SLP_REQUIRE(hs[2 * b] < ((i64)1 << 28), "tall cells: a row block's payload exceeds 2 GB");
-        hbase[b + 1] = hbase[b] + ((hs[2 * b] + 3) & ~(i64)3);  // 16-byte aligned row blocks
-        hpkt[b + 1] = hpkt[b] + hs[2 * b + 1];
-    }
-    f.tall_base.upload(hbase.data(), hbase.size());
-    f.tall_pkt.upload(hpkt.data(), hpkt.size());
-    f.tall_dir.alloc((size_t)hpkt[V] * 8);
-    f.tall_pay.alloc((size_t)hbase[V] + 64);
-    if (dict) {
-        hipLaunchKernelGGL((k_tall_build<true, true>), dim3((unsigned)V), dim3(kTallT), 0, st, R, T, S, a.ncol, sorted.p, (const double *)nullptr,
-                           cellptr.p, (i64 *)nullptr, f.tall_base.p, f.tall_pkt.p, reinterpret_cast<TallPkt *>(f.tall_dir.p), f.tall_pay.p,
-                           (double *)nullptr);
-    } else {
-        f.val.alloc((size_t)hbase[V] + 64);
-        hipLaunchKernelGGL((k_tall_build<true, false>), dim3((unsigned)V), dim3(kTallT), 0, st, R, T, S, a.ncol, sorted.p, svals.p, cellptr.p,
-                           (i64 *)nullptr, f.tall_base.p, f.tall_pkt.p, reinterpret_cast<TallPkt *>(f.tall_dir.p), f.tall_pay.p, f.val.p);
-    }
-    SLP_HIP(hipGetLastError());
-    SLP_HIP(hipStreamSynchronize(st));
-    f.nrow = a.nrow; f.ncol = a.ncol; f.nnz = a.nnz; f.T = T; f.B = B; f.C = kTallC; f.rpl = 1;
+    f.tall_wg.upload(wg.data(), wg.size());
+    f.tall_bytes += wg.size() * sizeof(TallWg) + (dict ? (size_t)dict->D * sizeof(double) : 0);
+    f.nrow = nrowF; f.ncol = ncolF; f.nnz = a.nnz; f.T = T; f.B = B; f.C = kTallC; f.rpl = 1;
     f.D = dict ? dict->D : 0;
     f.dict = dict ? dict->values.p : nullptr;
     f.tall = true;
     f.tall_R = R;
     f.S = S;
-    if (S > 1) f.part.alloc((size_t)S * (size_t)a.nrow);
+    if (S > 1) f.part.alloc((size_t)S * (size_t)nrowF);
     f.ok = true;
     return true;
 }
 
-__global__ void k_tall_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out) {
+__global__ void k_tall_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out, int accum) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
-        double a = part[r];
+        double a = accum ? out[r] + part[r] : part[r];
         for (int s = 1; s < S; ++s) a += part[(i64)s * nrow + r];  // strip ranges in order: deterministic
         out[r] = a;
     }
 }
 
-void tall_spmv(const StripJds &f, const double *x, double *out) {
+void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
     double *dst = f.S > 1 ? f.part.p : out;
     const unsigned grid = (unsigned)(f.B * f.S);
     if (f.D > 0)
-        hipLaunchKernelGGL((k_tall_spmv<true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_pkt.p,
-                           f.tall_base.p, f.tall_dir.p, f.tall_pay.p, (const double *)nullptr, f.dict, f.D, x, dst);
+        hipLaunchKernelGGL((k_tall_spmv<true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_wg.p, f.dict, f.D,
+                           x, dst, accum);
     else
-        hipLaunchKernelGGL((k_tall_spmv<false>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_pkt.p,
-                           f.tall_base.p, f.tall_dir.p, f.tall_pay.p, f.val.p, (const double *)nullptr, 0, x, dst);
+        hipLaunchKernelGGL((k_tall_spmv<false>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_wg.p,
+                           (const double *)nullptr, 0, x, dst, accum);
     if (f.S > 1)
-        hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out);
+        hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());
 }
 
 // Long rows over a width far beyond an L2, too sparse for the LDS strips: 0.05 .. 2.5 entries per (row, 4096 columns).
-bool tall_wanted(const CsrDev &a) {
+bool tall_wanted(i64 nrow, i64 ncol, i64 nnz) {
     const char *e = getenv("SLP_TALL");
     if (e && e[0] == '0') return false;
     const char *m = getenv("SLP_STRIP_MIN_NNZ");
     const i64 min_nnz = m ? atoll(m) : 30000000ll;
-    if (a.nnz < min_nnz || a.nrow <= 0) return false;
-    const double per_cell = a.mean_row_len() / (double)((a.ncol + kTallC - 1) / kTallC);
+    if (nnz < min_nnz || nrow <= 0 || ncol <= 0) return false;
+    const double per_cell = ((double)nnz / (double)nrow) / (double)((ncol + kTallC - 1) / kTallC);
     return per_cell >= 0.05 && per_cell < 2.5;
 }
 

@@ -139,10 +139,41 @@ class DeviceMatrix:
         _lib.check(self._l.slp_matrix_bench_spmv(self._h, int(transposed), int(order), int(reps), _lib.ptr(ms)))
         return float(ms[0])
 
-    def random_lp_vectors(self, density, seed, row_offset=0):
-        """``(feasible_x, c, lb, ub, b_upper)`` of the synthetic LP whose rows this matrix holds."""
+    def random_lp_vectors(self, density, seed, row_offset=0, columns=True):
+        """``(feasible_x, c, lb, ub, b_upper)`` of the synthetic LP whose rows this matrix holds
+        (``columns=False``: only ``b_upper``, the others ``None`` -- a row chunk of a chunked matrix)."""
         n, m = self.shape[1], self.shape[0]
-        xf, c, lb, ub, b = (np.empty(n), np.empty(n), np.empty(n), np.empty(n), np.empty(m))
+        xf, c, lb, ub = (np.empty(n), np.empty(n), np.empty(n), np.empty(n)) if columns else (None, None, None, None)
+        b = np.empty(m)
         _lib.check(self._l.slp_random_lp_vectors(self._h, float(density), int(seed), int(row_offset), _lib.ptr(xf),
                                                  _lib.ptr(c), _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(b)))
         return xf, c, lb, ub, b
+
+
+class ChunkedDeviceMatrix(DeviceMatrix):
+    """A constraint matrix assembled from row chunks whose CSR never coexists (``slp_matrix_chunked_*`` of
+    include/slp_hip.h): every appended chunk is converted into its product copies for both orientations and its CSR is
+    released, so an LP larger than one CSR copy of itself fits one GPU.  Products and the at-scale solvers
+    (``DeviceCP``, ``DeviceADMM``) take it like a ``DeviceMatrix``; ``A^T y`` continues the column sums from chunk to
+    chunk, bit for bit the unchunked product."""
+
+    def __init__(self, ncol):
+        l = _lib.lib()
+        super().__init__(_lib.check_handle(l.slp_matrix_chunked_create(int(ncol))), (0, ncol))
+
+    def append(self, chunk):
+        """Takes ownership of ``chunk`` (a ``DeviceMatrix`` with its CSR); every chunk but the last needs an even row count."""
+        _lib.check(self._l.slp_matrix_chunked_append(self._h, chunk._h))
+        chunk._h = None  # the chunked matrix owns it now
+        self.shape = (self.shape[0] + chunk.shape[0], self.shape[1])
+        return self
+
+    @property
+    def chunks(self):
+        return int(self._l.slp_matrix_chunks(self._h))
+
+    @staticmethod
+    def cuts(rows, chunks):
+        """Row boundaries of ``chunks`` nearly equal chunks of ``rows`` rows, every inner boundary even."""
+        cuts = [(rows * k // chunks) & ~1 for k in range(chunks)] + [rows]
+        return [c for i, c in enumerate(cuts) if i == 0 or c > cuts[i - 1]]

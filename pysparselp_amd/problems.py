@@ -12,7 +12,7 @@ import scipy.sparse
 from scipy.sparse.csgraph import breadth_first_order, maximum_flow
 
 from .SparseLP import SparseLP
-from .device import DeviceMatrix
+from .device import ChunkedDeviceMatrix, DeviceMatrix
 
 
 def _min_cut_labels(unary, pairwise):
@@ -76,17 +76,34 @@ def potts_lp(image_size, coef_potts=0.5, coef_mul=500, seed=1):
     return lp, ground_truth, pix, unary
 
 
-def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None):
+def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1):
     """Synthetic random LP ``min c.x  s.t.  A x <= b_upper, lb <= x <= ub`` (all inequalities).
 
     Generates rows ``row_offset .. row_offset + rows`` (default: all ``m``) of the
     m x n matrix directly in HBM.  Returns ``(DeviceMatrix, feasible_x, c, lb, ub, b_upper)``;
     ``feasible_x`` satisfies every constraint by construction (randomLP.py:33,43-46,53-55).
+
+    ``chunks > 1``: the same LP as a ``ChunkedDeviceMatrix`` -- the rows are generated, converted and released ``chunks``
+    row ranges at a time, so the CSR of the whole matrix never exists (the generator is keyed by the global row: every
+    chunking draws the same matrix, and ``b_upper`` is taken from each chunk's CSR exactly as from the whole one).
     """
     rows = m if rows is None else rows
     assert 0 <= row_offset and row_offset + rows <= m
-    a = DeviceMatrix.random(rows, n, density, seed, row_offset)
-    xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset)
+    if chunks <= 1:
+        a = DeviceMatrix.random(rows, n, density, seed, row_offset)
+        xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset)
+        return a, xf, c, lb, ub, b
+    cuts = ChunkedDeviceMatrix.cuts(rows, chunks)
+    a = ChunkedDeviceMatrix(n)
+    b = np.empty(rows)
+    xf = c = lb = ub = None
+    for k, (r0, r1) in enumerate(zip(cuts, cuts[1:])):
+        chunk = DeviceMatrix.random(r1 - r0, n, density, seed, row_offset + r0)
+        got = chunk.random_lp_vectors(density, seed, row_offset + r0, columns=(k == 0))
+        if k == 0:
+            xf, c, lb, ub = got[:4]
+        b[r0:r1] = got[4]
+        a.append(chunk)
     return a, xf, c, lb, ub, b
 
 

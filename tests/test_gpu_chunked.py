@@ -1,0 +1,217 @@
+"""Chunked matrices (csrc/slp_chunked.hip, ``ChunkedDeviceMatrix``): a constraint matrix handed over / generated in row
+chunks whose CSR never coexists -- how BASELINE config 4's 1e7 x 2e7 LP (2e10 entries) becomes resident on ONE GPU.
+Reference products: ``a * x`` / ``y * a`` (ChambollePockPPD.py:206,216,235,240 ; ADMM.py:148,262), restated in
+oracle/slp_oracle.c; solvers ChambollePockPPD.py:195-343 and ADMM.py:143-268 (use_cg flags), restated in oracle/oracle.py.
+
+Bar: for ANY chunking (K = 1, 3, 8) ``A x`` and ``A^T y`` equal the unchunked product AND the oracle bit for bit -- chunk k
+continues the column sums of chunk k - 1, so every sum stays the single chain of the CSR walk; Chambolle-Pock ``x`` bit for
+bit vs unchunked and vs the oracle; matrix-free ADMM <= 1e-12 vs unchunked, <= 1e-9 vs the oracle.  Shapes are reduced
+copies of config 4's (tall cells in both orientations) and of config 3's (LDS strips).  The copy of a chunk's transpose is
+built straight from the chunk's CSR (no transposed CSR): compared with the device transposition of the whole matrix.
+The full-size run is tools/c4_full.py (profiles/r04_bench_*_c4_1gpu.json).  -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _small_matrices_take_the_strip_formats():
+    os.environ["SLP_STRIP_MIN_NNZ"] = "1"
+    yield
+    del os.environ["SLP_STRIP_MIN_NNZ"]
+    for k in ("SLP_TALL_SPLIT", "SLP_TALL_PASS_NNZ", "SLP_TALL_R"):
+        os.environ.pop(k, None)
+
+
+TALL = dict(n=300_000, m=60_000, density=2e-4, seed=5)     # 60 entries per row, 0.8 per (row, 4096 columns) in both orientations
+STRIPS = dict(n=20_000, m=30_000, density=2e-3, seed=6)    # 40 entries per row, 10 per (row, strip): LDS strips
+
+
+def _lp(shape, chunks):
+    from pysparselp_amd.problems import random_lp_on_device
+
+    return random_lp_on_device(shape["n"], shape["m"], shape["density"], seed=shape["seed"], chunks=chunks)
+
+
+@pytest.fixture(scope="module")
+def tall_reference():
+    """The unchunked LP, its products and its host copy (the oracle's operand)."""
+    os.environ["SLP_STRIP_MIN_NNZ"] = "1"
+    a, xf, c, lb, ub, b = _lp(TALL, 1)
+    rng = np.random.RandomState(1)
+    x, y = rng.randn(TALL["n"]), rng.randn(TALL["m"])
+    assert a.spmv_kernel(False) == 6 and a.spmv_kernel(True) == 6
+    host = a.download()
+    ref = dict(a=a, vectors=(xf, c, lb, ub, b), x=x, y=y, ax=a.matvec(x), aty=a.rmatvec(y), host=host)
+    # the unchunked tall-cell products are the oracle's, bit for bit (also pinned in tests/test_gpu_tall.py)
+    assert np.array_equal(ref["ax"], oracle.matvec(oracle.as_csr(host), x))
+    assert np.array_equal(ref["aty"], oracle.rmatvec(oracle.as_csr(host), y))
+    yield ref
+    a.close()
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 8])
+def test_chunked_products_equal_the_unchunked_ones_and_the_oracle_bit_for_bit(tall_reference, chunks):
+    ref = tall_reference
+    a, xf, c, lb, ub, b = _lp(TALL, chunks)
+    try:
+        assert a.chunks == chunks and a.shape == (TALL["m"], TALL["n"]) and a.nnz == ref["a"].nnz
+        assert a.spmv_kernel(False) == 6 and a.spmv_kernel(True) == 6
+        for got, want in zip((xf, c, lb, ub, b), ref["vectors"]):
+            assert np.array_equal(got, want)               # the same LP whatever the chunking
+        assert np.array_equal(a.matvec(ref["x"]), ref["ax"])
+        assert np.array_equal(a.rmatvec(ref["y"]), ref["aty"])
+        # twice: the accumulation across chunks starts afresh in every product
+        assert np.array_equal(a.rmatvec(ref["y"]), ref["aty"])
+        lhs, rhs = float(a.matvec(ref["x"]).dot(ref["y"])), float(ref["x"].dot(a.rmatvec(ref["y"])))
+        assert abs(lhs - rhs) <= 1e-10 * (abs(lhs) + 1)
+        assert a.bench_spmv(False, reps=2) > 0 and a.bench_spmv(True, reps=2) > 0
+        assert 0 < a._l.slp_matrix_format_bytes(a._h, 0) < 12 * a.nnz   # 5-6 bytes per entry, not the CSR's 12
+        with pytest.raises(Exception, match="chunked"):
+            a.download()
+    finally:
+        a.close()
+
+
+@pytest.mark.parametrize("chunks", [3, 8])
+def test_chunked_solvers_equal_the_unchunked_ones_and_the_oracle(tall_reference, chunks):
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.scale import DeviceCP
+
+    ref = tall_reference
+    xf, c, lb, ub, b = ref["vectors"]
+    host = oracle.as_csr(ref["host"])
+    a = _lp(TALL, chunks)[0]
+    try:
+        iters = 12
+        x_cpu, _ = oracle.chambolle_pock_ppd(c, None, None, host, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9)
+        xs = []
+        for mat in (ref["a"], a):
+            s = DeviceCP(mat, b, c, lb, ub)
+            s.iterate(iters - 1)
+            s.primal_step()
+            rep = s.report()
+            s.dual_step()
+            xs.append((s.x(), rep))
+            s.close()
+        assert np.array_equal(xs[0][0], xs[1][0]) and np.array_equal(xs[0][1], xs[1][1])   # iterate AND report: bit for bit
+        assert np.array_equal(xs[1][0], x_cpu)
+        x_cpu = oracle.lp_admm_cg(c, None, None, host, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
+        xs = []
+        for mat in (ref["a"], a):
+            s = DeviceADMM(mat, b, c, lb, ub)
+            assert s.reuse == 4
+            s.iterate(iters)
+            xs.append(s.x(TALL["n"]))
+            rep = s.report()
+            assert np.all(np.isfinite(rep))
+            s.close()
+        err = float(np.max(np.abs(xs[0] - xs[1]) / (1 + np.abs(xs[0]))))
+        assert err <= 1e-12, err
+        err = float(np.max(np.abs(xs[1] - x_cpu) / (1 + np.abs(x_cpu))))
+        assert err <= 1e-9, err
+        assert abs(float(c.dot(xs[1])) - float(c.dot(x_cpu))) <= 1e-6 * abs(float(c.dot(x_cpu)))
+    finally:
+        a.close()
+
+
+def test_strip_format_chunks_and_fp64_chunks():
+    """Chunks dense enough for the LDS strips (config 3's regime): dictionary strips and, with the dictionary ruled out
+    chunk by chunk, fp64 strips; the products and Chambolle-Pock bit for bit, ADMM refused without a dictionary."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.device import ChunkedDeviceMatrix, DeviceMatrix
+    from pysparselp_amd.scale import DeviceCP
+
+    sh = STRIPS
+    a0, xf, c, lb, ub, b = _lp(sh, 1)
+    host = oracle.as_csr(a0.download())
+    rng = np.random.RandomState(2)
+    x, y = rng.randn(sh["n"]), rng.randn(sh["m"])
+    ax, aty = oracle.matvec(host, x), oracle.rmatvec(host, y)
+    x_cpu, _ = oracle.chambolle_pock_ppd(c, None, None, host, None, b, lb, ub, nb_max_iter=10, nb_iter_plot=10 ** 9)
+    try:
+        for policy in (0, 1):
+            cuts = ChunkedDeviceMatrix.cuts(sh["m"], 3)
+            a = ChunkedDeviceMatrix(sh["n"])
+            for r0, r1 in zip(cuts, cuts[1:]):
+                chunk = DeviceMatrix.random(r1 - r0, sh["n"], sh["density"], sh["seed"], r0)
+                chunk.set_format(policy)
+                a.append(chunk)
+                assert chunk._h is None
+            assert a.spmv_kernel(False) in ((2, 3) if policy == 0 else (1,)), a.spmv_kernel(False)
+            assert a.spmv_kernel(True) in ((2, 3) if policy == 0 else (1,)), a.spmv_kernel(True)
+            assert np.array_equal(a.matvec(x), ax) and np.array_equal(a.rmatvec(y), aty)
+            s = DeviceCP(a, b, c, lb, ub)
+            s.iterate(10)
+            assert np.array_equal(s.x(), x_cpu), policy
+            s.close()
+            if policy == 1:
+                with pytest.raises(Exception, match="value-dictionary"):
+                    DeviceADMM(a, b, c, lb, ub)
+            else:
+                s = DeviceADMM(a, b, c, lb, ub)
+                s.iterate(8)
+                s0 = DeviceADMM(a0, b, c, lb, ub)
+                s0.iterate(8)
+                err = float(np.max(np.abs(s.x(sh["n"]) - s0.x(sh["n"])) / (1 + np.abs(s0.x(sh["n"])))))
+                s.close()
+                s0.close()
+                assert err <= 1e-12, err
+            a.close()
+    finally:
+        a0.close()
+
+
+def test_build_passes_and_strip_range_split_do_not_change_the_copy():
+    """The tall-cell copies are written in passes over ranges of row blocks (bounded temporaries): 1 pass and many passes give
+    the same products; with the strip-range split (partial sums per range) chunks still continue each other's sums."""
+    ref = None
+    for env in ({}, {"SLP_TALL_PASS_NNZ": "400000"}, {"SLP_TALL_PASS_NNZ": "400000", "SLP_TALL_R": "1500"}):
+        os.environ.update(env)
+        a = _lp(TALL, 3)[0]
+        rng = np.random.RandomState(9)
+        x, y = rng.randn(TALL["n"]), rng.randn(TALL["m"])
+        got = (a.matvec(x), a.rmatvec(y))
+        a.close()
+        for k in env:
+            del os.environ[k]
+        if ref is None:
+            ref = got
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), env
+    os.environ["SLP_TALL_SPLIT"] = "3"
+    a = _lp(TALL, 3)[0]
+    got = (a.matvec(x), a.rmatvec(y))
+    a.close()
+    for g, r in zip(got, ref):
+        assert float(np.max(np.abs(g - r) / (1 + np.abs(r)))) <= 1e-13
+
+
+def test_chunked_api_errors():
+    from pysparselp_amd._lib import SlpError
+    from pysparselp_amd.device import ChunkedDeviceMatrix, DeviceMatrix
+
+    a = ChunkedDeviceMatrix(50_000)
+    odd = DeviceMatrix.random(10_001, 50_000, 1e-3, 1, 0)
+    a.append(odd)                                   # an odd chunk may only be the last one
+    nxt = DeviceMatrix.random(10_000, 50_000, 1e-3, 1, 10_001)
+    with pytest.raises(SlpError, match="even number of rows"):
+        a.append(nxt)
+    nxt.close()
+    other = DeviceMatrix.random(10_000, 40_000, 1e-3, 1, 0)
+    with pytest.raises(SlpError, match="column count"):
+        ChunkedDeviceMatrix(50_000).append(other)
+    other.close()
+    plain = DeviceMatrix.random(10_000, 50_000, 1e-3, 1, 0)
+    extra = DeviceMatrix.random(10_000, 50_000, 1e-3, 1, 0)
+    assert plain._l.slp_matrix_chunked_append(plain._h, extra._h) != 0      # the target must come from slp_matrix_chunked_create
+    assert b"not a chunked matrix" in plain._l.slp_last_error()
+    extra.close()
+    plain.close()
+    with pytest.raises(SlpError, match="chunked"):
+        a.random_lp_vectors(1e-3, 1, 0)             # b_upper needs the CSR: chunk by chunk, before the append
+    a.close()
