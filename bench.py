@@ -62,15 +62,19 @@ KERNEL_NAMES = {
     0: "k_spmv (row-per-lane-group CSR SpMV)",
 }
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this exact workload (tools/profile_c3.sh, tools/summarize_rocprof.py)
-PMC_FILES = {
-    3: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_quad.json"), "slp::k_qstrip_spmv<1"),   # kernel-name prefixes: the template
-    2: (("r02_c3_pmc_hbm.json", "r01_c3_pmc_hbm_dict.json"), "slp::k_dstrip_spmv<1"),   # argument lists grew between rounds
-    1: (("r02_c3_pmc_hbm.json", "r01_cp_c3_pmc_hbm.json"), "slp::k_strip_spmv<0"),
+PMC_FILES = {   # newest record first
+    3: (("r04_c3_pmc_hbm.json", "r03_c3_pmc_hbm.json", "r02_c3_pmc_hbm.json"), "slp::k_qstrip_spmv<1"),   # kernel-name prefixes: the
+    2: (("r04_c3_pmc_hbm.json", "r03_c3_pmc_hbm.json", "r02_c3_pmc_hbm.json"), "slp::k_dstrip_spmv<1"),   # template argument lists
+    1: (("r04_c3_pmc_hbm.json", "r03_c3_pmc_hbm.json", "r02_c3_pmc_hbm.json"), "slp::k_strip_spmv<0"),    # grew between rounds
 }
 # named workloads: (variables, rows, density); c4slice = the 1/8 row slice of a 1e7 x 2e7, density-1e-4 LP -- BASELINE
 # config 4's per-rank shape at a density that fits (the 1e-3 of config 4 is 2.4 TB of CSR)
-CONFIGS = {"c3": (1_000_000, 2_000_000, 1e-3), "c4slice": (10_000_000, 2_500_000, 1e-4)}
-PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: (("r03_tall_slice_pmc_hbm.json",), "slp::k_tall_spmv")}}
+# c4 = the metric's named LP, 1e7 x 2e7 at the density that fits one node (1e-4: 2e10 stored entries): this rank's row block is
+# generated, converted and released in row chunks (ChunkedDeviceMatrix), so it is resident on 1, 2, 4 or 8 GPUs alike
+CONFIGS = {"c3": (1_000_000, 2_000_000, 1e-3), "c4slice": (10_000_000, 2_500_000, 1e-4), "c4": (10_000_000, 20_000_000, 1e-4)}
+PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: (("r04_tall_slice_pmc_hbm.json", "r03_tall_slice_pmc_hbm.json"), "slp::k_tall_spmv")},
+                      (10_000_000, 20_000_000, 1e-4): {6: (("r04_c4_pmc_hbm.json",), "slp::k_tall_spmv")}}
+CHUNK_ENTRIES = 2.6e9   # a chunk's CSR (12 B per entry) + its conversion temporaries must fit beside the copies already built
 
 
 def parse():
@@ -95,6 +99,9 @@ def parse():
     p.add_argument("--keep-csr", dest="release_csr", action="store_false",
                    help="keep both CSR orientations resident during the timed region (default: released once the strip copies exist)")
     p.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU sample (default m / 10)")
+    p.add_argument("--chunks", type=int, default=0,
+                   help="row chunks this rank's block is generated / converted / released in (ChunkedDeviceMatrix); default: as many "
+                        "as keep a chunk below 2.6e9 stored entries (1 = an ordinary DeviceMatrix with its CSR)")
     p.add_argument("--format", type=int, default=0, choices=[0, 1, 2],
                    help="slp_matrix_set_format policy of the timed run: 0 best available, 1 no value dictionary, 2 CSR kernels")
     args = p.parse_args()
@@ -162,7 +169,8 @@ def cpu_baseline(args, method):
     (profiles/r03_cpu_full_c3.json)."""
     from oracle import oracle
 
-    rows = args.cpu_sample_rows or max(1, args.m // 10)
+    # ~ 2e8 stored entries: 10-30 s of one CPU core for the timed iterations
+    rows = args.cpu_sample_rows or max(1, min(args.m // 10, int(2.0e8 / max(args.n * args.density, 1.0))))
     a = DeviceMatrix.random(rows, args.n, args.density, args.seed)
     xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed)
     s = a.download()
@@ -196,15 +204,25 @@ def cpu_baseline(args, method):
         "sample_setup_seconds": setup_s,
         "host_cores_present": os.cpu_count(),
     }
-    for name in ("r03_cpu_full_c3.json", "r02_cpu_full_c3.json"):  # (r02: Chambolle-Pock only)
-        full = os.path.join(REPO, "profiles", name)
-        try:
-            rec = json.load(open(full)).get(method)
-        except Exception:  # the validation record is optional evidence, never a reason to lose the bench line
-            rec = None
-        if rec:
-            out["full_size_validation"] = {"source": "profiles/" + name, **rec}
-            break
+    if (args.n, args.m, args.density) == CONFIGS["c3"]:
+        for name in ("r03_cpu_full_c3.json", "r02_cpu_full_c3.json"):  # (r02: Chambolle-Pock only)
+            full = os.path.join(REPO, "profiles", name)
+            try:
+                rec = json.load(open(full)).get(method)
+            except Exception:  # the validation record is optional evidence, never a reason to lose the bench line
+                rec = None
+            if rec:
+                out["full_size_validation"] = {"source": "profiles/" + name, **rec}
+                # the rate MEASURED at full size (one thread, this workload) is the baseline; the sample's extrapolation
+                # (which flatters the CPU: its gathers stay warmer) is kept beside it
+                full_rate = rec.get("full_size_it_per_s")
+                if full_rate:
+                    out["value_extrapolated_from_sample"] = out["value"]
+                    out["value"] = float(full_rate)
+                    out["extrapolated"] = False
+                    out["sample"] = (f"FULL size, one thread, measured by tools/cpu_full_c3.py (profiles/{name}); this run's sample: "
+                                     + out["sample"])
+                break
     return out
 
 
@@ -272,9 +290,13 @@ def main():
 
     shape = (args.n, args.m, args.density)
     r0, rows = row_block(args.m, world, rank)
+    chunks = args.chunks or max(1, int(np.ceil(rows * args.n * args.density / CHUNK_ENTRIES)))
+    alloc = np.zeros(4)
+    _lib.check(lib.slp_alloc_stats(None, 1))
     t_gen = time.perf_counter()
-    a = DeviceMatrix.random(rows, args.n, args.density, args.seed, r0)
-    xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed, r0)
+    from pysparselp_amd.problems import random_lp_on_device
+
+    a, xf, c, lb, ub, b = random_lp_on_device(args.n, args.m, args.density, seed=args.seed, row_offset=r0, rows=rows, chunks=chunks)
     nnz_local = a.nnz
     _lib.check(lib.slp_synchronize())
     t_generate = time.perf_counter() - t_gen  # the synthetic LP itself (randomLP.py's part); the rest of setup_seconds is the solver's
@@ -293,7 +315,8 @@ def main():
     t_gen = time.perf_counter() - t_gen
     # Steady state keeps only what the iteration reads: when both orientations run on strip copies, the two CSR copies
     # (48 GB at config 3) are dropped and the cached temporaries of the setup returned to the driver.
-    mem = {"in_use_after_setup_gb": device_memory_in_use(lib)}
+    _lib.check(lib.slp_alloc_stats(_lib.ptr(alloc), 0))
+    mem = {"in_use_after_setup_gb": device_memory_in_use(lib), "peak_held_by_the_library_gb": alloc[1] / 1e9}
     released = args.release_csr and args.blocks_per_rank == 1 and a.spmv_kernel(False) >= 1 and a.spmv_kernel(True) >= 1
     if released:
         a.release_csr()
@@ -367,7 +390,11 @@ def main():
             "config": {
                 "workload": f"randomLP synthetic: {args.n} vars, {args.m} inequality rows, density {args.density}, "
                             f"{nnz_total} stored entries, method {args.method} ({solver.describe()}), "
-                            f"rows partitioned over {world} GPU(s)",
+                            f"rows partitioned over {world} GPU(s)"
+                            + (f", every rank's block built in {chunks} row chunks whose CSR never coexists" if chunks > 1 else "")
+                            + (f", SLP_TALL_SPLIT={os.environ['SLP_TALL_SPLIT']} (strip ranges of a tall row block shared by several "
+                               "workgroups, partial sums added in range order)" if os.environ.get("SLP_TALL_SPLIT") else ""),
+                "chunks_per_rank": chunks,
                 "n": args.n, "m": args.m, "density": args.density, "seed": args.seed, "nnz": nnz_total, "eq_frac": args.eq_frac,
                 "method": args.method, "matrix_passes_per_iteration": passes,
                 "collectives_per_iteration": (coll / args.steps) if distributed else 0,
@@ -377,12 +404,16 @@ def main():
             "roofline": roofline,
             "objective_after_run": obj,
             "setup_seconds": t_gen,
-            "setup_breakdown": {"generate_lp_seconds": t_generate, "solver_setup_seconds": t_gen - t_generate},
+            "setup_breakdown": {"generate_lp_seconds": t_generate, "solver_setup_seconds": t_gen - t_generate,
+                                "allocation_seconds": alloc[0], "driver_allocation_calls": int(alloc[3]),
+                                "peak_device_gb": alloc[1] / 1e9,
+                                **({"note": "generate_lp_seconds includes every chunk's conversion into its product copies"}
+                                   if chunks > 1 else {})},
             "device_memory": mem,
         }
         solver.close()
         solver = None
-        if world == 1 and not args.no_general and args.format == 0 and which >= 2 and args.method != "admm_blocks":
+        if world == 1 and not args.no_general and args.format == 0 and which >= 2 and args.method != "admm_blocks" and chunks == 1:
             if released:  # the CSR entries are gone: the same rows again from the counter-based generator
                 a.close()
                 a = DeviceMatrix.random(rows, args.n, args.density, args.seed, r0)

@@ -45,6 +45,11 @@ int slp_synchronize(void);
  * returned to the driver; slp_trim() returns it all, slp_cached_bytes() tells how much is parked. */
 int slp_trim(void);
 int64_t slp_cached_bytes(void);
+/* What the library's device allocations cost and weigh: out[0] seconds spent inside hipMalloc / hipFree, out[1] the most
+ * bytes the library ever held from the driver at once (live + cached), out[2] bytes held now, out[3] driver calls -- all
+ * since the last call with reset != 0 (the peak restarts from what is held).  A set-up's allocation time and peak footprint
+ * as the bench line reports them. */
+int slp_alloc_stats(double out[4], int reset);
 const char *slp_last_error(void);
 /* Milliseconds the GPU spent between the two most recent slp_timer_start /
  * slp_timer_stop marks on the library's stream (HIP events). */

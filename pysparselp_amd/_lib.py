@@ -33,6 +33,7 @@ _SIGNATURES = {
     "slp_synchronize": (c_int, []),
     "slp_trim": (c_int, []),
     "slp_cached_bytes": (c_i64, []),
+    "slp_alloc_stats": (c_int, [c_vp, c_int]),
     "slp_last_error": (ctypes.c_char_p, []),
     "slp_timer_start": (c_int, []),
     "slp_timer_stop": (c_int, [c_vp]),

@@ -33,19 +33,33 @@ void trace_slow(const char *what, size_t bytes, double t0) {
 static std::multimap<size_t, void *> g_free_blocks;  // capacity -> block
 static size_t g_cached_bytes = 0;
 static std::mutex g_alloc_mutex;
+// bookkeeping for slp_alloc_stats: what the driver calls cost and how much memory the library ever held at once
+static double g_driver_seconds = 0.0;
+static size_t g_held_bytes = 0, g_peak_bytes = 0;
+static long long g_driver_calls = 0;
 
 void comm_sync_side();  // slp_comm.hip: drains the second stream (asynchronous all-reduces may still write cached blocks)
 
 static void trim_cache() {
     comm_sync_side();
-    for (auto &kv : g_free_blocks) (void)hipFree(kv.second);
+    const double t0 = trace_now();
+    for (auto &kv : g_free_blocks) { (void)hipFree(kv.second); g_held_bytes -= kv.first; ++g_driver_calls; }
+    g_driver_seconds += trace_now() - t0;
     g_free_blocks.clear();
     g_cached_bytes = 0;
 }
 
 void *dev_alloc(size_t bytes, size_t *capacity) {
     static const bool off = [] { const char *e = getenv("SLP_NO_ALLOC_CACHE"); return e && e[0] == '1'; }();
-    const size_t want = (bytes + 255) & ~(size_t)255;
+    size_t want = (bytes + 255) & ~(size_t)255;
+    if (want > ((size_t)64 << 20)) {
+        // large blocks in size classes of 1/32 .. 1/64 of their size: the CSR arrays, sort buffers and packet streams of
+        // successive row chunks (sizes equal to a fraction of a percent) then reuse each other's blocks instead of going to the
+        // driver for a new multi-GB allocation each time
+        size_t g = 1;
+        while ((g << 6) <= want) g <<= 1;
+        want = (want + g - 1) & ~(g - 1);
+    }
     std::lock_guard<std::mutex> lock(g_alloc_mutex);
     if (!off) {
         // a cached block is taken when it is not much larger than the request: up to 2 x for small ones, up to 12.5 % above
@@ -62,16 +76,21 @@ void *dev_alloc(size_t bytes, size_t *capacity) {
         }
     }
     void *p = nullptr;
-    const double t0 = trace_enabled() ? trace_now() : 0.0;
+    const double t0 = trace_now();
     hipError_t e = hipMalloc(&p, want);
+    ++g_driver_calls;
     if (e != hipSuccess && !g_free_blocks.empty()) {  // out of memory with blocks parked in the cache: give them back, retry
         (void)hipGetLastError();
         SLP_HIP(hipStreamSynchronize(ctx().stream));
         trim_cache();
         e = hipMalloc(&p, want);
+        ++g_driver_calls;
     }
+    g_driver_seconds += trace_now() - t0;
     if (e != hipSuccess) throw Error(std::string("hipMalloc of ") + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
-    if (t0 != 0.0) trace_slow("hipMalloc", want, t0);
+    if (trace_enabled()) trace_slow("hipMalloc", want, t0);
+    g_held_bytes += want;
+    if (g_held_bytes > g_peak_bytes) g_peak_bytes = g_held_bytes;
     *capacity = want;
     return p;
 }
@@ -80,9 +99,13 @@ void dev_free(void *p, size_t capacity) {
     static const bool off = [] { const char *e = getenv("SLP_NO_ALLOC_CACHE"); return e && e[0] == '1'; }();
     if (!p) return;
     if (off || capacity == 0) {
-        const double t0 = trace_enabled() ? trace_now() : 0.0;
+        const double t0 = trace_now();
         (void)hipFree(p);
-        if (t0 != 0.0) trace_slow("hipFree", capacity, t0);
+        if (trace_enabled()) trace_slow("hipFree", capacity, t0);
+        std::lock_guard<std::mutex> lock(g_alloc_mutex);
+        g_driver_seconds += trace_now() - t0;
+        g_held_bytes -= capacity;
+        ++g_driver_calls;
         return;
     }
     std::lock_guard<std::mutex> lock(g_alloc_mutex);
@@ -486,6 +509,19 @@ int slp_trim(void) {
 }
 
 int64_t slp_cached_bytes(void) { return (int64_t)g_cached_bytes; }
+
+int slp_alloc_stats(double out[4], int reset) {
+    SLP_API_INT({
+        std::lock_guard<std::mutex> lock(g_alloc_mutex);
+        if (out) {
+            out[0] = g_driver_seconds;
+            out[1] = (double)g_peak_bytes;
+            out[2] = (double)g_held_bytes;
+            out[3] = (double)g_driver_calls;
+        }
+        if (reset) { g_driver_seconds = 0.0; g_peak_bytes = g_held_bytes; g_driver_calls = 0; }
+    })
+}
 
 int slp_synchronize(void) { SLP_API_INT({ SLP_HIP(hipStreamSynchronize(ctx().stream)); }) }
 

@@ -659,8 +659,10 @@ static void tall_geometry(i64 nrow, i64 T, int *R_out, int *S_out) {
     *R_out = (int)std::min<i64>(R, kTallRmax);
 }
 
-// Entries per build pass (SLP_TALL_PASS_NNZ): the temporaries of a pass are ~ 24 bytes per entry (keys, sorted keys, sort
-// scratch; 40 with fp64 entries), so a pass of 5e8 entries needs ~ 12 GB whatever the size of the matrix.
+// Entries per sort pass (SLP_TALL_PASS_NNZ): the keys of a pass and the sort's scratch are ~ 16 bytes per entry (32 with fp64
+// entries), so a pass of 5e8 entries needs ~ 8 GB whatever the size of the matrix; the sorted keys of the whole copy (8 bytes
+// per entry) stay until the packets are written -- all row blocks in ONE launch (a launch per pass leaves most of the chip
+// idle: measured 5 x 142 ms against 142 ms on the 2.5e6 x 1e7 slice).
 static i64 tall_pass_nnz() {
     const char *e = getenv("SLP_TALL_PASS_NNZ");
     const i64 v = e ? atoll(e) : 500000000ll;
@@ -680,7 +682,8 @@ static void tall_launch_build(bool write, unsigned V, int R, i64 T, int S, i64 n
     SLP_HIP(hipGetLastError());
 }
 
-// The tall-cell copy of `a` (transposed: of a^T) straight from the CSR of `a`, in passes over ranges of the copy's row blocks.
+// The tall-cell copy of `a` (transposed: of a^T) straight from the CSR of `a`.  Keys are drawn and sorted in passes over ranges
+// of the copy's row blocks (a pass's cells all precede the next pass's: the sorted ranges line up into the sorted whole).
 bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict) {
     Phase ph(transposed ? "tall_build (A^T from the CSR of A)" : "tall_build");
     hipStream_t st = ctx().stream;
@@ -691,14 +694,12 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     const i64 T = (ncolF + kTallC - 1) / kTallC;
     int R = 0, S = 1;
     tall_geometry(nrowF, T, &R, &S);
-    const i64 B = (nrowF + R - 1) / R, V = B * S;  // V workgroups: (row block, strip range)
+    const i64 B = (nrowF + R - 1) / R, ncell = B * T, V = B * S;  // V workgroups: (row block, strip range)
+    unsigned int cellbits = 1;
+    while (((i64)1 << cellbits) < ncell) ++cellbits;
+    if (kTallCellShift + cellbits > 64) return false;
     i64 P = (a.nnz + tall_pass_nnz() - 1) / tall_pass_nnz();
     P = std::max<i64>(1, std::min<i64>(P, B));
-    {
-        unsigned int cellbits = 1;
-        while (((i64)1 << cellbits) < ((B + P - 1) / P) * T) ++cellbits;
-        if (kTallCellShift + cellbits > 64) return false;
-    }
     DevBuf<int> bad(1);
     bad.zero();
     if (transposed) {  // the per-row column ranges of the passes are binary searches: the rows must be sorted
@@ -708,114 +709,110 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
         bad.download(&hbad, 1);
         if (hbad) return false;
     }
-    std::vector<TallWg> wg((size_t)V);
-    const i64 limit = dict ? ((i64)1 << 28) : ((i64)1 << 27);  // payload words of one workgroup (32-bit byte offsets; fp64: 2 x)
-    DevBuf<i64> lo, len, opos;
-    if (transposed) { lo.alloc((size_t)a.nrow); len.alloc((size_t)a.nrow + 1); opos.alloc((size_t)a.nrow + 1); }
-    for (i64 pass = 0; pass < P; ++pass) {
-        const i64 bb0 = B * pass / P, bb1 = B * (pass + 1) / P, nb = bb1 - bb0;
-        if (nb == 0) continue;
-        const i64 ncell = nb * T, Vp = nb * S;
-        const i64 f0 = bb0 * (i64)R, f1 = std::min<i64>(bb1 * (i64)R, nrowF);  // rows of the copy in this pass
-        // entries of the pass and where each row's keys go
-        i64 n_p = 0, obase = 0;
-        if (!transposed) {
-            i64 ends[2];
-            SLP_HIP(hipMemcpyAsync(&ends[0], a.ptr.p + f0, sizeof(i64), hipMemcpyDeviceToHost, st));
-            SLP_HIP(hipMemcpyAsync(&ends[1], a.ptr.p + f1, sizeof(i64), hipMemcpyDeviceToHost, st));
-            SLP_HIP(hipStreamSynchronize(st));
-            obase = ends[0];
-            n_p = ends[1] - ends[0];
-        } else {
-            hipLaunchKernelGGL(k_tall_range, dim3(grid_for(a.nrow, kBlock)), dim3(kBlock), 0, st, a.nrow, a.ptr.p, a.idx.p, f0, f1, lo.p, len.p);
-            SLP_HIP(hipGetLastError());
-            size_t bytes = 0;
-            SLP_HIP(rocprim::exclusive_scan(nullptr, bytes, len.p, opos.p, (i64)0, (size_t)a.nrow + 1, rocprim::plus<i64>(), st));
-            DevBuf<char> tmp(bytes);
-            SLP_HIP(rocprim::exclusive_scan(tmp.p, bytes, len.p, opos.p, (i64)0, (size_t)a.nrow + 1, rocprim::plus<i64>(), st));
-            SLP_HIP(hipMemcpyAsync(&n_p, opos.p + a.nrow, sizeof(i64), hipMemcpyDeviceToHost, st));
-            SLP_HIP(hipStreamSynchronize(st));
-        }
-        DevBuf<i64> cellptr((size_t)ncell + 1);
-        DevBuf<unsigned long long> sorted((size_t)std::max<i64>(n_p, 1));
-        DevBuf<double> svals;  // fp64 entries: the values in the sorted order
-        if (n_p > 0) {
-            Phase p1("  tall: keys + sort");
+    DevBuf<unsigned long long> sorted((size_t)a.nnz);
+    DevBuf<double> svals;  // fp64 entries: the values in the sorted order
+    if (!dict) svals.alloc((size_t)a.nnz);
+    {
+        Phase p1("  tall: keys + sort");
+        DevBuf<i64> lo, len, opos;
+        if (transposed) { lo.alloc((size_t)a.nrow); len.alloc((size_t)a.nrow + 1); opos.alloc((size_t)a.nrow + 1); }
+        const int D = dict ? dict->D : 0;
+        const unsigned long long *dk = dict ? dict->keys.p : (const unsigned long long *)nullptr;
+        // TR: by (cell, local row) -- see k_tall_keys
+        const unsigned b0 = transposed ? (unsigned)(kTallIdBits + kTallColBits) : (unsigned)kTallCellShift, b1 = (unsigned)kTallCellShift + cellbits;
+        i64 done = 0;  // entries of the passes so far = where this pass's sorted keys go
+        for (i64 pass = 0; pass < P; ++pass) {
+            const i64 bb0 = B * pass / P, bb1 = B * (pass + 1) / P;
+            if (bb1 == bb0) continue;
+            const i64 f0 = bb0 * (i64)R, f1 = std::min<i64>(bb1 * (i64)R, nrowF);  // rows of the copy in this pass
+            i64 n_p = 0, obase = 0;
+            if (!transposed) {
+                i64 ends[2];
+                SLP_HIP(hipMemcpyAsync(&ends[0], a.ptr.p + f0, sizeof(i64), hipMemcpyDeviceToHost, st));
+                SLP_HIP(hipMemcpyAsync(&ends[1], a.ptr.p + f1, sizeof(i64), hipMemcpyDeviceToHost, st));
+                SLP_HIP(hipStreamSynchronize(st));
+                obase = ends[0];
+                n_p = ends[1] - ends[0];
+            } else {
+                hipLaunchKernelGGL(k_tall_range, dim3(grid_for(a.nrow, kBlock)), dim3(kBlock), 0, st, a.nrow, a.ptr.p, a.idx.p, f0, f1, lo.p, len.p);
+                SLP_HIP(hipGetLastError());
+                size_t bytes = 0;
+                SLP_HIP(rocprim::exclusive_scan(nullptr, bytes, len.p, opos.p, (i64)0, (size_t)a.nrow + 1, rocprim::plus<i64>(), st));
+                DevBuf<char> tmp(bytes);
+                SLP_HIP(rocprim::exclusive_scan(tmp.p, bytes, len.p, opos.p, (i64)0, (size_t)a.nrow + 1, rocprim::plus<i64>(), st));
+                SLP_HIP(hipMemcpyAsync(&n_p, opos.p + a.nrow, sizeof(i64), hipMemcpyDeviceToHost, st));
+                SLP_HIP(hipStreamSynchronize(st));
+            }
+            if (n_p == 0) continue;
             DevBuf<unsigned long long> keys((size_t)n_p);
             DevBuf<double> kvals;
             if (!dict && transposed) kvals.alloc((size_t)n_p);
             const i64 scan_rows = transposed ? a.nrow : f1 - f0, r0 = transposed ? 0 : f0;
-            const int D = dict ? dict->D : 0;
-            const unsigned long long *dk = dict ? dict->keys.p : (const unsigned long long *)nullptr;
             if (transposed)
-                hipLaunchKernelGGL((k_tall_keys<true>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, bb0, D, dk,
+                hipLaunchKernelGGL((k_tall_keys<true>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, (i64)0, D, dk,
                                    a.ptr.p, a.idx.p, a.val.p, lo.p, opos.p, obase, keys.p, kvals.p, bad.p);
             else
-                hipLaunchKernelGGL((k_tall_keys<false>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, bb0, D, dk,
+                hipLaunchKernelGGL((k_tall_keys<false>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, (i64)0, D, dk,
                                    a.ptr.p, a.idx.p, a.val.p, (const i64 *)nullptr, (const i64 *)nullptr, obase, keys.p, (double *)nullptr, bad.p);
             SLP_HIP(hipGetLastError());
-            int hbad = 0;
-            bad.download(&hbad, 1);
-            if (hbad) { f = StripJds(); return false; }  // unsorted rows (or a value outside the dictionary)
-            unsigned int cellbits = 1;
-            while (((i64)1 << cellbits) < ncell) ++cellbits;
             size_t bytes = 0;
-            // TR: by (cell, local row) -- see k_tall_keys
-            const unsigned b0 = transposed ? (unsigned)(kTallIdBits + kTallColBits) : (unsigned)kTallCellShift, b1 = (unsigned)kTallCellShift + cellbits;
             if (dict) {
-                SLP_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys.p, sorted.p, (size_t)n_p, b0, b1, st));
+                SLP_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys.p, sorted.p + done, (size_t)n_p, b0, b1, st));
                 DevBuf<char> tmp(bytes);
-                SLP_HIP(rocprim::radix_sort_keys(tmp.p, bytes, keys.p, sorted.p, (size_t)n_p, b0, b1, st));
+                SLP_HIP(rocprim::radix_sort_keys(tmp.p, bytes, keys.p, sorted.p + done, (size_t)n_p, b0, b1, st));
                 SLP_HIP(hipStreamSynchronize(st));
             } else {
-                svals.alloc((size_t)n_p);
                 const double *vin = transposed ? kvals.p : a.val.p + obase;
-                SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, sorted.p, vin, svals.p, (size_t)n_p, b0, b1, st));
+                SLP_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, sorted.p + done, vin, svals.p + done, (size_t)n_p, b0, b1, st));
                 DevBuf<char> tmp(bytes);
-                SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.p, sorted.p, vin, svals.p, (size_t)n_p, b0, b1, st));
+                SLP_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.p, sorted.p + done, vin, svals.p + done, (size_t)n_p, b0, b1, st));
                 SLP_HIP(hipStreamSynchronize(st));
             }
-            hipLaunchKernelGGL(k_tall_cellptr, dim3(grid_for(n_p, kBlock)), dim3(kBlock), 0, st, n_p, ncell, sorted.p, cellptr.p);
-            SLP_HIP(hipGetLastError());
-        } else {
-            cellptr.zero();  // no entries in these row blocks: every cell is empty
+            done += n_p;
         }
-        Phase p2("  tall: packets (sizes + fill)");
-        DevBuf<i64> sizes(2 * (size_t)Vp);
-        if (dict) tall_launch_build<true>(false, (unsigned)Vp, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, sizes.p, nullptr, nullptr, nullptr, nullptr, nullptr);
-        else tall_launch_build<false>(false, (unsigned)Vp, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, sizes.p, nullptr, nullptr, nullptr, nullptr, nullptr);
-        std::vector<i64> hs(2 * (size_t)Vp), hbase((size_t)Vp + 1), hpkt((size_t)Vp + 1);
-        sizes.download(hs.data(), hs.size());
-        hbase[0] = hpkt[0] = 0;
-        for (i64 v = 0; v < Vp; ++v) {
-            if (hs[2 * v] >= limit) { f = StripJds(); return false; }  // a workgroup's payload outgrows its 32-bit byte offsets: another format
-            hbase[v + 1] = hbase[v] + ((hs[2 * v] + 3) & ~(i64)3);  // 16-byte aligned streams
-            hpkt[v + 1] = hpkt[v] + hs[2 * v + 1];
-        }
-        DevBuf<i64> dbase, dpkt;
-        dbase.upload(hbase.data(), hbase.size());
-        dpkt.upload(hpkt.data(), hpkt.size());
-        f.tall_dir.emplace_back((size_t)hpkt[Vp] * 8);
-        f.tall_pay.emplace_back((size_t)hbase[Vp] + 64);
-        DevBuf<unsigned int> &dir = f.tall_dir.back(), &pay = f.tall_pay.back();
-        double *vals = nullptr;
-        if (!dict) { f.tall_val.emplace_back((size_t)hbase[Vp] + 64); vals = f.tall_val.back().p; }
-        f.tall_bytes += (dir.n + pay.n) * sizeof(unsigned int) + (vals ? (pay.n * sizeof(double)) : 0);
-        if (dict) tall_launch_build<true>(true, (unsigned)Vp, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, nullptr, dbase.p, dpkt.p,
-                                          reinterpret_cast<TallPkt *>(dir.p), pay.p, nullptr);
-        else tall_launch_build<false>(true, (unsigned)Vp, R, T, S, ncolF, sorted.p, svals.p, cellptr.p, nullptr, dbase.p, dpkt.p,
-                                      reinterpret_cast<TallPkt *>(dir.p), pay.p, vals);
-        for (i64 v = 0; v < Vp; ++v) {
-            TallWg &w = wg[(size_t)(bb0 * S + v)];
-            w.dir = dir.p + hpkt[v] * 8;
-            w.pay = pay.p + hbase[v];
-            w.val = vals ? vals + hbase[v] : nullptr;
-            w.npk = hpkt[v + 1] - hpkt[v];
-        }
-        SLP_HIP(hipStreamSynchronize(st));  // the pass's temporaries go back to the allocator
+        int hbad = 0;
+        bad.download(&hbad, 1);
+        if (hbad || done != a.nnz) return false;  // unsorted rows (or a value outside the dictionary)
+    }
+    DevBuf<i64> cellptr((size_t)ncell + 1);
+    hipLaunchKernelGGL(k_tall_cellptr, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, ncell, sorted.p, cellptr.p);
+    SLP_HIP(hipGetLastError());
+    Phase p2("  tall: packets (sizes + fill)");
+    DevBuf<i64> sizes(2 * (size_t)V);
+    if (dict) tall_launch_build<true>(false, (unsigned)V, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, sizes.p, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else tall_launch_build<false>(false, (unsigned)V, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, sizes.p, nullptr, nullptr, nullptr, nullptr, nullptr);
+    std::vector<i64> hs(2 * (size_t)V), hbase((size_t)V + 1), hpkt((size_t)V + 1);
+    sizes.download(hs.data(), hs.size());
+    const i64 limit = dict ? ((i64)1 << 28) : ((i64)1 << 27);  // payload words of one workgroup (32-bit byte offsets; fp64: 2 x)
+    hbase[0] = hpkt[0] = 0;
+    for (i64 v = 0; v < V; ++v) {
+        if (hs[2 * v] >= limit) return false;  // a workgroup's payload outgrows its 32-bit byte offsets: another format serves
+        hbase[v + 1] = hbase[v] + ((hs[2 * v] + 3) & ~(i64)3);  // 16-byte aligned streams
+        hpkt[v + 1] = hpkt[v] + hs[2 * v + 1];
+    }
+    DevBuf<i64> dbase, dpkt;
+    dbase.upload(hbase.data(), hbase.size());
+    dpkt.upload(hpkt.data(), hpkt.size());
+    f.tall_dir.emplace_back((size_t)hpkt[V] * 8);
+    f.tall_pay.emplace_back((size_t)hbase[V] + 64);
+    DevBuf<unsigned int> &dir = f.tall_dir.back(), &pay = f.tall_pay.back();
+    double *vals = nullptr;
+    if (!dict) { f.tall_val.emplace_back((size_t)hbase[V] + 64); vals = f.tall_val.back().p; }
+    if (dict) tall_launch_build<true>(true, (unsigned)V, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, nullptr, dbase.p, dpkt.p,
+                                      reinterpret_cast<TallPkt *>(dir.p), pay.p, nullptr);
+    else tall_launch_build<false>(true, (unsigned)V, R, T, S, ncolF, sorted.p, svals.p, cellptr.p, nullptr, dbase.p, dpkt.p,
+                                  reinterpret_cast<TallPkt *>(dir.p), pay.p, vals);
+    std::vector<TallWg> wg((size_t)V);
+    for (i64 v = 0; v < V; ++v) {
+        wg[(size_t)v].dir = dir.p + hpkt[v] * 8;
+        wg[(size_t)v].pay = pay.p + hbase[v];
+        wg[(size_t)v].val = vals ? vals + hbase[v] : nullptr;
+        wg[(size_t)v].npk = hpkt[v + 1] - hpkt[v];
     }
     f.tall_wg.upload(wg.data(), wg.size());
-    f.tall_bytes += wg.size() * sizeof(TallWg) + (dict ? (size_t)dict->D * sizeof(double) : 0);
+    SLP_HIP(hipStreamSynchronize(st));
+    f.tall_bytes = (dir.n + pay.n) * sizeof(unsigned int) + (vals ? pay.n * sizeof(double) : 0) + wg.size() * sizeof(TallWg) +
+                   (dict ? (size_t)dict->D * sizeof(double) : 0);
     f.nrow = nrowF; f.ncol = ncolF; f.nnz = a.nnz; f.T = T; f.B = B; f.C = kTallC; f.rpl = 1;
     f.D = dict ? dict->D : 0;
     f.dict = dict ? dict->values.p : nullptr;

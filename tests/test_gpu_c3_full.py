@@ -132,73 +132,86 @@ def test_c3_solver_runs_are_deterministic_and_match_the_recorded_convergence(c3)
     assert abs(float(np.max(a.matvec(x) - b)) - viol) <= 1e-6 * (1 + viol)
 
 
-def test_more_than_2_31_stored_entries():
+@pytest.fixture(scope="module")
+def c4slice():
     """The 1/8 row slice of a 1e7-variable, density-1e-4 LP (BASELINE config 4's per-rank shape at a density that fits):
-    2.5e6 x 1e7, ~2.5e9 stored entries (> 2^31: every entry offset is 64-bit).  Tall cells (csrc/slp_tall.hip) in both
-    orientations vs the thread-per-row CSR kernel bit for bit, the oracle on row slices of both orientations, the adjoint
-    identity; then the WHOLE SOLVERS on this slice against the CPU oracle (Chambolle-Pock bit for bit, matrix-free ADMM
-    1e-9 / 1e-6 in the objective) when the host has the memory for the oracle's copies."""
+    2.5e6 x 1e7, ~2.5e9 stored entries (> 2^31: every entry offset is 64-bit)."""
+    from pysparselp_amd.device import DeviceMatrix
+
+    a = DeviceMatrix.random(C4S_ROWS, C4S_N, C4S_DENSITY, C4S_SEED, 0)
+    yield a
+    a.close()
+
+
+C4S_N, C4S_ROWS, C4S_DENSITY, C4S_SEED = 10_000_000, 2_500_000, 1e-4, 1
+
+
+def test_more_than_2_31_stored_entries(c4slice):
+    """Tall cells (csrc/slp_tall.hip) in both orientations vs the thread-per-row CSR kernel bit for bit, the oracle on row
+    slices of both orientations, the adjoint identity."""
+    a, n, rows = c4slice, C4S_N, C4S_ROWS
+    assert a.nnz > 2 ** 31
+    rng = np.random.RandomState(6)
+    x, y = rng.randn(n), rng.randn(rows)
+    assert a.spmv_kernel(False) == 6 and a.spmv_kernel(True) == 6
+    ax, aty = a.matvec(x, order=1), a.rmatvec(y, order=1)
+    a.set_format(2)
+    assert np.array_equal(a.matvec(x, order=1), ax)
+    assert np.array_equal(a.rmatvec(y, order=1), aty)
+    lhs, rhs = float(ax.dot(y)), float(x.dot(aty))
+    assert abs(lhs - rhs) <= 1e-10 * (abs(lhs) + np.linalg.norm(ax) * np.linalg.norm(y))
+    for r0 in (0, rows - 1024):  # the last rows sit behind offset 2^31
+        sl = a.download_rows(r0, 1024)
+        assert np.array_equal(oracle.matvec(oracle.as_csr(sl), x), ax[r0:r0 + 1024])
+    for c0 in (0, n - 4096):
+        sl = a.download_rows(c0, 4096, transposed=True)
+        assert np.array_equal(oracle.matvec(oracle.as_csr(sl), y), aty[c0:c0 + 4096])
+    a.set_format(0)
+
+
+def test_c4slice_whole_solvers_match_the_cpu_oracle_at_full_size(c4slice):
+    """The per-rank solvers of config 4 on the FULL slice against the oracle on the downloaded matrix: Chambolle-Pock bit for
+    bit, matrix-free ADMM 1e-9 / 1e-6 in the objective.  Skips (visibly) when the host lacks the memory for the oracle's
+    copies."""
     import time
 
     from pysparselp_amd.admm_cg import DeviceADMM
-    from pysparselp_amd.device import DeviceMatrix
     from pysparselp_amd.scale import DeviceCP
 
-    n, rows, dens, seed = 10_000_000, 2_500_000, 1e-4, 1
-    a = DeviceMatrix.random(rows, n, dens, seed, 0)
+    if _mem_available_gb() < 300:
+        pytest.skip("less than 300 GB of host memory available for the oracle's copies of the 2.5e9-entry slice")
+    a, n, rows, dens, seed = c4slice, C4S_N, C4S_ROWS, C4S_DENSITY, C4S_SEED
+    a.set_format(0)
+    xf, c, lb, ub, b = a.random_lp_vectors(dens, seed, 0)
+    record = {"n": n, "rows": rows, "stored_entries": a.nnz, "oracle_threads": min(64, os.cpu_count() or 1)}
+    oracle.set_threads(record["oracle_threads"])
     try:
-        assert a.nnz > 2 ** 31
-        rng = np.random.RandomState(6)
-        x, y = rng.randn(n), rng.randn(rows)
+        host = oracle.as_csr(a.download())
+        stamps = []
+        x_cpu, _ = oracle.chambolle_pock_ppd(c, None, None, host, None, b, lb, ub, nb_max_iter=3, nb_iter_plot=10 ** 9,
+                                             iterate_hook=lambda *_: stamps.append(time.perf_counter()))
+        record["chambolle_pock_oracle_seconds_per_iteration"] = float(np.mean(np.diff(stamps)))
+        host._csc = None
+        s = DeviceCP(a, b, c, lb, ub)
+        s.iterate(3)
+        assert np.array_equal(s.x(), x_cpu)
+        s.close()
+        x_cpu = oracle.lp_admm_cg(c, None, None, host, None, b, lb, ub, nb_iter=2, nb_iter_plot=10 ** 9)
+        del host
+        s = DeviceADMM(a, b, c, lb, ub)
         assert a.spmv_kernel(False) == 6 and a.spmv_kernel(True) == 6
-        ax, aty = a.matvec(x, order=1), a.rmatvec(y, order=1)
-        a.set_format(2)
-        assert np.array_equal(a.matvec(x, order=1), ax)
-        assert np.array_equal(a.rmatvec(y, order=1), aty)
-        lhs, rhs = float(ax.dot(y)), float(x.dot(aty))
-        assert abs(lhs - rhs) <= 1e-10 * (abs(lhs) + np.linalg.norm(ax) * np.linalg.norm(y))
-        for r0 in (0, rows - 1024):  # the last rows sit behind offset 2^31
-            sl = a.download_rows(r0, 1024)
-            assert np.array_equal(oracle.matvec(oracle.as_csr(sl), x), ax[r0:r0 + 1024])
-        for c0 in (0, n - 4096):
-            sl = a.download_rows(c0, 4096, transposed=True)
-            assert np.array_equal(oracle.matvec(oracle.as_csr(sl), y), aty[c0:c0 + 4096])
-        a.set_format(0)
-        if _mem_available_gb() < 300:
-            return
-        # ---- the per-rank solver of config 4 on this slice, against the oracle on the downloaded matrix
-        xf, c, lb, ub, b = a.random_lp_vectors(dens, seed, 0)
-        record = {"n": n, "rows": rows, "stored_entries": a.nnz, "oracle_threads": min(64, os.cpu_count() or 1)}
-        oracle.set_threads(record["oracle_threads"])
-        try:
-            host = oracle.as_csr(a.download())
-            stamps = []
-            x_cpu, _ = oracle.chambolle_pock_ppd(c, None, None, host, None, b, lb, ub, nb_max_iter=3, nb_iter_plot=10 ** 9,
-                                                 iterate_hook=lambda *_: stamps.append(time.perf_counter()))
-            record["chambolle_pock_oracle_seconds_per_iteration"] = float(np.mean(np.diff(stamps)))
-            host._csc = None
-            s = DeviceCP(a, b, c, lb, ub)
-            s.iterate(3)
-            assert np.array_equal(s.x(), x_cpu)
-            s.close()
-            x_cpu = oracle.lp_admm_cg(c, None, None, host, None, b, lb, ub, nb_iter=2, nb_iter_plot=10 ** 9)
-            del host
-            s = DeviceADMM(a, b, c, lb, ub)
-            assert a.spmv_kernel(False) == 6 and a.spmv_kernel(True) == 6
-            s.iterate(3)
-            x_gpu = s.x(n)
-            s.close()
-            err = float(np.max(np.abs(x_gpu - x_cpu) / (1 + np.abs(x_cpu))))
-            record["admm_max_scaled_error"] = err
-            assert err <= 1e-9, err
-            assert abs(float(c.dot(x_gpu)) - float(c.dot(x_cpu))) <= 1e-6 * abs(float(c.dot(x_cpu)))
-        finally:
-            oracle.set_threads(1)
-        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(REPO, "gpurun_out", "c4slice_oracle_parity.json"), "w") as f:
-            json.dump(record, f, indent=1)
+        s.iterate(3)
+        x_gpu = s.x(n)
+        s.close()
+        err = float(np.max(np.abs(x_gpu - x_cpu) / (1 + np.abs(x_cpu))))
+        record["admm_max_scaled_error"] = err
+        assert err <= 1e-9, err
+        assert abs(float(c.dot(x_gpu)) - float(c.dot(x_cpu))) <= 1e-6 * abs(float(c.dot(x_cpu)))
     finally:
-        a.close()
+        oracle.set_threads(1)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "c4slice_oracle_parity.json"), "w") as f:
+        json.dump(record, f, indent=1)
 
 
 def _mem_available_gb():
