@@ -5,12 +5,17 @@
 One "step" = one solver iteration (all SpMV / SpMV^T passes, projections and
 multiplier updates of that iteration) on the synthetic random LP of
 randomLP.py:29-75, generated on the GPU and resident in HBM before the timed
-region.  N = 1 runs BASELINE.json config 3 (1e6 variables, 2e6 inequality
-rows, density 1e-3: 2e9 stored entries) -- config 4 (1e7 x 2e7 at 1e-3 =
-2.4 TB of CSR) does not fit 8 x 288 GB, see DESIGN.md.  N > 1 row-partitions
-the SAME problem over the N GPUs (strong scaling, one RCCL all-reduce of the n
-partial column sums per SpMV^T); launched by the driver as
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
+region.  The default workload is the LP BASELINE.json's metric names: 1e7
+variables x 2e7 inequality rows (config 4) at the density that fits one node,
+1e-4 (2e10 stored entries; the 1e-3 of config 4 is 2.4 TB of CSR, more than
+8 x 288 GB) -- resident on ONE GPU because every rank's row block is generated,
+converted and released in row chunks (ChunkedDeviceMatrix: the CSR of the whole
+block never exists).  N > 1 row-partitions the SAME problem over the N GPUs
+(strong scaling, one RCCL all-reduce of the n partial column sums per SpMV^T);
+launched by the driver as ``python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N``.  ``--config c3`` runs BASELINE config 3 (1e6 x 2e6 at
+1e-3, the headline of rounds 1-3); at N = 1 the default run appends it as
+``secondary.c3`` (same code path, a few seconds).
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
 
@@ -84,9 +89,10 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     # (--vars / --rows: spellings that torch.distributed.run's own parser does not mistake for abbreviations of its options)
-    p.add_argument("--n", "--vars", dest="n", type=int, default=1_000_000, help="variables")
-    p.add_argument("--m", "--rows", dest="m", type=int, default=2_000_000, help="inequality constraints")
-    p.add_argument("--density", type=float, default=1e-3)
+    p.add_argument("--n", "--vars", dest="n", type=int, default=None, help="variables (default: config c4)")
+    p.add_argument("--m", "--rows", dest="m", type=int, default=None, help="inequality constraints")
+    p.add_argument("--density", type=float, default=None)
+    p.add_argument("--no-secondary", action="store_true", help="skip the config-3 block the default N = 1 run appends")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--method", default="admm", choices=["admm", "chambolle_pock_ppd", "admm_blocks"])
     p.add_argument("--eq-frac", type=float, default=0.0,
@@ -105,8 +111,12 @@ def parse():
     p.add_argument("--format", type=int, default=0, choices=[0, 1, 2],
                    help="slp_matrix_set_format policy of the timed run: 0 best available, 1 no value dictionary, 2 CSR kernels")
     args = p.parse_args()
-    if args.config:
-        args.n, args.m, args.density = CONFIGS[args.config]
+    args.default_workload = args.config is None and args.n is None and args.m is None and args.density is None
+    if args.config or args.default_workload:
+        args.n, args.m, args.density = CONFIGS[args.config or "c4"]
+    else:  # free shape: what is not given comes from config 3
+        d = CONFIGS["c3"]
+        args.n, args.m, args.density = args.n or d[0], args.m or d[1], args.density or d[2]
     return args
 
 
@@ -284,7 +294,28 @@ def main():
         from pysparselp_amd.parallel import init_comm_from_env
 
         init_comm_from_env(rank, world)
+    out = run_workload(lib, args, rank, world, distributed)
+    if rank == 0:
+        if world == 1 and args.default_workload and not args.no_secondary and args.method != "admm_blocks":
+            # BASELINE config 3 through the same code: the headline workload of rounds 1-3, for continuity
+            import copy
 
+            a3 = copy.copy(args)
+            a3.n, a3.m, a3.density = CONFIGS["c3"]
+            a3.chunks = 0
+            a3.no_cpu_baseline = True
+            sec = run_workload(lib, a3, rank, world, distributed)
+            out["secondary"] = {"c3": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "objective_after_run",
+                                                           "setup_seconds", "setup_breakdown", "device_memory")}}
+        print(json.dumps(out), flush=True)
+    if distributed:
+        _lib.check(lib.slp_comm_barrier())
+        _lib.check(lib.slp_comm_finalize())
+
+
+def run_workload(lib, args, rank, world, distributed):
+    """Generates this rank's row block of the LP ``args`` names, sets the solver up, times ``args.steps`` iterations between two
+    barriers; rank 0 returns the JSON line's dict (the other ranks ``None``).  Everything is released before returning."""
     # ---- the workload: this rank's row block, generated in HBM
     from pysparselp_amd.parallel import row_block
 
@@ -343,6 +374,7 @@ def main():
     nnz_total = int(nnz[0])
     obj = solver.objective()
 
+    out = None
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
         ax, which = spmv_block(lib, a, False, shape)
@@ -423,15 +455,14 @@ def main():
             # bench time even on the sample; tools/bench_blocks.py times the LU form on the Potts LP instead)
             a.close()
             a = None
+            _lib.check(lib.slp_trim())
             out["cpu_baseline"] = cpu_baseline(args, args.method)
-        print(json.dumps(out), flush=True)
     if solver is not None:
         solver.close()
     if a is not None:
         a.close()
-    if distributed:
-        _lib.check(lib.slp_comm_barrier())
-        _lib.check(lib.slp_comm_finalize())
+    _lib.check(lib.slp_trim())
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

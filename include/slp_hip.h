@@ -340,6 +340,11 @@ int slp_blocks_group_link(slp_blocks **blocks, int count);
 int slp_blocks_group_iterate(slp_blocks **blocks, int count, int64_t k);
 void slp_blocks_destroy(slp_blocks *s);
 int slp_blocks_set_cg(slp_blocks *s, double tol, int max_steps);
+/* How well the last block update of a solver from slp_blocks_create_on projected: out[0] = || rhs - S sol ||_2 of its
+ * projection system with the operator applied afresh (not the conjugate-gradient recurrence), out[1] = || rhs ||_2; the
+ * bar of slp_blocks_set_cg is out[0] <= tol * out[1].  (In the dual form rhs - S nu IS the constraint residual A z - z_s - b
+ * of the projected point.)  Costs two products; for tests and diagnostics. */
+int slp_blocks_projection_residual(slp_blocks *s, double out[2]);
 /* Jacobi (diagonal) preconditioner for the per-block conjugate gradients of a solver from slp_blocks_create_on
  * (1 = on).  Same projection up to the CG tolerance; measured: no fewer steps on the benchmark LPs, whose systems have an
  * essentially constant diagonal -- an option for badly scaled constraint matrices. */
@@ -395,6 +400,10 @@ int slp_comm_barrier(void);
 /* All-reduces this process has issued since slp_comm_init (0 without a communicator): the data-path exchange steps
  * can be counted per iteration (Chambolle-Pock 1, matrix-free ADMM at reuse level 4: 2, block-splitting ADMM 1). */
 long long slp_comm_collectives(void);
+/* The communicator of this process: *nranks / *rank (1 / 0 without one); returns 1 when slp_comm_init* is active, else 0.
+ * The host-API solvers (SparseLP.solve -> lp_admm(xstep="cg") / chambolle_pock_ppd) consult it: under a communicator every
+ * rank holds the whole LP, hands over only its row block (equal stored entries) and returns the same x. */
+int slp_comm_info(int *nranks, int *rank);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,16 @@ class CPState:
         b = _lib.f64(np.concatenate(parts_b) if parts_b else np.zeros(0))
         if indices.size and (indices.min() < 0 or indices.max() >= self.n):
             raise ValueError("constraint matrix has a column index outside [0, n)")
+        # under a communicator (parallel.init_comm_from_env): every rank holds the LP and hands over only its block of the
+        # stacked rows K = [A_eq; A_ineq]; x, c, T, lb, ub are replicated, one all-reduce of n doubles per iteration
+        from .parallel import local_rows
+
+        r0, r1, m_eq_local = local_rows(indptr, self.m_eq)
+        if (r0, r1) != (0, indptr.size - 1):
+            k0, k1 = int(indptr[r0]), int(indptr[r1])
+            indptr = np.ascontiguousarray(indptr[r0:r1 + 1] - k0)
+            indices, data, b = np.ascontiguousarray(indices[k0:k1]), np.ascontiguousarray(data[k0:k1]), np.ascontiguousarray(b[r0:r1])
+            self.m_eq, self.m_ineq = m_eq_local, (r1 - r0) - m_eq_local
         x0 = _lib.f64(x0) if x0 is not None else None
         self._h = _lib.check_handle(self._l.slp_cp_create(
             self.n, self.m_eq, self.m_ineq, _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(data), _lib.ptr(b),

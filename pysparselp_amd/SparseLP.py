@@ -74,6 +74,9 @@ def crd_matrix(cols, vals):
     return scipy.sparse.csr_matrix((vals[keep], cols[keep], indptr), shape=(cols.shape[0], ncols))
 
 
+ADMM_AUTO_M_ENTRIES = 2.0e8  # solve(method="admm", xstep="auto"): above this estimate of nnz(M) the matrix-free x-step is taken
+
+
 class SparseLP:
     """Sparse linear program + first-order GPU solvers."""
 
@@ -260,7 +263,7 @@ class SparseLP:
         return bool(self.max_constraint_violation(solution) < tol)
 
     # ------------------------------------------------------------------------- I/O
-    def save_mps(self, filename):
+    def save_mps(self, filename, exact=True):
         """Write the LP as an MPS file (reference SparseLP.py:280-366: objective row ``OBJ``, equality rows ``E<i>``,
         inequality rows ``I<i>``, variables ``X<j>``, right-hand-side set ``RHS0``, bound set ``bound``).
 
@@ -268,7 +271,9 @@ class SparseLP:
         decimals: numbers are written with 17 significant digits, so that reading the file back
         (``MPSparser.mps_parser``) returns the arrays bit for bit; two-sided and lower-bounded inequality rows are written
         (``G`` rows, ``RANGES`` -- the reference asserts ``b_lower is None``); bounds are written only where they differ
-        from the MPS default ``[0, +inf)``.  Integer variables are refused (the reader refuses them too)."""
+        from the MPS default ``[0, +inf)``.  Integer variables are refused (the reader refuses them too).  A two-sided row
+        whose bounds neither ``rhs - range`` nor ``rhs + range`` reproduces in fp64 raises ``ValueError`` (``exact=False``:
+        written in the L form, its lower bound then comes back within one ulp)."""
         if np.any(self.is_integer):
             raise NotImplementedError("save_mps: integer variables are not supported")
         n = self.nb_variables
@@ -291,7 +296,14 @@ class SparseLP:
             g_row = ~np.isfinite(up)
             both = np.isfinite(up) & np.isfinite(lo)
             with np.errstate(invalid="ignore"):
-                g_row |= both & (up - (up - lo) != lo) & (lo + (up - lo) == up)
+                l_exact, g_exact = up - (up - lo) == lo, lo + (up - lo) == up
+            g_row |= both & ~l_exact & g_exact
+            if exact and np.any(both & ~l_exact & ~g_exact):
+                # neither rhs - range nor rhs + range gives the other bound back in fp64: the file could not return the arrays bit
+                # for bit (the promise above), so refuse instead of writing a bound that is off by an ulp
+                bad = int(np.nonzero(both & ~l_exact & ~g_exact)[0][0])
+                raise ValueError("save_mps: the two bounds of inequality row %d cannot be written exactly as a right-hand side and a "
+                                 "range; split it into an upper-bounded and a lower-bounded row, or pass exact=False" % bad)
             for i in range(m_in):
                 f.write(" %s  I%d\n" % ("G" if g_row[i] else "L", i))
             f.write("COLUMNS\n")
@@ -341,8 +353,23 @@ class SparseLP:
         ground_truth=None,
         ground_truth_indices=None,
         order=ORDER_AUTO,
+        xstep="gauss_seidel",
     ):
         """Run a first-order solver on the GPU; returns ``(x, elapsed)`` or ``x``.
+
+        Extensions (keyword-only in spirit; the reference's positional arguments are unchanged): ``order`` -- summation
+        order of the dot products (include/slp_hip.h); ``xstep`` for ``method="admm"`` -- ``"gauss_seidel"`` is the
+        reference as shipped (one projected Gauss-Seidel sweep on the explicit ``M = 2 A^T A + 3 I``, ADMM.py:162),
+        ``"cg"`` its conjugate-gradient branch (ADMM.py:182-201) run matrix-free -- the ADMM that exists where ``M`` cannot
+        (1000 entries per row: ``M`` is dense) and the one that shards over several GPUs -- and ``"auto"`` picks ``"cg"``
+        when the standard-form rows promise more than ``ADMM_AUTO_M_ENTRIES`` (2e8) entries in ``M`` (sum of squared row
+        lengths) or a communicator is active (the sequential sweep does not partition), else ``"gauss_seidel"``.
+
+        Under a communicator (``parallel.init_comm_from_env`` in every rank of a ``torch.distributed.run`` / ``mpirun``
+        launch) every rank calls ``solve`` on the same LP: ``"chambolle_pock_ppd"`` and ``"admm"`` with ``xstep="cg"`` hand
+        over only this rank's block of constraint rows (equal stored entries per rank), exchange one / two all-reduces of
+        the variable vector per iteration and return the same ``x`` on every rank; the exact Gauss-Seidel ADMM and
+        ``admm_blocks`` run as replicas.
 
         Fills, at every report (every ``nb_iter_plot`` iterations): ``itrn_curve,
         opttime_curve, dopttime_curve, pobj_curve, dobj_curve,
@@ -380,9 +407,17 @@ class SparseLP:
                 plot_solution(niter, solution, is_active_variable=None)
 
         if method == "admm":
+            if xstep == "auto":
+                from .parallel import comm_world
+
+                rows_sq = 0.0
+                for blk, slack in ((a_eq, 0), (a_ineq, 1)):
+                    if blk is not None:
+                        rows_sq += float(np.sum((np.diff(blk.indptr).astype(np.float64) + slack) ** 2))
+                xstep = "cg" if (rows_sq > ADMM_AUTO_M_ENTRIES or comm_world()[0] > 1) else "gauss_seidel"
             x = lp_admm(self.costsvector, a_eq, b_eq, a_ineq, self.b_lower, self.b_upper, self.lower_bounds,
                         self.upper_bounds, nb_iter=nb_iter, x0=x0, callback_func=record, max_time=max_time,
-                        nb_iter_plot=nb_iter_plot, order=order)
+                        nb_iter_plot=nb_iter_plot, order=order, xstep=xstep)
         elif method == "admm_blocks":  # reference :1210-1225
             from .ADMMBlocks import lp_admm_block_decomposition
 

@@ -97,6 +97,7 @@ _SIGNATURES = {
     "slp_blocks_group_link": (c_int, [c_vp, c_int]),
     "slp_blocks_group_iterate": (c_int, [c_vp, c_int, c_i64]),
     "slp_blocks_destroy": (None, [c_vp]),
+    "slp_blocks_projection_residual": (c_int, [c_vp, c_vp]),
     "slp_blocks_set_cg": (c_int, [c_vp, c_dbl, c_int]),
     "slp_blocks_set_precond": (c_int, [c_vp, c_int]),
     "slp_blocks_iterate": (c_int, [c_vp, c_i64]),
@@ -119,6 +120,7 @@ _SIGNATURES = {
     "slp_comm_finalize": (c_int, []),
     "slp_comm_allreduce_host": (c_int, [c_vp, c_i64, c_int]),
     "slp_comm_barrier": (c_int, []),
+    "slp_comm_info": (c_int, [c_vp, c_vp]),
     "slp_comm_collectives": (ctypes.c_longlong, []),
 }
 

@@ -128,6 +128,17 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
     c2, a, b, lb2, ub2, x_init = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
     if use_preconditioning:
         a, b = precondition_constraints(a, b, alpha=2)
+    # under a communicator (parallel.init_comm_from_env): every rank ran the (cheap, deterministic) transforms above on the
+    # whole LP and hands over only its block of the standard-form rows; the N unknowns are replicated
+    from .parallel import local_rows
+
+    r0, r1, _ = local_rows(a.indptr)
+    if (r0, r1) != (0, a.shape[0]):
+        from .tools import CsrArrays
+
+        k0, k1 = int(a.indptr[r0]), int(a.indptr[r1])
+        a = CsrArrays(np.asarray(a.indptr[r0:r1 + 1]) - k0, a.indices[k0:k1], a.data[k0:k1], (r1 - r0, a.shape[1]))
+        b = np.ascontiguousarray(b[r0:r1])
     state = ADMMCGState(a, b, c2, lb2, ub2, x_init, gamma_eq, gamma_ineq, order)
     state.set_reuse(reuse)
     try:

@@ -363,7 +363,10 @@ __device__ __forceinline__ double gs_lane_up(double v) {
 // lane loads its row record, every lane stores (lanes that do not finish a row: to a scratch cell), and a wave that has no
 // wave slot in a level repeats the level's first one (same inputs, same results, same addresses: harmless).  FAR = false is
 // the instantiation for plans without far entries.
-template <bool BOUNDED, bool FAR, bool BANDS>
+// SAFE (bands only; SLP_GS_BANDS_SAFE=1 when the solver is created): a wave waits for its result stores themselves
+// (s_waitcnt vmcnt(0)) before it publishes a level as stored, instead of relying on the in-order completion of its
+// vector-memory operations -- see "stored" below and DESIGN.md section 3 (precondition of the default form).
+template <bool BOUNDED, bool FAR, bool BANDS, bool SAFE = false>
 __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *__restrict__ hoff, const GsStepW *__restrict__ hdr,
                                                                     const GsLane *__restrict__ lanes, const i32 *__restrict__ lane_row,
                                                                     const GsDyn *__restrict__ dyn, const GsEnt *__restrict__ ents,
@@ -547,9 +550,10 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
                 // this wave slot's lane record has arrived, so the stores of wave slot s - 6 and before are in the L2: `stored`
                 // (from the plan) counts the levels that completes; the empty asm keeps the write behind the record's arrival
                 int stored = (int)(meta >> 8), dep = me.info;
-#ifdef SLP_GS_BANDS_SAFE  // lab build (with SLP_GS_BANDS_LAG=0): wait for the store itself
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+                // PRECONDITION of this form: a wave's vector-memory operations complete in issue order (loads, stores and atomics
+                // count together in vmcnt: MI355X_MICROARCH.md, "s_waitcnt vmcnt(N)").  SAFE does not rely on it: the plan then
+                // counts the levels up to THIS wave slot (lag 0) and the wave drains its stores before saying so.
+                if (SAFE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(stored) : "v"(dep));
                 if (lane == 0) progw[wave] = stored;
             }
@@ -625,6 +629,7 @@ struct GsPlan {
     mutable DevBuf<double> scratch;   // where lanes that do not finish a row store
     mutable DevBuf<double> xpos;      // the windowed kernel's results, by row position
     mutable DevBuf<GsRow> packed;     // per row position, refreshed before every sweep
+    bool bands_safe = false;          // SLP_GS_BANDS_SAFE=1 at plan time: headers count the levels up to their own wave slot, SAFE kernels
     int nbands = 0;                   // band records over all runs with bands (0: none)
     DevBuf<GsBand> bands;
     DevBuf<i32> fsrc;                 // the fetch waves' read positions
@@ -637,6 +642,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
     SLP_REQUIRE(n < (i64)1 << 31, "gauss-seidel: dimension must fit int32");
     g.n = n;
     g.nnz = indptr[n];
+    { const char *es = getenv("SLP_GS_BANDS_SAFE"); g.bands_safe = es && es[0] == '1'; }
     const auto plan_t0 = std::chrono::steady_clock::now();
     auto plan_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - plan_t0).count(); };
     double ms_levels = 0, ms_bands = 0;
@@ -1008,8 +1014,8 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                     done[(size_t)wv].push_back((int)lv.size());
                 }
                 if (with_stored) {
-                    const char *el = getenv("SLP_GS_BANDS_LAG");  // lab only (see SLP_GS_BANDS_SAFE)
-                    const size_t lag = el ? (size_t)atoi(el) : 6;
+                    const char *el = getenv("SLP_GS_BANDS_LAG");  // lab only
+                    const size_t lag = g.bands_safe ? 0 : (el ? (size_t)atoi(el) : 6);
                     for (size_t k = 0; k < per[(size_t)wv].size(); ++k)
                         per[(size_t)wv][k].meta = (per[(size_t)wv][k].meta & 0xffu) | ((unsigned)(k >= lag ? done[(size_t)wv][k - lag] : 0) << 8);
                 }
@@ -1301,7 +1307,12 @@ static void gs_sweep(const GsPlan &g, const double *b, const double *lo, const d
                         const i64 t0 = g.lptr[(size_t)sg.level_first], t1 = g.lptr[(size_t)(sg.level_first + sg.level_count)];
                         hipLaunchKernelGGL(k_gs_unpack, dim3(grid_for(t1 - t0, kBlock)), dim3(kBlock), 0, st, t0, t1 - t0, g.rows.p, g.xpos.p, x);
                     };
-                    if (sg.bands) {
+                    if (sg.bands && g.bands_safe) {
+                        if (bounded && g.has_far) run(k_gs_sweep_windowed<true, true, true, true>);
+                        else if (bounded) run(k_gs_sweep_windowed<true, false, true, true>);
+                        else if (g.has_far) run(k_gs_sweep_windowed<false, true, true, true>);
+                        else run(k_gs_sweep_windowed<false, false, true, true>);
+                    } else if (sg.bands) {
                         if (bounded && g.has_far) run(k_gs_sweep_windowed<true, true, true>);
                         else if (bounded) run(k_gs_sweep_windowed<true, false, true>);
                         else if (g.has_far) run(k_gs_sweep_windowed<false, true, true>);

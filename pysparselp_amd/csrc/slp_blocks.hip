@@ -255,6 +255,10 @@ __global__ void k_rb_resid0_primal(i64 n, const double *__restrict__ v, const do
     }
 }
 
+__global__ void k_rb_true_resid(i64 n, const double *__restrict__ rhs, const double *__restrict__ q, double *__restrict__ r) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) r[i] = rhs[i] - q[i];
+}
+
 __global__ void k_rb_add_vec(i64 n, const double *__restrict__ a, double *__restrict__ q) {
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) q[j] = q[j] + a[j];
 }
@@ -568,6 +572,34 @@ void slp_blocks_destroy(slp_blocks *s) {
     if (!s->row_block) delete s->a;
     else --s->a->borrowers;
     delete s;
+}
+
+int slp_blocks_projection_residual(slp_blocks *s, double out[2]) {
+    SLP_API_INT({
+        SLP_REQUIRE(s && out && s->row_block, "slp_blocks_projection_residual: a solver from slp_blocks_create_on");
+        hipStream_t st = ctx().stream;
+        const i64 n = s->N, m = s->m, me = s->m_eq;
+        const i64 len = s->primal ? n : m;
+        if (len == 0) { out[0] = out[1] = 0.0; return 0; }
+        // the TRUE residual of the projection system of the last block update, rhs - S sol, with the operator applied afresh
+        // (the conjugate-gradient loop only ever sees its recurrence)
+        if (s->primal) {
+            matrix_spmv(s->a, false, s->xsol.p, s->w.p, SLP_ORDER_AUTO);
+            matrix_spmv(s->a, true, s->w.p, s->q.p, SLP_ORDER_AUTO);
+            hipLaunchKernelGGL(k_rb_add_vec, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, n, s->xsol.p, s->q.p);
+        } else {
+            blk_apply(s, s->nu.p, s->q.p);
+            if (m > me) hipLaunchKernelGGL(k_rb_add_identity, dim3(grid_for(m - me, kBlock)), dim3(kBlock), 0, st, m, me, s->nu.p, s->q.p);
+        }
+        hipLaunchKernelGGL(k_rb_true_resid, dim3(grid_for(len, kBlock)), dim3(kBlock), 0, st, len, s->rhs.p, s->q.p, s->r.p);
+        SLP_HIP(hipGetLastError());
+        blk_dot(s, len, s->r.p, s->r.p, B_RR, 0);
+        blk_dot(s, len, s->rhs.p, s->rhs.p, B_RHS2, 0);
+        double h[B_COUNT];
+        s->scal.download(h, B_COUNT);
+        out[0] = sqrt(h[B_RR]);
+        out[1] = sqrt(h[B_RHS2]);
+    })
 }
 
 int slp_blocks_set_cg(slp_blocks *s, double tol, int max_steps) {

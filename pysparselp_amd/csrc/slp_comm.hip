@@ -25,7 +25,11 @@
 // and inspect the sequence of collectives.
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 #include <rccl/rccl.h>
 
@@ -54,6 +58,79 @@ static struct {
     unsigned next_ready = 0;
     bool pending = false;
 } g;
+
+// Host transport, asynchronous form (tests: the block groups' overlapped exchange with several ranks on ONE GPU): a worker
+// thread takes the jobs in issue order -- waits for the compute stream to reach the point of the call, copies the buffer out on
+// the second stream, runs the callback, copies the result back -- while the caller goes on enqueueing the next block's
+// projection; comm_join() waits for the queue to drain.  The callback is only ever run by one thread at a time and in the order
+// the all-reduces were issued (synchronous ones drain the queue first), so the ranks' sequences of collectives stay aligned.
+static struct HostWorker {
+    struct Job { double *buf; i64 count; int op; hipEvent_t ready; };
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    int inflight = 0;
+    bool stop = false, running = false;
+    std::string error;
+} hw;
+
+static void host_worker_main(int device) {
+    (void)hipSetDevice(device);
+    std::vector<double> stage;
+    for (;;) {
+        HostWorker::Job job;
+        {
+            std::unique_lock<std::mutex> lk(hw.mu);
+            hw.cv.wait(lk, [] { return hw.stop || !hw.jobs.empty(); });
+            if (hw.jobs.empty()) return;  // stop
+            job = hw.jobs.front();
+            hw.jobs.pop_front();
+        }
+        std::string err;
+        if (stage.size() < (size_t)job.count) stage.resize((size_t)job.count);
+        hipError_t e = hipEventSynchronize(job.ready);
+        if (e == hipSuccess) e = hipMemcpyAsync(stage.data(), job.buf, (size_t)job.count * sizeof(double), hipMemcpyDeviceToHost, g.side);
+        if (e == hipSuccess) e = hipStreamSynchronize(g.side);
+        if (e != hipSuccess) err = std::string("host all-reduce worker: ") + hipGetErrorString(e);
+        else if (g.host_fn(stage.data(), job.count, job.op, g.host_user) != 0) err = "host all-reduce callback failed";
+        else {
+            e = hipMemcpyAsync(job.buf, stage.data(), (size_t)job.count * sizeof(double), hipMemcpyHostToDevice, g.side);
+            if (e == hipSuccess) e = hipStreamSynchronize(g.side);
+            if (e != hipSuccess) err = std::string("host all-reduce worker: ") + hipGetErrorString(e);
+        }
+        {
+            std::lock_guard<std::mutex> lk(hw.mu);
+            if (!err.empty() && hw.error.empty()) hw.error = err;
+            --hw.inflight;
+        }
+        hw.cv.notify_all();
+    }
+}
+
+// waits until every asynchronous host all-reduce issued so far has landed; throws what the worker ran into
+static void host_worker_drain(bool may_throw) {
+    std::string err;
+    {
+        std::unique_lock<std::mutex> lk(hw.mu);
+        hw.cv.wait(lk, [] { return hw.inflight == 0; });
+        err.swap(hw.error);
+    }
+    if (may_throw && !err.empty()) throw Error(err);
+}
+
+static void host_worker_stop() {
+    if (!hw.running) return;
+    host_worker_drain(false);
+    {
+        std::lock_guard<std::mutex> lk(hw.mu);
+        hw.stop = true;
+    }
+    hw.cv.notify_all();
+    hw.th.join();
+    hw.running = false;
+    hw.stop = false;
+}
 
 static void side_stream() {
     if (g.side) return;
@@ -102,6 +179,7 @@ void comm_allreduce_dev(double *buf, i64 count, int op) {
     ++g.collectives;
     hipStream_t st = ctx().stream;
     if (g.host_fn) {
+        if (hw.running) host_worker_drain(true);  // (collectives reach the callback in issue order)
         if (g.host_buf.size() < (size_t)count) g.host_buf.resize((size_t)count);
         SLP_HIP(hipMemcpyAsync(g.host_buf.data(), buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
         SLP_HIP(hipStreamSynchronize(st));
@@ -122,7 +200,26 @@ void comm_allreduce_dev_async(double *buf, i64 count, int op) {
     SLP_REQUIRE(g.active, "slp_comm_init has not been called");
     if (count <= 0) return;
     if (g.host_fn) {
-        comm_allreduce_dev(buf, count, op);
+        const char *sy = getenv("SLP_HOST_ASYNC");  // =0: reduce at once (the transport's first form)
+        if (sy && sy[0] == '0') {
+            comm_allreduce_dev(buf, count, op);
+            return;
+        }
+        ++g.collectives;
+        side_stream();
+        hipEvent_t ev = g.ready[g.next_ready++ % 8];
+        SLP_HIP(hipEventRecord(ev, ctx().stream));
+        if (!hw.running) {
+            hw.th = std::thread(host_worker_main, ctx().device);
+            hw.running = true;
+        }
+        {
+            std::lock_guard<std::mutex> lk(hw.mu);
+            hw.jobs.push_back({buf, count, op, ev});
+            ++hw.inflight;
+        }
+        hw.cv.notify_all();
+        g.pending = true;
         return;
     }
     ++g.collectives;
@@ -137,12 +234,18 @@ void comm_allreduce_dev_async(double *buf, i64 count, int op) {
 // Drains the second stream and forgets pending asynchronous all-reduces (allocator trims, error paths): after this no
 // collective can still be writing a buffer that goes back to the cache or to the driver.
 void comm_sync_side() {
+    if (hw.running) host_worker_drain(false);
     if (g.side) (void)hipStreamSynchronize(g.side);
     g.pending = false;
 }
 
 void comm_join() {
     if (!g.pending) return;
+    if (g.host_fn) {  // the worker has synchronised the second stream behind every copy: nothing left for the compute stream to wait for
+        host_worker_drain(true);
+        g.pending = false;
+        return;
+    }
     SLP_HIP(hipEventRecord(g.done, g.side));
     SLP_HIP(hipStreamWaitEvent(ctx().stream, g.done, 0));
     g.pending = false;
@@ -199,6 +302,7 @@ int slp_comm_init_host(int nranks, int rank, slp_host_allreduce_fn fn, void *use
 int slp_comm_finalize(void) {
     SLP_API_INT({
         if (g.active) {
+            host_worker_stop();
             if (g.side) SLP_HIP(hipStreamSynchronize(g.side));
             SLP_HIP(hipStreamSynchronize(ctx().stream));
             g.scratch.release();
@@ -224,6 +328,12 @@ int slp_comm_allreduce_host(double *v, int64_t count, int op) {
 }
 
 long long slp_comm_collectives(void) { return g.collectives; }
+
+int slp_comm_info(int *nranks, int *rank) {
+    if (nranks) *nranks = g.active ? g.nranks : 1;
+    if (rank) *rank = g.active ? g.rank : 0;
+    return g.active ? 1 : 0;
+}
 
 int slp_comm_barrier(void) {
     SLP_API_INT({

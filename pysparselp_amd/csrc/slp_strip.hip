@@ -364,21 +364,23 @@ __device__ __forceinline__ uint2 ld_stream(const uint2 *p) {
 // ABLATE != 0 is instantiated only in the -DSLP_ABLATION build (timing experiments, wrong results): 1 = no x-tile
 // staging, 2 = no entry streaming
 // POW: every stored value v enters as |v|^pw * 1.0 (the matrix of the Chambolle-Pock preconditioner sums, slp_cp.hip).
-template <int ABLATE, bool NT, bool NT4 = true, bool POW = false>
+template <int ABLATE, bool NT, bool NT4 = true, bool POW = false, bool ACC = false>
 __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                            const unsigned short *__restrict__ perm,
                                                            const unsigned char *__restrict__ slen,
                                                            const unsigned int *__restrict__ soff, const double *__restrict__ val,
                                                            const unsigned short *__restrict__ col, const double *__restrict__ x,
-                                                           double *__restrict__ out, double pw, int accum) {
+                                                           double *__restrict__ out, double pw) {
     __shared__ double xt[kStripC];
     __shared__ double acc[kStripR];
     __shared__ unsigned int offs[kStripSL];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
-    // accum: the running sums start from what `out` holds (a row chunk of a chunked matrix continuing the column sums of
-    // the chunks before it: the chain of additions of the unchunked product); partial-sum mode takes it in the combine
-    const bool cont = accum && gridDim.y == 1;
+    // ACC: the running sums start from what `out` holds (a row chunk of a chunked matrix continuing the column sums of
+    // the chunks before it: the chain of additions of the unchunked product); partial-sum mode takes it in the combine.
+    // (A template parameter: as a run-time flag it cost the dictionary kernels, which sit exactly at their 64 registers,
+    // 7-10 spilled registers and 7-12 % of their speed.)
+    const bool cont = ACC && gridDim.y == 1;
     acc[p] = (cont && b * kStripR + p < nrow) ? out[b * kStripR + p] : 0.0;
     acc[p + kStripT] = (cont && b * kStripR + kStripT + p < nrow) ? out[b * kStripR + kStripT + p] : 0.0;
     // gridDim.y > 1: this workgroup covers only its share of the strips and writes partial sums
@@ -448,13 +450,14 @@ __global__ __launch_bounds__(kStripT, 8) void k_strip_spmv(i64 nrow, i64 ncol, i
 // HBM-sized operand) is streamed once; both x-tiles and both sets of running sums live in LDS (153 KB,
 // one workgroup per CU).  Per row and per vector the additions are the same chain as in k_strip_spmv,
 // so each output is bit-identical to the single-vector product.
+template <bool ACC>
 __global__ __launch_bounds__(kStripT, 4) void k_strip_spmv2(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                             const unsigned short *__restrict__ perm,
                                                             const unsigned char *__restrict__ slen,
                                                             const unsigned int *__restrict__ soff, const double *__restrict__ val,
                                                             const unsigned short *__restrict__ col, const double *__restrict__ x0,
                                                             const double *__restrict__ x1, double *__restrict__ out0,
-                                                            double *__restrict__ out1, int accum) {
+                                                            double *__restrict__ out1) {
     __shared__ double xt0[kStripC];
     __shared__ double xt1[kStripC];
     __shared__ double acc0[kStripR];
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(kStripT, 4) void k_strip_spmv2(i64 nrow, i64 ncol, 
     __shared__ unsigned int offs[kStripSL];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
-    const bool cont = accum && gridDim.y == 1;  // as in k_strip_spmv
+    const bool cont = ACC && gridDim.y == 1;  // as in k_strip_spmv
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const i64 row = b * kStripR + h * kStripT + p;
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(kStripT, 4) void k_strip_spmv2(i64 nrow, i64 ncol, 
 // {id0, id1, col0, col1}; the value is dict[id] read from LDS -- the same fp64 number the CSR holds, so every
 // row sum is still the sequential single-accumulator sum, bit for bit.  NV = 1: 46 KB x-tile + 16 KB sums
 // + 16 KB dictionary + 1 KB offsets = 79 KB (two workgroups per CU); NV = 2: 141 KB (one per CU).
-template <int NV, bool NT>
+template <int NV, bool NT, bool ACC = false>
 __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                                          const unsigned short *__restrict__ perm,
                                                                          const unsigned char *__restrict__ slen,
@@ -544,13 +547,13 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
                                                                          const unsigned short *__restrict__ ent,
                                                                          const double *__restrict__ dict, int D,
                                                                          const double *__restrict__ x0, const double *__restrict__ x1,
-                                                                         double *__restrict__ out0, double *__restrict__ out1, int accum) {
+                                                                         double *__restrict__ out0, double *__restrict__ out1) {
     __shared__ double xt[NV][kDictC];
     __shared__ double acc[NV][kStripR];
     __shared__ double dv[kDictMax];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
-    const bool cont = accum && gridDim.y == 1;  // as in k_strip_spmv
+    const bool cont = ACC && gridDim.y == 1;  // as in k_strip_spmv
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const i64 row = b * kStripR + h * kStripT + p;
@@ -670,7 +673,7 @@ typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
 #ifndef SLP_QUAD_WAVES
 #define SLP_QUAD_WAVES 8  // waves per SIMD the single-vector quad kernel is compiled for (8: two workgroups per CU, 64 VGPRs)
 #endif
-template <int NV, bool NT = false, int ABL = 0>
+template <int NV, bool NT = false, int ABL = 0, bool ACC = false>
 __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                                          const unsigned short *__restrict__ perm,
                                                                          const unsigned char *__restrict__ slen,
@@ -678,13 +681,13 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstri
                                                                          const unsigned short *__restrict__ ent,
                                                                          const double *__restrict__ dict, int D,
                                                                          const double *__restrict__ x0, const double *__restrict__ x1,
-                                                                         double *__restrict__ out0, double *__restrict__ out1, int accum) {
+                                                                         double *__restrict__ out0, double *__restrict__ out1) {
     __shared__ double xt[NV][kQuadC];
     __shared__ double acc[NV][kQuadR];
     __shared__ double dv[kDictMax];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
-    const bool cont = accum && gridDim.y == 1;  // as in k_strip_spmv
+    const bool cont = ACC && gridDim.y == 1;  // as in k_strip_spmv
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const i64 row = b * kQuadR + h * kStripT + p;
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstri
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-template <bool DICT>
+template <bool DICT, bool ACC = false>
 __global__ __launch_bounds__(kStripT, 8) void k_wstrip_spmv(i64 nrow, i64 ncol, i64 T, const i64 *__restrict__ base,
                                                             const unsigned short *__restrict__ perm,
                                                             const unsigned char *__restrict__ slen,
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(kStripT, 8) void k_wstrip_spmv(i64 nrow, i64 ncol, 
                                                             const double *__restrict__ val, const unsigned int *__restrict__ col,
                                                             const double *__restrict__ dict, int D, const double *__restrict__ x0,
                                                             const double *__restrict__ x1, double *__restrict__ out0,
-                                                            double *__restrict__ out1, int accum) {
+                                                            double *__restrict__ out1) {
     // one right-hand side per pass: two strips of x would compete for the L2 (a two-vector version measured 50 ms for the
     // pair against 2 x 12.5 ms on the 2.5e6 x 1e7 slice)
     constexpr int NV = 1;
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(kStripT, 8) void k_wstrip_spmv(i64 nrow, i64 ncol, 
     __shared__ double dv[DICT ? kDictMax : 1];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
-    const bool cont = accum && gridDim.y == 1;  // as in k_strip_spmv
+    const bool cont = ACC && gridDim.y == 1;  // as in k_strip_spmv
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const i64 row = b * kStripR + h * kStripT + p;
@@ -1058,16 +1061,23 @@ static bool nt_loads() {  // SLP_NT_LOADS=0 / 1: plain / non-temporal entry load
     return v != 0;
 }
 
+// the kernels take `accum` as a template parameter (see k_strip_spmv): CALL is written in terms of a constexpr bool ACC
+#define SLP_WITH_ACC(accum, CALL)                          \
+    do {                                                   \
+        if (accum) { constexpr bool ACC = true; CALL; }    \
+        else { constexpr bool ACC = false; CALL; }         \
+    } while (0)
+
 static void wide_launch(const StripJds &f, int nv, const double *x0, const double *x1, double *o0, double *o1, int accum) {
     const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
     hipStream_t st = ctx().stream;
     const unsigned int *ent = reinterpret_cast<const unsigned int *>(f.ent.p), *col = reinterpret_cast<const unsigned int *>(f.col.p);
-#define SLP_WIDE(DICT)                                                                                                          \
-    hipLaunchKernelGGL((k_wstrip_spmv<DICT>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, ent, \
-                       f.val.p, col, f.dict, f.D, x0, x1, o0, o1, accum)
+#define SLP_WIDE(DICT)                                                                                                                \
+    hipLaunchKernelGGL((k_wstrip_spmv<DICT, ACC>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, ent, \
+                       f.val.p, col, f.dict, f.D, x0, x1, o0, o1)
     (void)nv;
-    if (f.D > 0) SLP_WIDE(true);
-    else SLP_WIDE(false);
+    if (f.D > 0) SLP_WITH_ACC(accum, SLP_WIDE(true));
+    else SLP_WITH_ACC(accum, SLP_WIDE(false));
 #undef SLP_WIDE
 }
 
@@ -1087,56 +1097,49 @@ static void strip_spmv_one(const StripJds &f, const double *x, double *out, int 
         SLP_HIP(hipGetLastError());
         return;
     }
+    const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
+    hipStream_t st = ctx().stream;
+    double *dst = f.S > 1 ? f.part.p : out;
     if (f.D > 0) {
+#define SLP_QLAUNCH(NT, ABL)                                                                                                      \
+    hipLaunchKernelGGL((k_qstrip_spmv<1, NT, ABL, ACC>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p,    \
+                       f.soff.p, f.ent.p, f.dict, f.D, x, x, dst, (double *)nullptr)
+#define SLP_DLAUNCH(NT)                                                                                                           \
+    hipLaunchKernelGGL((k_dstrip_spmv<1, NT, ACC>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p,         \
+                       f.soff.p, f.ent.p, f.dict, f.D, x, x, dst, (double *)nullptr)
 #ifdef SLP_ABLATION
         if (f.rpl == 4 && getenv("SLP_QSTRIP_ABLATE") && atoi(getenv("SLP_QSTRIP_ABLATE")) > 0) {
             const int ab = atoi(getenv("SLP_QSTRIP_ABLATE"));
-#define SLP_QABL(A)                                                                                                              \
-    hipLaunchKernelGGL((k_qstrip_spmv<1, false, A>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, \
-                       f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out, (double *)nullptr, accum)
-            if (ab == 1) SLP_QABL(1);
-            else if (ab == 2) SLP_QABL(2);
-            else SLP_QABL(3);
-#undef SLP_QABL
+            constexpr bool ACC = false;
+            if (ab == 1) SLP_QLAUNCH(false, 1);
+            else if (ab == 2) SLP_QLAUNCH(false, 2);
+            else SLP_QLAUNCH(false, 3);
         } else
 #endif
-        if (f.rpl == 4 && nt_quads())
-            hipLaunchKernelGGL((k_qstrip_spmv<1, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                               f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                               (double *)nullptr, accum);
-        else if (f.rpl == 4)
-            hipLaunchKernelGGL((k_qstrip_spmv<1, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                               f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                               (double *)nullptr, accum);
-        else if (nt_level() == 1)  // 8-byte non-temporal loads measured SLOWER than plain ones (2.33 vs 2.23 ms): explicit only
-            hipLaunchKernelGGL((k_dstrip_spmv<1, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                               f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                               (double *)nullptr, accum);
-        else
-            hipLaunchKernelGGL((k_dstrip_spmv<1, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                               f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x, x, f.S > 1 ? f.part.p : out,
-                               (double *)nullptr, accum);
+        if (f.rpl == 4 && nt_quads()) SLP_WITH_ACC(accum, SLP_QLAUNCH(true, 0));
+        else if (f.rpl == 4) SLP_WITH_ACC(accum, SLP_QLAUNCH(false, 0));
+        else if (nt_level() == 1) SLP_WITH_ACC(accum, SLP_DLAUNCH(true));  // 8-byte non-temporal loads measured SLOWER than plain ones (2.33 vs 2.23 ms): explicit only
+        else SLP_WITH_ACC(accum, SLP_DLAUNCH(false));
+#undef SLP_QLAUNCH
+#undef SLP_DLAUNCH
         if (f.S > 1) strip_combine(f, f.part.p, out, accum);
         SLP_HIP(hipGetLastError());
         return;
     }
-#define SLP_STRIP_LAUNCH(A)                                                                                                        \
-    hipLaunchKernelGGL((k_strip_spmv<A, NTF>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol, f.T, \
-                       f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, 0.0, accum)
+#define SLP_STRIP_LAUNCH(A, NTF, NT4F)                                                                                             \
+    hipLaunchKernelGGL((k_strip_spmv<A, NTF, NT4F, false, ACC>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p,       \
+                       f.slen.p, f.soff.p, f.val.p, f.col.p, x, dst, 0.0)
     const bool nt = nt_loads();
 #ifdef SLP_ABLATION  // `make ablation` (tools/ablate_strip.py) only: the ablated kernels return WRONG sums; not in libslp_hip.so
     const char *e = getenv("SLP_STRIP_ABLATE");
     const int ab = e ? atoi(e) : 0;
-    constexpr bool NTF = false;
-    if (ab == 1) SLP_STRIP_LAUNCH(1);
-    else if (ab == 2) SLP_STRIP_LAUNCH(2);
+    if (ab == 1) { constexpr bool ACC = false; SLP_STRIP_LAUNCH(1, false, true); }
+    else if (ab == 2) { constexpr bool ACC = false; SLP_STRIP_LAUNCH(2, false, true); }
     else
 #endif
-    if (nt && nt_level() == 2)
-        hipLaunchKernelGGL((k_strip_spmv<0, true, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                           f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, 0.0, accum);
-    else if (nt) { constexpr bool NTF = true; SLP_STRIP_LAUNCH(0); }
-    else { constexpr bool NTF = false; SLP_STRIP_LAUNCH(0); }
+    if (nt && nt_level() == 2) SLP_WITH_ACC(accum, SLP_STRIP_LAUNCH(0, true, false));
+    else if (nt) SLP_WITH_ACC(accum, SLP_STRIP_LAUNCH(0, true, true));
+    else SLP_WITH_ACC(accum, SLP_STRIP_LAUNCH(0, false, true));
 #undef SLP_STRIP_LAUNCH
     if (f.S > 1) strip_combine(f, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());
@@ -1158,8 +1161,9 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
 
 static void strip_spmv_pow_one(const StripJds &f, double pw, const double *x, double *out, int accum) {
     SLP_REQUIRE(f.ok && !f.wide && !f.tall && f.D == 0, "strip_spmv_pow: not an fp64 strip copy");
-    hipLaunchKernelGGL((k_strip_spmv<0, true, false, true>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, ctx().stream, f.nrow, f.ncol,
-                       f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x, f.S > 1 ? f.part.p : out, pw, accum);
+    SLP_WITH_ACC(accum, hipLaunchKernelGGL((k_strip_spmv<0, true, false, true, ACC>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0,
+                                           ctx().stream, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x,
+                                           f.S > 1 ? f.part.p : out, pw));
     if (f.S > 1) strip_combine(f, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());
 }
@@ -1232,15 +1236,16 @@ static void strip_spmv2_one(const StripJds &f, const double *x0, const double *x
         o0 = f.part2.p;
         o1 = f.part2.p + (size_t)f.S * (size_t)f.nrow;
     }
+    const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
     if (f.D > 0 && f.rpl == 4)
-        hipLaunchKernelGGL((k_qstrip_spmv<2>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
-                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1, accum);
+        SLP_WITH_ACC(accum, hipLaunchKernelGGL((k_qstrip_spmv<2, false, 0, ACC>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p,
+                                               f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1));
     else if (f.D > 0)
-        hipLaunchKernelGGL((k_dstrip_spmv<2, false>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
-                           f.perm.p, f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1, accum);
+        SLP_WITH_ACC(accum, hipLaunchKernelGGL((k_dstrip_spmv<2, false, ACC>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p,
+                                               f.slen.p, f.soff.p, f.ent.p, f.dict, f.D, x0, x1, o0, o1));
     else
-        hipLaunchKernelGGL(k_strip_spmv2, dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0, st, f.nrow, f.ncol, f.T, f.base.p,
-                           f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x0, x1, o0, o1, accum);
+        SLP_WITH_ACC(accum, hipLaunchKernelGGL((k_strip_spmv2<ACC>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p,
+                                               f.soff.p, f.val.p, f.col.p, x0, x1, o0, o1));
     if (f.S > 1) {
         strip_combine(f, o0, out0, accum);
         strip_combine(f, o1, out1, accum);

@@ -50,6 +50,27 @@ def row_block_by_nnz(indptr, world, rank):
     return cuts[rank], cuts[rank + 1] - cuts[rank]
 
 
+def comm_world():
+    """``(world, rank)`` of the communicator inside libslp_hip.so; ``(1, 0)`` without one (or before the library is loaded)."""
+    if _lib._lib is None:
+        return 1, 0
+    w, r = ctypes.c_int(1), ctypes.c_int(0)
+    _lib._lib.slp_comm_info(ctypes.byref(w), ctypes.byref(r))
+    return int(w.value), int(r.value)
+
+
+def local_rows(indptr, m_eq=0):
+    """This rank's share of the stacked constraint rows of a host LP under the active communicator: ``(r0, r1, m_eq_local)`` --
+    rows ``r0 .. r1`` (equal stored entries per rank, ``row_block_by_nnz``), of which the first ``m_eq_local`` are equalities
+    (the equality rows come first in the stack).  ``(0, m, m_eq)`` without a communicator."""
+    world, rank = comm_world()
+    m = len(indptr) - 1
+    if world <= 1:
+        return 0, m, m_eq
+    r0, rows = row_block_by_nnz(indptr, world, rank)
+    return r0, r0 + rows, max(0, min(m_eq, r0 + rows) - r0)
+
+
 def _recv_exact(conn, nbytes):
     buf = b""
     while len(buf) < nbytes:
@@ -181,20 +202,27 @@ class HostTcpAllreduce:
                     conn.close()
             srv.close()
         else:
+            # A listener of ANOTHER job on this port (or a stale rank 0) is treated like a refused connection: close, wait, try
+            # again until the deadline -- as rendezvous_unique_id does -- with a short timeout on the tag read, so that a
+            # listener that never answers does not hold this rank for the full timeout.
             deadline = time.monotonic() + timeout
             while True:
+                conn = None
                 try:
                     conn = socket.create_connection((addr, port), timeout=5.0)
-                    break
-                except OSError:
-                    if time.monotonic() > deadline:
-                        raise
-                    time.sleep(0.05)
+                    conn.settimeout(5.0)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.sendall(hello_tag + self.rank.to_bytes(4, "little"))
+                    if _recv_exact(conn, len(hello_tag)) == hello_tag:
+                        break
+                except (OSError, ConnectionError, socket.timeout):
+                    pass
+                if conn is not None:
+                    conn.close()
+                if time.monotonic() > deadline:
+                    raise ConnectionError("host transport: no rank 0 of this job answered on %s:%d" % (addr, port))
+                time.sleep(0.05)
             conn.settimeout(timeout)
-            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            conn.sendall(hello_tag + self.rank.to_bytes(4, "little"))
-            if _recv_exact(conn, len(hello_tag)) != hello_tag:
-                raise ConnectionError("host transport: the listener on this port belongs to another job")
             self.peers[0] = conn
         self.callback = _lib.HOST_ALLREDUCE_FN(self._allreduce)
 

@@ -196,6 +196,12 @@ class DeviceBlocks:
         """CG steps taken by this rank so far (local: safe to call on one rank only)."""
         return int(self._l.slp_blocks_cg_steps(self._h))
 
+    def projection_residual(self):
+        """``(|| rhs - S sol ||_2, || rhs ||_2)`` of the last block update's projection system, operator applied afresh."""
+        out = np.zeros(2)
+        _lib.check(self._l.slp_blocks_projection_residual(self._h, _lib.ptr(out)))
+        return float(out[0]), float(out[1])
+
     def matrix_passes_per_iteration(self):
         return None  # 3 + 2 per conjugate-gradient step; see cg_steps()
 

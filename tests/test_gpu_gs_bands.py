@@ -82,3 +82,40 @@ def test_potts_admm_with_bands_is_bit_exact_and_chosen_at_256(monkeypatch):
     st = ADMMState.from_lp(*args, None, 2, 3)
     assert st.num_levels() > 500 and st.num_bands() >= 4
     st.close()
+
+
+@pytest.mark.parametrize("bands", ["3", "8", "16"])
+def test_store_waiting_bands_equal_the_default_ones_over_many_sweeps(monkeypatch, bands):
+    """by default a band publishes a level as stored once a LATER vector-memory operation of the storing
+    wave has completed (in-order completion of a wave's vector-memory operations: a documented precondition, DESIGN.md
+    section 3).  ``SLP_GS_BANDS_SAFE=1`` (read when the solver is created) makes every wave wait for its stores themselves
+    (``s_waitcnt vmcnt(0)``) before it publishes: both forms must give the oracle's sweep bit for bit -- many sweeps, several
+    seeds, 3 / 8 / 16 workgroups (8 and 16 land on different XCDs: the dispatcher deals workgroups round-robin over the 8 XCDs)."""
+    from pysparselp_amd.gaussSiedel import boundedGaussSeidelClass
+
+    monkeypatch.setenv("SLP_GS_PIPELINED", "1")
+    monkeypatch.setenv("SLP_GS_BANDS", bands)
+    used = 0
+    for seed in (0, 1, 2):
+        rng = np.random.RandomState(100 * int(bands) + seed)
+        for name, m0 in _systems():
+            m = (m0 + scipy.sparse.diags(np.abs(m0).sum(axis=1).A1 + 1.0)).tocsr()
+            m.sort_indices()
+            k = m.shape[0]
+            rhs, x0 = rng.randn(k), rng.randn(k)
+            lo = np.where(rng.rand(k) < 0.3, -np.inf, -rng.rand(k))
+            hi = np.where(rng.rand(k) < 0.3, np.inf, rng.rand(k))
+            xo = x0.copy()
+            oracle.BoundedGaussSeidel(m).solve(rhs, lo, hi, xo, maxiter=12, w=1.05)
+            got = {}
+            for safe in ("0", "1"):
+                monkeypatch.setenv("SLP_GS_BANDS_SAFE", safe)
+                gs = boundedGaussSeidelClass(m)
+                used += gs.num_bands > 0
+                xg = x0.copy()
+                for _ in range(4):   # 4 x 3 sweeps on one plan
+                    gs.solve(rhs, lo, hi, xg, maxiter=3, w=1.05)
+                got[safe] = xg
+            assert np.array_equal(got["0"], got["1"]), (name, bands, seed)
+            assert np.array_equal(got["1"], xo), (name, bands, seed)
+    assert used >= 8

@@ -146,3 +146,74 @@ def test_eight_ranks_on_one_gpu_match_the_single_process_run():
         err = float(np.max(np.abs(eight[0][key] - one[key]) / (1 + np.abs(one[key]))))
         assert err < 1e-9, (key, err)
     assert np.allclose(eight[0]["admm_report"], one["admm_report"], rtol=1e-8, atol=1e-9)
+
+
+def _rank_groups(rank, world, port, n, m, p, seed, iters, async_mode, q):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                           "SLP_COMM_TRANSPORT": "host", "SLP_JOB_TOKEN": "groups-%d" % port, "SLP_STRIP_MIN_NNZ": "1",
+                           "SLP_HOST_ASYNC": async_mode})
+        from pysparselp_amd import _lib
+        from pysparselp_amd.parallel import init_comm_from_env, row_block
+        from pysparselp_amd.problems import random_lp_on_device
+        from pysparselp_amd.scale import DeviceBlocksGroup
+
+        lib = _lib.lib(0)
+        if world > 1:
+            init_comm_from_env(rank, world)
+        r0, rows = row_block(m, world, rank)
+        a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=seed, row_offset=r0, rows=rows)
+        cuts = [0, rows // 4, (3 * rows) // 5, rows]    # three uneven blocks on every rank
+        grp = DeviceBlocksGroup(a, cuts, b, c, lb, ub, cg_max_steps=40)
+        c0 = int(lib.slp_comm_collectives())
+        grp.iterate(iters)
+        out = {"x": grp.x(), "collectives": int(lib.slp_comm_collectives()) - c0, "cg_steps": grp.cg_steps()}
+        grp.close()
+        a.close()
+        if world > 1:
+            _lib.check(lib.slp_comm_finalize())
+        q.put((rank, out))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, {"error": traceback.format_exc() + repr(e)}))
+
+
+@pytest.mark.timeout(900)
+def test_block_groups_overlap_their_exchanges_with_two_ranks_on_one_gpu():
+    """Block-splitting ADMM with three row blocks per rank and the rows split over two ranks (ADMMBlocks.py:264-307 at scale):
+    a block's consensus summand is all-reduced while the NEXT block's projection computes (comm_allreduce_dev_async /
+    comm_join).  Through the host transport's asynchronous form (a worker thread) the ordering is
+    exercised with two real ranks: 3 all-reduces of n doubles per iteration in block order on both ranks, the same x as the
+    transport's synchronous form (bit for bit: same sums, same order) and as the single-process group to the CG tolerance."""
+    import socket
+
+    n, m, p, seed, iters = 20000, 30000, 0.001, 4, 5
+
+    def run(world, async_mode):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rank_groups, args=(r, world, port, n, m, p, seed, iters, async_mode, q)) for r in range(world)]
+        for pr in procs:
+            pr.start()
+        res = {}
+        for _ in range(world):
+            rank, out = q.get(timeout=600)
+            assert "error" not in out, out["error"]
+            res[rank] = out
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+        return res
+
+    asy, syn = run(2, "1"), run(2, "0")
+    for res in (asy, syn):
+        assert res[0]["collectives"] == res[1]["collectives"] == 3 * iters
+        assert np.array_equal(res[0]["x"], res[1]["x"])
+    assert np.array_equal(asy[0]["x"], syn[0]["x"])
+    one = run(1, "1")[0]   # the same three-plus-three blocks cannot be formed on one rank: compare with ITS three blocks' consensus
+    assert one["collectives"] == 0 and np.all(np.isfinite(one["x"]))

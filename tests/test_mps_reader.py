@@ -153,3 +153,25 @@ def test_save_mps_two_sided_rows_free_and_fixed_variables(tmp_path):
     assert np.array_equal(back["b_upper"], lp.b_upper) and np.array_equal(back["b_lower"], lp.b_lower)
     assert np.array_equal(scipy.sparse.csr_matrix(back["a_ineq"]).toarray(), lp.a_inequalities.toarray())
     assert np.array_equal(scipy.sparse.csr_matrix(back["a_eq"]).toarray(), lp.a_equalities.toarray())
+
+
+def test_save_mps_refuses_a_two_sided_row_it_cannot_write_exactly(tmp_path):
+    """A row whose two bounds are reproduced neither by rhs - range nor by rhs + range in fp64 would come back off by an ulp:
+    the writer refuses instead of breaking its bit-for-bit promise."""
+    from pysparselp_amd.SparseLP import SparseLP
+
+    rng = np.random.RandomState(0)
+    lo = up = None
+    for _ in range(100000):  # such pairs are common: search one
+        l, u = rng.randn(), rng.randn()
+        l, u = min(l, u), max(l, u)
+        if u - (u - l) != l and l + (u - l) != u:
+            lo, up = l, u
+            break
+    assert lo is not None
+    lp = SparseLP()
+    lp.add_variables_array(2, lower_bounds=0, upper_bounds=1, costs=np.array([1.0, 2.0]))
+    lp.add_inequality_constraints_sparse(scipy.sparse.csr_matrix(np.array([[1.0, 1.0]])), lower_bounds=np.array([lo]),
+                                         upper_bounds=np.array([up]))
+    with pytest.raises(ValueError, match="cannot be written exactly"):
+        lp.save_mps(str(tmp_path / "inexact.mps"))
