@@ -147,7 +147,8 @@ def pmc_traffic(kernel_id, shape):
 
 
 def spmv_block(lib, a, transposed, shape, reps=5):
-    """Roofline figures of one SpMV orientation of the resident matrix, timed with HIP events on the library's stream."""
+    """Roofline figures of one SpMV orientation of the resident matrix, timed with HIP events on the library's stream.
+    A chunked matrix runs one launch per chunk: "per launch" figures are per PRODUCT (all of its launches)."""
     rows, cols = (a.shape[1], a.shape[0]) if transposed else a.shape
     ms = a.bench_spmv(transposed, reps=reps)
     which = int(lib.slp_matrix_spmv_kernel(a._h, int(transposed)))
@@ -155,11 +156,15 @@ def spmv_block(lib, a, transposed, shape, reps=5):
     moved = copy_bytes + 8 * cols + 8 * rows  # the matrix copy streamed once + x read once + y written once
     alg = spmv_bytes(a.nnz, rows, cols)
     traffic, src = pmc_traffic(which, shape) if not transposed else (None, None)
+    launches = max(1, int(lib.slp_matrix_chunks(a._h)))
+    if traffic is not None:
+        traffic *= launches   # the PMC summary is per kernel launch
     out = {
         "kernel": KERNEL_NAMES.get(which, "?"),
         "achieved": moved / (ms * 1e-3) / 1e9,
         "frac": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "ms_per_launch": ms,
+        "launches_per_product": launches,
         "bytes_per_launch": moved,
         "matrix_copy_bytes_per_launch": copy_bytes,
         "csr_equivalent": {"algorithmic_bytes_per_launch": alg, "gbps": alg / (ms * 1e-3) / 1e9,

@@ -142,8 +142,17 @@ __global__ __launch_bounds__(kBlock) void k_cp_dual(i64 m, const i64 *__restrict
 // index 0, value 0, skipped in the sum) -- two dependent memory hops per half-iteration (entries -> gather)
 // instead of the three of CSR (row pointer -> entries -> gather); these LPs are latency-bound, not bandwidth-bound.
 // Sums run over e = 0 .. len-1 in storage order: the same sequential sums as k_cp_primal<1> / k_cp_dual<1>.
+// Packed form (few distinct stored values, D <= 256, and fewer than 2^24 rows / columns -- Potts: +-1): an entry is ONE 32-bit
+// word, index | value id << 24, the D values sit in LDS: 4 bytes per entry instead of 12.  These LPs live in the caches: the
+// iteration's time is the bytes it pulls through the L2s from the Infinity Cache, and the ELL copies were two thirds of them.
+// The looked-up value is the fp64 number the CSR holds: the same sums, bit for bit.
+__host__ __device__ inline unsigned long long cp_value_key(unsigned long long bits) {  // order-preserving image (slp_strip.hip)
+    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+}
+
 __global__ void k_ell_fill(i64 nrow, int W, const i64 *__restrict__ ptr, const i32 *__restrict__ idx, const double *__restrict__ val,
-                           i32 *__restrict__ oidx, double *__restrict__ oval, unsigned char *__restrict__ olen, int *__restrict__ bad) {
+                           i32 *__restrict__ oidx, double *__restrict__ oval, unsigned char *__restrict__ olen, int *__restrict__ bad,
+                           int D, const unsigned long long *__restrict__ dkeys) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
         const i64 s = ptr[r];
         const i64 full = ptr[r + 1] - s;
@@ -151,24 +160,50 @@ __global__ void k_ell_fill(i64 nrow, int W, const i64 *__restrict__ ptr, const i
         const int len = (int)(full < W ? full : W);
         olen[r] = (unsigned char)len;
         for (int e = 0; e < W; ++e) {
-            oidx[(i64)e * nrow + r] = e < len ? idx[s + e] : 0;
-            oval[(i64)e * nrow + r] = e < len ? val[s + e] : 0.0;
+            if (D > 0) {  // packed: index | value id << 24
+                unsigned int w = 0;
+                if (e < len) {
+                    const unsigned long long key = cp_value_key((unsigned long long)__double_as_longlong(val[s + e]));
+                    int lo = 0, hi = D - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (dkeys[mid] < key) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    if (dkeys[lo] != key || (unsigned)idx[s + e] >= (1u << 24)) atomicOr(bad, 2);
+                    w = (unsigned int)idx[s + e] | ((unsigned int)lo << 24);
+                }
+                oidx[(i64)e * nrow + r] = (i32)w;
+            } else {
+                oidx[(i64)e * nrow + r] = e < len ? idx[s + e] : 0;
+                oval[(i64)e * nrow + r] = e < len ? val[s + e] : 0.0;
+            }
         }
     }
 }
 
-template <int W>
+// PACKED: eidx holds index | value id << 24 and eval the D <= 256 values (k_ell_fill)
+template <int W, bool PACKED>
 __global__ __launch_bounds__(kBlock) void k_cp_primal_ell(i64 n, const unsigned char *__restrict__ len, const i32 *__restrict__ eidx,
                                                           const double *__restrict__ eval, const double *__restrict__ y,
                                                           const double *__restrict__ c, const double *__restrict__ t,
                                                           const double *__restrict__ lb, const double *__restrict__ ub,
                                                           double *__restrict__ x, double *__restrict__ z, double *__restrict__ d_out,
-                                                          i32 m_eq, i64 m_ineq, double one_plus_theta, double theta) {
+                                                          i32 m_eq, i64 m_ineq, double one_plus_theta, double theta, int D) {
+    __shared__ double tab[PACKED ? 256 : 1];
+    if (PACKED) {
+        if ((int)threadIdx.x < D) tab[threadIdx.x] = eval[threadIdx.x];
+        __syncthreads();
+    }
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
         i32 ix[W];
         double v[W], g[W];
 #pragma unroll
-        for (int e = 0; e < W; ++e) { ix[e] = eidx[(i64)e * n + j]; v[e] = eval[(i64)e * n + j]; }
+        for (int e = 0; e < W; ++e) {
+            const i32 raw = eidx[(i64)e * n + j];
+            ix[e] = PACKED ? (i32)((unsigned int)raw & 0xffffffu) : raw;
+            v[e] = PACKED ? tab[(unsigned int)raw >> 24] : eval[(i64)e * n + j];
+        }
         const int L = len[j];
         const double cj = c[j], tj = t[j], l = lb[j], u = ub[j], xo = x[j];
 #pragma unroll
@@ -193,16 +228,25 @@ __global__ __launch_bounds__(kBlock) void k_cp_primal_ell(i64 n, const unsigned 
     }
 }
 
-template <int W>
+template <int W, bool PACKED>
 __global__ __launch_bounds__(kBlock) void k_cp_dual_ell(i64 m, const unsigned char *__restrict__ len, const i32 *__restrict__ eidx,
                                                         const double *__restrict__ eval, const double *__restrict__ z,
                                                         const double *__restrict__ b, const double *__restrict__ sigma,
-                                                        double *__restrict__ y, i64 m_eq) {
+                                                        double *__restrict__ y, i64 m_eq, int D) {
+    __shared__ double tab[PACKED ? 256 : 1];
+    if (PACKED) {
+        if ((int)threadIdx.x < D) tab[threadIdx.x] = eval[threadIdx.x];
+        __syncthreads();
+    }
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
         i32 ix[W];
         double v[W], g[W];
 #pragma unroll
-        for (int e = 0; e < W; ++e) { ix[e] = eidx[(i64)e * m + i]; v[e] = eval[(i64)e * m + i]; }
+        for (int e = 0; e < W; ++e) {
+            const i32 raw = eidx[(i64)e * m + i];
+            ix[e] = PACKED ? (i32)((unsigned int)raw & 0xffffffu) : raw;
+            v[e] = PACKED ? tab[(unsigned int)raw >> 24] : eval[(i64)e * m + i];
+        }
         const int L = len[i];
         const double bi = b[i], sg = sigma[i], yo = y[i];
 #pragma unroll
@@ -387,6 +431,7 @@ struct slp_cp {
     DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, kz, rep, rowparts, colparts, out;
     // ELL copies for short rows (0 = not used)
     int ell_w_rows = 0, ell_w_cols = 0;
+    int ell_D = 0;                 // > 0: the ELL copies are packed (index | value id << 24), the values are k's dictionary
     DevBuf<i32> ell_idx_rows, ell_idx_cols;
     DevBuf<double> ell_val_rows, ell_val_cols;
     DevBuf<unsigned char> ell_len_rows, ell_len_cols;
@@ -422,14 +467,21 @@ static void cp_setup(slp_cp *s) {
         const char *ee = getenv("SLP_CP_ELL");
         auto width = [](i64 maxlen) { return maxlen <= 4 ? 4 : (maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : 0)); };
         const bool small = a.nnz <= 50000000 && !(ee && ee[0] == '0') && !s->distributed && !fast_format(s->k, false) && !fast_format(s->k, true);
+        // packed entries when the matrix has at most 256 distinct values and 24-bit indices (SLP_CP_PACKED=0: fp64 + int32 entries)
+        const char *ep = getenv("SLP_CP_PACKED");
+        const bool packed = small && !(ep && ep[0] == '0') && s->n < ((i64)1 << 24) && s->m < ((i64)1 << 24) && matrix_dictionary(s->k) &&
+                            s->k->vdict.D <= 256;
+        s->ell_D = packed ? s->k->vdict.D : 0;
         auto build = [&](const CsrDev &csr, int &W, DevBuf<i32> &ei, DevBuf<double> &ev, DevBuf<unsigned char> &el) {
             W = width(csr.max_row_len);
             if (!W || csr.nrow == 0) { W = 0; return; }
-            ei.alloc((size_t)W * (size_t)csr.nrow); ev.alloc((size_t)W * (size_t)csr.nrow); el.alloc((size_t)csr.nrow);
+            ei.alloc((size_t)W * (size_t)csr.nrow); el.alloc((size_t)csr.nrow);
+            if (s->ell_D) ev.copy_from(s->k->vdict.values);  // the table
+            else ev.alloc((size_t)W * (size_t)csr.nrow);
             DevBuf<int> bad(1);
             bad.zero();
             hipLaunchKernelGGL(k_ell_fill, dim3(grid_for(csr.nrow, kBlock)), dim3(kBlock), 0, st, csr.nrow, W, csr.ptr.p, csr.idx.p,
-                               csr.val.p, ei.p, ev.p, el.p, bad.p);
+                               csr.val.p, ei.p, ev.p, el.p, bad.p, s->ell_D, s->ell_D ? s->k->vdict.keys.p : (const unsigned long long *)nullptr);
             SLP_HIP(hipGetLastError());
             int hbad = 0;
             bad.download(&hbad, 1);
@@ -530,13 +582,17 @@ static void cp_primal(slp_cp *s, bool store_d) {
                            s->m_ineq, opt, s->theta);
     } else if (s->ell_w_cols) {
         const int grid = grid_for(s->n, kBlock);
-#define SLP_ELL_PRIMAL(W)                                                                                                          \
-    hipLaunchKernelGGL((k_cp_primal_ell<W>), dim3(grid), dim3(kBlock), 0, st, s->n, s->ell_len_cols.p, s->ell_idx_cols.p,           \
+#define SLP_ELL_PRIMAL(W, P)                                                                                                       \
+    hipLaunchKernelGGL((k_cp_primal_ell<W, P>), dim3(grid), dim3(kBlock), 0, st, s->n, s->ell_len_cols.p, s->ell_idx_cols.p,        \
                        s->ell_val_cols.p, s->y.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq, s->m_ineq, opt, \
-                       s->theta)
-        if (s->ell_w_cols == 4) SLP_ELL_PRIMAL(4);
-        else if (s->ell_w_cols == 8) SLP_ELL_PRIMAL(8);
-        else SLP_ELL_PRIMAL(16);
+                       s->theta, s->ell_D)
+        if (s->ell_D) {
+            if (s->ell_w_cols == 4) SLP_ELL_PRIMAL(4, true);
+            else if (s->ell_w_cols == 8) SLP_ELL_PRIMAL(8, true);
+            else SLP_ELL_PRIMAL(16, true);
+        } else if (s->ell_w_cols == 4) SLP_ELL_PRIMAL(4, false);
+        else if (s->ell_w_cols == 8) SLP_ELL_PRIMAL(8, false);
+        else SLP_ELL_PRIMAL(16, false);
 #undef SLP_ELL_PRIMAL
     } else {
         require_csr(s->k, "Chambolle-Pock primal step (CSR walk)");
@@ -562,12 +618,16 @@ static void cp_dual(slp_cp *s) {
     }
     if (s->ell_w_rows) {
         const int grid = grid_for(s->m, kBlock);
-#define SLP_ELL_DUAL(W)                                                                                                         \
-    hipLaunchKernelGGL((k_cp_dual_ell<W>), dim3(grid), dim3(kBlock), 0, ctx().stream, s->m, s->ell_len_rows.p, s->ell_idx_rows.p, \
-                       s->ell_val_rows.p, s->z.p, s->b.p, s->sigma.p, s->y.p, s->m_eq)
-        if (s->ell_w_rows == 4) SLP_ELL_DUAL(4);
-        else if (s->ell_w_rows == 8) SLP_ELL_DUAL(8);
-        else SLP_ELL_DUAL(16);
+#define SLP_ELL_DUAL(W, P)                                                                                                         \
+    hipLaunchKernelGGL((k_cp_dual_ell<W, P>), dim3(grid), dim3(kBlock), 0, ctx().stream, s->m, s->ell_len_rows.p, s->ell_idx_rows.p, \
+                       s->ell_val_rows.p, s->z.p, s->b.p, s->sigma.p, s->y.p, s->m_eq, s->ell_D)
+        if (s->ell_D) {
+            if (s->ell_w_rows == 4) SLP_ELL_DUAL(4, true);
+            else if (s->ell_w_rows == 8) SLP_ELL_DUAL(8, true);
+            else SLP_ELL_DUAL(16, true);
+        } else if (s->ell_w_rows == 4) SLP_ELL_DUAL(4, false);
+        else if (s->ell_w_rows == 8) SLP_ELL_DUAL(8, false);
+        else SLP_ELL_DUAL(16, false);
 #undef SLP_ELL_DUAL
         SLP_HIP(hipGetLastError());
         return;

@@ -486,10 +486,10 @@ struct TallRegs {
 };
 
 // DICT: depth 4 (20 KB of payload per packet); fp64 entries: depth 2 (48 KB per packet, 16 more registers per packet)
-template <bool DICT>
+template <bool DICT, bool ACC>
 __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, int S, const TallWg *__restrict__ wgs,
                                                       const double *__restrict__ dict, int D, const double *__restrict__ x,
-                                                      double *__restrict__ out, int accum) {
+                                                      double *__restrict__ out) {
     constexpr int kDepth = DICT ? kTallDepth : 2;
     __shared__ double acc[kTallRmax];
     __shared__ double dv[kTallDictMax];
@@ -497,13 +497,21 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     const int p = threadIdx.x;
     const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
     const i64 v = blockIdx.x, b = v / S;  // workgroup v walks the strips of range v % S of row block b
-    // accum (S == 1): the sums continue from what `out` holds -- a row chunk of a chunked matrix carrying on the column sums of
-    // the chunks before it, the chain of additions of the unchunked product (S > 1: taken in k_tall_combine)
-    for (int r = p; r < R; r += kTallT) acc[r] = (accum && S == 1 && b * (i64)R + r < nrow) ? out[b * (i64)R + r] : 0.0;
+    // ACC (S == 1): the sums continue from what `out` holds -- a row chunk of a chunked matrix carrying on the column sums of
+    // the chunks before it, the chain of additions of the unchunked product (S > 1: taken in k_tall_combine).  A template
+    // parameter: loads under a run-time condition in front of the pipeline made the compiler wait for vmcnt(0) in the loop.
+    for (int r = p; r < R; r += kTallT) acc[r] = (ACC && S == 1 && b * (i64)R + r < nrow) ? out[b * (i64)R + r] : 0.0;
     if (DICT)
         for (int q = p; q < D; q += kTallT) dv[q] = dict[q];
     const TallWg wg = wgs[v];
-    const unsigned int *__restrict__ hd = wg.dir + (p & 7);                   // this lane's dword of every header
+    // this lane's dword of every header -- through a GLOBAL-address-space pointer: a pointer read from a structure in memory is
+    // a generic one to the compiler, its loads become flat_load (complete out of order: every wait a vmcnt(0), the pipeline gone)
+#ifdef SLP_TALL_FLAT  // lab: the generic-pointer form (drains the pipeline at every packet group), for re-measurement
+    const unsigned int *hd = wg.dir + (p & 7);
+#else
+    typedef const unsigned int __attribute__((address_space(1))) *gptr_t;
+    const gptr_t hd = (gptr_t)(unsigned long long)wg.dir + (p & 7);
+#endif
     const int npk = (int)wg.npk - 2 * kTallDepth;                             // the last 2 x depth packets are prefetch targets only
     // buffer descriptors: lanes without work address past num_records (the load returns 0 without a memory request)
     const __amdgpu_buffer_rsrc_t rs_pay =
@@ -835,12 +843,13 @@ __global__ void k_tall_combine(i64 nrow, int S, const double *__restrict__ part,
 void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
     double *dst = f.S > 1 ? f.part.p : out;
     const unsigned grid = (unsigned)(f.B * f.S);
-    if (f.D > 0)
-        hipLaunchKernelGGL((k_tall_spmv<true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_wg.p, f.dict, f.D,
-                           x, dst, accum);
-    else
-        hipLaunchKernelGGL((k_tall_spmv<false>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_wg.p,
-                           (const double *)nullptr, 0, x, dst, accum);
+    const bool acc = accum && f.S == 1;
+#define SLP_TALL_LAUNCH(DICT, ACC)                                                                                                   \
+    hipLaunchKernelGGL((k_tall_spmv<DICT, ACC>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_wg.p, \
+                       DICT ? f.dict : (const double *)nullptr, DICT ? f.D : 0, x, dst)
+    if (f.D > 0) { if (acc) SLP_TALL_LAUNCH(true, true); else SLP_TALL_LAUNCH(true, false); }
+    else { if (acc) SLP_TALL_LAUNCH(false, true); else SLP_TALL_LAUNCH(false, false); }
+#undef SLP_TALL_LAUNCH
     if (f.S > 1)
         hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());
