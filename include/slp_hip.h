@@ -45,11 +45,12 @@ int slp_synchronize(void);
  * returned to the driver; slp_trim() returns it all, slp_cached_bytes() tells how much is parked. */
 int slp_trim(void);
 int64_t slp_cached_bytes(void);
-/* What the library's device allocations cost and weigh: out[0] seconds spent inside hipMalloc / hipFree, out[1] the most
- * bytes the library ever held from the driver at once (live + cached), out[2] bytes held now, out[3] driver calls -- all
- * since the last call with reset != 0 (the peak restarts from what is held).  A set-up's allocation time and peak footprint
- * as the bench line reports them. */
-int slp_alloc_stats(double out[4], int reset);
+/* What the library's device allocations cost and weigh: out[0] seconds the calling thread spent inside hipMalloc / hipFree
+ * (or waiting for a reservation), out[1] the most bytes the library ever held from the driver at once (live + cached),
+ * out[2] bytes held now, out[3] driver calls, out[4] seconds of hipMalloc the reservation helper thread absorbed beside
+ * other work (slp_matrix_chunked_expect) -- all since the last call with reset != 0 (the peak restarts from what is
+ * held).  A set-up's allocation time and peak footprint as the bench line reports them. */
+int slp_alloc_stats(double out[5], int reset);
 const char *slp_last_error(void);
 /* Milliseconds the GPU spent between the two most recent slp_timer_start /
  * slp_timer_stop marks on the library's stream (HIP events). */
@@ -135,6 +136,11 @@ int64_t slp_matrix_format_bytes(slp_matrix *a, int transposed);
  * 288 GB GPU this way (208 GB of tall cells for both orientations). */
 slp_matrix *slp_matrix_chunked_create(int64_t ncol);
 int slp_matrix_chunked_append(slp_matrix *chunked, slp_matrix *chunk);
+/* Optional: how many chunks will be appended in all.  While chunks are still to come, every append then asks a helper thread
+ * to hipMalloc the next chunk's two packet-stream buffers (sizes of the chunk just appended) beside the generation and
+ * conversion of that chunk: on boxes whose hipMalloc runs at ~27 ms per GB this hides most of the 0.7 s per chunk it costs at
+ * config 4's size.  Never changes results. */
+int slp_matrix_chunked_expect(slp_matrix *chunked, int64_t chunks);
 /* Chunks appended so far; 0 for an ordinary matrix, -1 for NULL. */
 int64_t slp_matrix_chunks(const slp_matrix *a);
 

@@ -100,6 +100,22 @@ int slp_matrix_chunked_append(slp_matrix *g, slp_matrix *c) {
         g->a.nnz += c->a.nnz;
         g->a.max_row_len = std::max(g->a.max_row_len, c->a.max_row_len);
         refresh_composites(g);
+        // more chunks to come: their packet streams will be as large as this one's -- have a helper thread take those blocks
+        // from the driver while the next chunk is generated and converted
+        if ((i64)g->chunks.size() < g->expect_chunks) {
+            std::vector<size_t> sizes;
+            for (const StripJds *f : {f0, f1})
+                if (f->tall)
+                    for (const auto &b : f->tall_pay) sizes.push_back(b.cap);
+            dev_reserve_async(sizes);
+        }
+    })
+}
+
+int slp_matrix_chunked_expect(slp_matrix *g, int64_t chunks) {
+    SLP_API_INT({
+        SLP_REQUIRE(g && g->csr_released && g->a.ptr.p == nullptr && chunks >= 0, "slp_matrix_chunked_expect: bad arguments");
+        g->expect_chunks = chunks;
     })
 }
 

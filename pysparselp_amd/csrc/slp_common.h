@@ -80,6 +80,8 @@ void trace_slow(const char *what, size_t bytes, double t0);
 // reused by work enqueued later on that stream.
 void *dev_alloc(size_t bytes, size_t *capacity);
 void dev_free(void *p, size_t capacity);
+// blocks of these sizes will be asked for soon: a helper thread takes them from the driver meanwhile (slp_matrix.hip)
+void dev_reserve_async(const std::vector<size_t> &sizes);
 
 // ---- device buffer
 template <class T>
@@ -289,6 +291,7 @@ struct slp_matrix {
     std::vector<slp_matrix *> chunks;
     std::vector<slp::i64> chunk_row0;      // first row of every chunk
     slp::DevBuf<double> rowsq;             // a chunk: [2 * rows] the two sums of squares behind the ADMM row scaling (tools.py:272-290)
+    slp::i64 expect_chunks = 0;            // slp_matrix_chunked_expect: chunks to come in all (0: unknown, nothing is reserved ahead)
     ~slp_matrix();
 };
 

@@ -4,8 +4,10 @@
 // (ChambollePockPPD.py:206,216,235,240 ; ADMM.py:95,148,220,262).
 #include <chrono>
 #include <algorithm>
+#include <condition_variable>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <cstring>
 #include <cstdlib>
 
@@ -37,10 +39,78 @@ static std::mutex g_alloc_mutex;
 static double g_driver_seconds = 0.0;
 static size_t g_held_bytes = 0, g_peak_bytes = 0;
 static long long g_driver_calls = 0;
+// Reservations: hipMalloc of blocks that will be asked for soon, issued by a helper thread while the GPU (and this thread) work on
+// something else -- on this platform a hipMalloc costs 24-28 ms per GB on many boxes (the driver clears the memory), 0.36 s
+// for the 13 GB packet stream of one row chunk of config 4, 5.8 s of the 12 s that LP took to set up.  The blocks land in the
+// cache; a request that fits a reservation still in flight waits for it instead of going to the driver a second time.
+static std::multimap<size_t, int> g_reserving;   // capacity -> (unused): blocks the helper is allocating
+static std::condition_variable g_reserve_cv;
+static std::thread g_reserve_thread;
+static double g_background_seconds = 0.0;
+
+static size_t size_class(size_t bytes) {
+    size_t want = (bytes + 255) & ~(size_t)255;
+    if (want > ((size_t)64 << 20)) {
+        // large blocks in size classes of 1/32 .. 1/64 of their size: the CSR arrays, sort buffers and packet streams of
+        // successive row chunks (sizes equal to a fraction of a percent) then reuse each other's blocks instead of going to the
+        // driver for a new multi-GB allocation each time
+        size_t g = 1;
+        while ((g << 6) <= want) g <<= 1;
+        want = (want + g - 1) & ~(g - 1);
+    }
+    return want;
+}
+
+static void reserve_join() {
+    if (g_reserve_thread.joinable()) g_reserve_thread.join();
+}
+
+void dev_reserve_async(const std::vector<size_t> &sizes) {
+    static const bool off = [] { const char *e = getenv("SLP_NO_RESERVE"); return e && e[0] == '1'; }();
+    if (off || sizes.empty()) return;
+    static const bool at_exit = (atexit([] { reserve_join(); }), true);  // a joinable std::thread must not reach its destructor
+    (void)at_exit;
+    reserve_join();  // (one helper at a time: requests are few and large)
+    std::vector<size_t> caps;
+    {
+        std::lock_guard<std::mutex> lock(g_alloc_mutex);
+        for (size_t b : sizes) {
+            const size_t c = size_class(b);
+            // already parked in the cache?  then nothing to do for this one
+            auto it = g_free_blocks.find(c);
+            if (it != g_free_blocks.end()) continue;
+            caps.push_back(c);
+            g_reserving.emplace(c, 0);
+        }
+    }
+    if (caps.empty()) return;
+    const int device = ctx().device;
+    g_reserve_thread = std::thread([caps, device] {
+        (void)hipSetDevice(device);
+        for (size_t c : caps) {
+            void *p = nullptr;
+            const double t0 = trace_now();
+            const hipError_t e = hipMalloc(&p, c);
+            if (e != hipSuccess) (void)hipGetLastError();  // no memory for a reservation: the request itself will deal with it
+            std::lock_guard<std::mutex> lock(g_alloc_mutex);
+            g_background_seconds += trace_now() - t0;
+            ++g_driver_calls;
+            auto it = g_reserving.find(c);
+            if (it != g_reserving.end()) g_reserving.erase(it);
+            if (e == hipSuccess) {
+                g_free_blocks.emplace(c, p);
+                g_cached_bytes += c;
+                g_held_bytes += c;
+                if (g_held_bytes > g_peak_bytes) g_peak_bytes = g_held_bytes;
+            }
+            g_reserve_cv.notify_all();
+        }
+    });
+}
 
 void comm_sync_side();  // slp_comm.hip: drains the second stream (asynchronous all-reduces may still write cached blocks)
 
-static void trim_cache() {
+static void trim_cache() {   // (called with g_alloc_mutex held)
     comm_sync_side();
     const double t0 = trace_now();
     for (auto &kv : g_free_blocks) { (void)hipFree(kv.second); g_held_bytes -= kv.first; ++g_driver_calls; }
@@ -51,28 +121,27 @@ static void trim_cache() {
 
 void *dev_alloc(size_t bytes, size_t *capacity) {
     static const bool off = [] { const char *e = getenv("SLP_NO_ALLOC_CACHE"); return e && e[0] == '1'; }();
-    size_t want = (bytes + 255) & ~(size_t)255;
-    if (want > ((size_t)64 << 20)) {
-        // large blocks in size classes of 1/32 .. 1/64 of their size: the CSR arrays, sort buffers and packet streams of
-        // successive row chunks (sizes equal to a fraction of a percent) then reuse each other's blocks instead of going to the
-        // driver for a new multi-GB allocation each time
-        size_t g = 1;
-        while ((g << 6) <= want) g <<= 1;
-        want = (want + g - 1) & ~(g - 1);
-    }
-    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    const size_t want = size_class(bytes);
+    std::unique_lock<std::mutex> lock(g_alloc_mutex);
     if (!off) {
         // a cached block is taken when it is not much larger than the request: up to 2 x for small ones, up to 12.5 % above
         // 64 MB (a 10 GB request must not sit on a 20 GB block for its whole lifetime: the out-of-memory retry cannot get
         // that slack back)
         const size_t limit = want > ((size_t)64 << 20) ? want + want / 8 : 2 * want + (1u << 20);
-        auto it = g_free_blocks.lower_bound(want);
-        if (it != g_free_blocks.end() && it->first <= limit) {
-            void *p = it->second;
-            *capacity = it->first;
-            g_cached_bytes -= it->first;
-            g_free_blocks.erase(it);
-            return p;
+        for (;;) {
+            auto it = g_free_blocks.lower_bound(want);
+            if (it != g_free_blocks.end() && it->first <= limit) {
+                void *p = it->second;
+                *capacity = it->first;
+                g_cached_bytes -= it->first;
+                g_free_blocks.erase(it);
+                return p;
+            }
+            auto rv = g_reserving.lower_bound(want);   // a reservation of this size is on its way: wait for it
+            if (rv == g_reserving.end() || rv->first > limit) break;
+            const double t0 = trace_now();
+            g_reserve_cv.wait(lock);
+            g_driver_seconds += trace_now() - t0;      // (time this thread lost to the driver all the same)
         }
     }
     void *p = nullptr;
@@ -503,6 +572,7 @@ int slp_init(int device) {
 int slp_trim(void) {
     SLP_API_INT({
         SLP_HIP(hipStreamSynchronize(ctx().stream));
+        reserve_join();
         std::lock_guard<std::mutex> lock(g_alloc_mutex);
         trim_cache();
     })
@@ -510,7 +580,7 @@ int slp_trim(void) {
 
 int64_t slp_cached_bytes(void) { return (int64_t)g_cached_bytes; }
 
-int slp_alloc_stats(double out[4], int reset) {
+int slp_alloc_stats(double out[5], int reset) {
     SLP_API_INT({
         std::lock_guard<std::mutex> lock(g_alloc_mutex);
         if (out) {
@@ -518,8 +588,9 @@ int slp_alloc_stats(double out[4], int reset) {
             out[1] = (double)g_peak_bytes;
             out[2] = (double)g_held_bytes;
             out[3] = (double)g_driver_calls;
+            out[4] = g_background_seconds;
         }
-        if (reset) { g_driver_seconds = 0.0; g_peak_bytes = g_held_bytes; g_driver_calls = 0; }
+        if (reset) { g_driver_seconds = 0.0; g_background_seconds = 0.0; g_peak_bytes = g_held_bytes; g_driver_calls = 0; }
     })
 }
 

@@ -157,9 +157,13 @@ class ChunkedDeviceMatrix(DeviceMatrix):
     (``DeviceCP``, ``DeviceADMM``) take it like a ``DeviceMatrix``; ``A^T y`` continues the column sums from chunk to
     chunk, bit for bit the unchunked product."""
 
-    def __init__(self, ncol):
+    def __init__(self, ncol, expect_chunks=0):
+        """``expect_chunks``: how many chunks will be appended (optional; lets the library take the next chunk's buffers from
+        the driver beside the work on it -- ``slp_matrix_chunked_expect``)."""
         l = _lib.lib()
         super().__init__(_lib.check_handle(l.slp_matrix_chunked_create(int(ncol))), (0, ncol))
+        if expect_chunks:
+            _lib.check(l.slp_matrix_chunked_expect(self._h, int(expect_chunks)))
 
     def append(self, chunk):
         """Takes ownership of ``chunk`` (a ``DeviceMatrix`` with its CSR); every chunk but the last needs an even row count."""

@@ -94,7 +94,7 @@ def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1
         xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset)
         return a, xf, c, lb, ub, b
     cuts = ChunkedDeviceMatrix.cuts(rows, chunks)
-    a = ChunkedDeviceMatrix(n)
+    a = ChunkedDeviceMatrix(n, expect_chunks=len(cuts) - 1)
     b = np.empty(rows)
     xf = c = lb = ub = None
     for k, (r0, r1) in enumerate(zip(cuts, cuts[1:])):
