@@ -169,6 +169,41 @@ def test_more_than_2_31_stored_entries(c4slice):
     a.set_format(0)
 
 
+def test_chunked_c4slice_equals_the_unchunked_one_at_full_size(c4slice):
+    """The same 2.5e9-entry slice as a ChunkedDeviceMatrix (4 row chunks whose CSR never coexists, csrc/slp_chunked.hip): products
+    and Chambolle-Pock iterates bit for bit the unchunked ones -- which the next test pins against the CPU oracle at this size --
+    and the matrix-free ADMM to 1e-12.  BASELINE config 4 on one GPU (bench.py's default workload) is eight such chunks."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    a, n, rows, dens, seed = c4slice, C4S_N, C4S_ROWS, C4S_DENSITY, C4S_SEED
+    a.set_format(0)
+    xf, c, lb, ub, b = a.random_lp_vectors(dens, seed, 0)
+    ch, xf2, c2, lb2, ub2, b2 = random_lp_on_device(n, rows, dens, seed=seed, chunks=4)
+    try:
+        assert ch.chunks == 4 and ch.nnz == a.nnz and np.array_equal(b2, b) and np.array_equal(c2, c)
+        rng = np.random.RandomState(8)
+        x, y = rng.randn(n), rng.randn(rows)
+        assert np.array_equal(ch.matvec(x), a.matvec(x)) and np.array_equal(ch.rmatvec(y), a.rmatvec(y))
+        xs = []
+        for mat in (a, ch):
+            s = DeviceCP(mat, b, c, lb, ub)
+            s.iterate(3)
+            xs.append(s.x())
+            s.close()
+        assert np.array_equal(xs[0], xs[1])
+        xs = []
+        for mat in (a, ch):
+            s = DeviceADMM(mat, b, c, lb, ub)
+            s.iterate(3)
+            xs.append(s.x(n))
+            s.close()
+        assert float(np.max(np.abs(xs[0] - xs[1]) / (1 + np.abs(xs[0])))) <= 1e-12
+    finally:
+        ch.close()
+
+
 def test_c4slice_whole_solvers_match_the_cpu_oracle_at_full_size(c4slice):
     """The per-rank solvers of config 4 on the FULL slice against the oracle on the downloaded matrix: Chambolle-Pock bit for
     bit, matrix-free ADMM 1e-9 / 1e-6 in the objective.  Skips (visibly) when the host lacks the memory for the oracle's

@@ -217,3 +217,74 @@ def test_block_groups_overlap_their_exchanges_with_two_ranks_on_one_gpu():
     assert np.array_equal(asy[0]["x"], syn[0]["x"])
     one = run(1, "1")[0]   # the same three-plus-three blocks cannot be formed on one rank: compare with ITS three blocks' consensus
     assert one["collectives"] == 0 and np.all(np.isfinite(one["x"]))
+
+
+def _rank_chunked(rank, world, port, n, m, p, seed, iters, chunks, q):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                           "SLP_COMM_TRANSPORT": "host", "SLP_JOB_TOKEN": "chunked-%d" % port, "SLP_STRIP_MIN_NNZ": "1"})
+        from pysparselp_amd import _lib
+        from pysparselp_amd.admm_cg import DeviceADMM
+        from pysparselp_amd.parallel import init_comm_from_env, row_block
+        from pysparselp_amd.problems import random_lp_on_device
+        from pysparselp_amd.scale import DeviceCP
+
+        lib = _lib.lib(0)
+        if world > 1:
+            init_comm_from_env(rank, world)
+        r0, rows = row_block(m, world, rank)
+        a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=seed, row_offset=r0, rows=rows, chunks=chunks)
+        out = {"chunks": getattr(a, "chunks", 1)}
+        cp = DeviceCP(a, b, c, lb, ub)
+        cp.iterate(iters)
+        out["cp_x"] = cp.x()
+        cp.close()
+        admm = DeviceADMM(a, b, c, lb, ub)
+        admm.iterate(iters)
+        out["admm_x"] = admm.x(n)
+        admm.close()
+        a.close()
+        if world > 1:
+            _lib.check(lib.slp_comm_finalize())
+        q.put((rank, out))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, {"error": traceback.format_exc() + repr(e)}))
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_with_chunked_row_blocks_match_the_single_process_run():
+    """What ``bench.py --gpus 2`` does on the metric's LP: every rank's row block is itself a ChunkedDeviceMatrix (here 3 chunks
+    of a tall-cell shape).  Replicas bit-identical, equal to the single-process unchunked run to the all-reduce's re-association."""
+    import socket
+
+    n, m, p, seed, iters = 200000, 48000, 1.5e-4, 7, 24
+
+    def run(world, chunks):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rank_chunked, args=(r, world, port, n, m, p, seed, iters, chunks, q)) for r in range(world)]
+        for pr in procs:
+            pr.start()
+        res = {}
+        for _ in range(world):
+            rank, out = q.get(timeout=600)
+            assert "error" not in out, out["error"]
+            res[rank] = out
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+        return res
+
+    one = run(1, 1)[0]
+    two = run(2, 3)
+    assert two[0]["chunks"] == two[1]["chunks"] == 3
+    for key in ("cp_x", "admm_x"):
+        assert np.array_equal(two[0][key], two[1][key]), key
+        err = float(np.max(np.abs(two[0][key] - one[key]) / (1 + np.abs(one[key]))))
+        assert err < 1e-9, (key, err)
