@@ -558,10 +558,17 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
         }
         // columns past ncol read 0: the displacement of each double is part of the voffset, which the descriptor's range check
         // covers (an soffset is not checked on gfx9 raw buffers)
-        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 4u * (unsigned int)p) * 8u;
+#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 6 || SLP_TALL_ABL == 7)   // lab (wrong results): no x-tile loads
+        const unsigned int xo = kOob + 0u * xs;
+#else
+        // lane p carries doubles 2p, 2p + 1 of the tile's first half and of its second half: consecutive lanes then write
+        // consecutive 16-byte pieces of the LDS tile (no bank conflicts; with 4p .. 4p + 3 per lane the two 16-byte writes of a
+        // lane pair collided -- the tile write was the largest single item of the kernel's ablation, 0.9 of 4.1 ms)
+        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)i, 0, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)(i & 1) + (i >> 1) * (unsigned int)(kTallC * 4), 0, 0);
             g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
         }
     };
@@ -572,13 +579,23 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
         widths(h, c);
         if (xw & kPktNewCell) {
             // sums of the previous cell (other lanes owned these rows there) and the x-tile: LDS only, loads stay in flight
+#if !defined(SLP_TALL_ABL) || (SLP_TALL_ABL != 4 && SLP_TALL_ABL != 7)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             cur ^= 1;
         }
+#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 5 || SLP_TALL_ABL == 7)   // lab: no x-tile LDS write
+        if (false) {
+#else
         if ((xw & 0x7fffffffu) != kNoTile) {
-            double *dst = &xt[cur ^ 1][4 * p];
+#endif
+            // (Bringing the tile in by LDS-DMA -- __builtin_amdgcn_global_load_lds, no registers, no ds_write -- was built and
+            // measured: 4.71 ms against 3.99.  With two tile buffers the DMA can only start at the cell's barrier and must have
+            // landed by the next one, 1.6 us later; the register path issues the loads four cells ahead.  A third buffer does
+            // not fit beside 78 KB of running sums.)
+            double *dst = &xt[cur ^ 1][2 * p];
             *reinterpret_cast<double2 *>(dst) = make_double2(g.x[0], g.x[1]);
-            *reinterpret_cast<double2 *>(dst + 2) = make_double2(g.x[2], g.x[3]);
+            *reinterpret_cast<double2 *>(dst + kTallC / 2) = make_double2(g.x[2], g.x[3]);
         }
         const double *__restrict__ tile = xt[cur];
         // Four slots at a time: all twelve LDS reads (running sums, values, x) are issued together, the products do not
@@ -599,18 +616,32 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
                     row[k] = (w[k] >> kTallColBits) & ((1u << kTallRowBits) - 1);
                 }
             }
+#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)   // lab: no running-sum traffic
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ar[k] = (double)row[k];
+#else
 #pragma unroll
             for (int k = 0; k < 4; ++k) ar[k] = acc[row[k]];
+#endif
+#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 1 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)   // lab: no value / x gathers
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pr[k] = (double)(w[k] & 0x7fffffu) * tile[p];
+#else
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 pr[k] = DICT ? dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)]
                              : g.val[DICT ? 0 : k0 + k] * tile[w[k] & (kTallC - 1)];
+#endif
             t[0] = ar[0] + pr[0];
 #pragma unroll
             for (int k = 1; k < 4; ++k) t[k] = ((row[k] == row[k - 1]) ? t[k - 1] : ar[k]) + pr[k];
+#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)
+            if ((unsigned)p < c[k0 + 3] && !(hb[3] & 0x80u)) acc[p] = ((t[0] + t[1]) + t[2]) + t[3];   // one store per group keeps the work alive
+#else
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if ((unsigned)p < c[k0 + k] && !(hb[k] & 0x80u)) acc[row[k]] = t[k];
+#endif
         };
         if (wbase < c[0]) {
             group(0);
