@@ -49,6 +49,7 @@ constexpr int kTallDictMax = 2048;
 constexpr int kTallBuckets = 6;    // rows are ordered by min(entries in the cell, 6), descending
 constexpr int kTallIdBits = 11, kTallColBits = 12, kTallRowBits = 14;
 constexpr int kTallCellShift = kTallIdBits + kTallColBits + kTallRowBits;  // sort key: cell | row | column | id
+static_assert(kTallBuckets * 32 == 3 * kWave, "k_tall_build scans the (count, bank class) buckets three per lane of one wave");
 static_assert(kTallRmax < (1 << kTallRowBits) && kTallC == (1 << kTallColBits) && kTallDictMax == (1 << kTallIdBits), "tall geometry");
 // LDS of the product kernel: sums + value table + two x-tiles
 static_assert(kTallRmax * 8 + kTallDictMax * 8 + 2 * kTallC * 8 <= 160 * 1024, "tall cells: LDS budget");
@@ -282,10 +283,19 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
             for (int cl = kTallBuckets; cl >= 1; --cl)
                 bcnt[(kTallBuckets - cl) * 32 + p] = (unsigned int)(((cl > 3 ? ta : tb) >> (21 * ((cl > 3 ? kTallBuckets : 3) - cl))) & 0x1fffffu);
         __syncthreads();
-        if (p == 0) {
-            unsigned int run = 0;
-            for (int q = 0; q < kTallBuckets * 32; ++q) { bstart[q] = run; run += bcnt[q]; }
-            bstart[kTallBuckets * 32] = run;
+        if (p < kWave) {   // exclusive scan of the 192 bucket counts by one wave: three per lane (one thread walking them was
+            const unsigned int c0 = bcnt[3 * p], c1 = bcnt[3 * p + 1], c2 = bcnt[3 * p + 2];  // 8 of the ~30 us a cell takes)
+            unsigned int inc = c0 + c1 + c2;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const unsigned int o = __shfl_up(inc, off, kWave);
+                if (p >= off) inc += o;
+            }
+            const unsigned int ex = inc - (c0 + c1 + c2);
+            bstart[3 * p] = ex;
+            bstart[3 * p + 1] = ex + c0;
+            bstart[3 * p + 2] = ex + c0 + c1;
+            if (p == kWave - 1) bstart[kTallBuckets * 32] = inc;
         }
         __syncthreads();
         for (int m = m0; m < m1; ++m) {
