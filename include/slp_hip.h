@@ -136,10 +136,11 @@ int64_t slp_matrix_format_bytes(slp_matrix *a, int transposed);
  * 288 GB GPU this way (208 GB of tall cells for both orientations). */
 slp_matrix *slp_matrix_chunked_create(int64_t ncol);
 int slp_matrix_chunked_append(slp_matrix *chunked, slp_matrix *chunk);
-/* Optional: how many chunks will be appended in all.  While chunks are still to come, every append then asks a helper thread
- * to hipMalloc the next chunk's two packet-stream buffers (sizes of the chunk just appended) beside the generation and
- * conversion of that chunk: on boxes whose hipMalloc runs at ~27 ms per GB this hides most of the 0.7 s per chunk it costs at
- * config 4's size.  Never changes results. */
+/* Optional: how many chunks will be appended in all.  With SLP_RESERVE=1 in the environment every append that is not the last
+ * then asks a helper thread to hipMalloc the next chunk's two packet-stream buffers (sizes of the chunk just appended) beside
+ * the generation and conversion of that chunk: on boxes whose hipMalloc runs at ~27 ms per GB this hid 3.4 of config 4's
+ * 10.4 s of set-up; on quick-malloc boxes it LOST time and it raises the peak footprint by the blocks taken ahead (measured:
+ * 279.8 -> 302.9 GB), hence off unless asked for.  Never changes results. */
 int slp_matrix_chunked_expect(slp_matrix *chunked, int64_t chunks);
 /* Chunks appended so far; 0 for an ordinary matrix, -1 for NULL. */
 int64_t slp_matrix_chunks(const slp_matrix *a);

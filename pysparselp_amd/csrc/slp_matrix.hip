@@ -67,8 +67,11 @@ static void reserve_join() {
 }
 
 void dev_reserve_async(const std::vector<size_t> &sizes) {
-    static const bool off = [] { const char *e = getenv("SLP_NO_RESERVE"); return e && e[0] == '1'; }();
-    if (off || sizes.empty()) return;
+    // OPT-IN (SLP_RESERVE=1).  Measured at config 4: on a box whose hipMalloc runs at 27 ms per GB the set-up went 10.4 -> 7.0 s;
+    // on a quick-malloc box it went 5.3 -> 8.8 s, and either way the blocks taken ahead sit beside the conversion's cached
+    // temporaries: the peak held rose from 279.8 to 302.9 GB of the 309 GB device.  Not worth that by default.
+    static const bool on = [] { const char *e = getenv("SLP_RESERVE"); return e && e[0] == '1'; }();
+    if (!on || sizes.empty()) return;
     static const bool at_exit = (atexit([] { reserve_join(); }), true);  // a joinable std::thread must not reach its destructor
     (void)at_exit;
     reserve_join();  // (one helper at a time: requests are few and large)
