@@ -72,6 +72,34 @@ def test_committed_round3_bench_lines(name):
         assert d["cpu_baseline"]["full_size_validation"]["source"] == "profiles/r03_cpu_full_c3.json"
 
 
+@pytest.mark.parametrize("name", ["r04_bench_admm_c4_1gpu.json", "r04_bench_cp_c4_1gpu.json", "r04_bench_admm_c4slice.json",
+                                  "r04_bench_admm_c3.json"])
+def test_committed_round4_bench_lines(name):
+    """Round 4: the default workload is the LP BASELINE.json's metric names -- 1e7 variables x 2e7 rows at the density that fits
+    (1e-4), resident on ONE GPU in row chunks -- with config 3 as the secondary block of the default line."""
+    d = json.loads(open(os.path.join(REPO, "profiles", name)).read().strip().splitlines()[-1])
+    check_line(d, need_cpu_baseline=True)
+    r = d["roofline"]
+    assert d["n_gpus"] == 1 and 0.0 < r["frac"] <= 1.0
+    if "c4_1gpu" in name:
+        assert (d["config"]["n"], d["config"]["m"], d["config"]["density"]) == (10_000_000, 20_000_000, 1e-4)
+        assert d["config"]["chunks_per_rank"] == 8 and d["config"]["nnz"] > 1.9e10 and "row chunks" in d["config"]["workload"]
+        assert "k_tall_spmv" in r["kernel"] and r["frac"] >= 0.40                       # north_star: >= 40 % of the HBM roofline on the SpMV
+        assert r["launches_per_product"] == 8
+        assert r["traffic"] is not None and abs(r["traffic"] / r["bytes_per_launch"] - 1.0) < 0.15   # PMC bytes = the copy, per PRODUCT
+        assert d["device_memory"]["in_use_in_timed_region_gb"] < 288 and d["setup_breakdown"]["peak_device_gb"] < 300
+        assert d["cpu_baseline"]["extrapolated"] is True and d["cpu_baseline"]["cores"] == 1
+        if "admm" in name:                                                                # the default line carries config 3 too
+            c3 = d["secondary"]["c3"]
+            assert c3["config"]["n"] == 1_000_000 and c3["value"] > 100 and 0.4 < c3["roofline"]["frac"] <= 1.0
+    elif "c4slice" in name:
+        assert d["config"]["chunks_per_rank"] == 1 and r["frac"] >= 0.38
+    else:
+        assert d["config"]["n"] == 1_000_000 and d["value"] > 100
+        assert d["cpu_baseline"]["extrapolated"] is False                                 # the full-size one-thread measurement
+        assert d["cpu_baseline"]["value_extrapolated_from_sample"] > d["cpu_baseline"]["value"] * 0.8
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["admm", "chambolle_pock_ppd"])
 def test_live_bench_line(method):
