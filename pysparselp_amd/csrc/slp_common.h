@@ -269,6 +269,7 @@ void strip_spmv_abs_pow(const StripJds &f, double pw, const double *x, double *o
 bool tall_wanted(i64 nrow, i64 ncol, i64 nnz);
 bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict);
 void tall_spmv(const StripJds &f, const double *x, double *out, int accum);
+void tall_spmv_pow(const StripJds &f, double pw, const double *x, double *out, int accum);  // fp64 entries: values |v|^pw * 1.0
 size_t strip_format_bytes(const StripJds &f);   // bytes of the copy a product streams (composites: all chunks)
 
 }  // namespace slp

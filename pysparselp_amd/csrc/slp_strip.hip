@@ -1160,6 +1160,7 @@ void strip_spmv(const StripJds &f, const double *x, double *out) {
 }
 
 static void strip_spmv_pow_one(const StripJds &f, double pw, const double *x, double *out, int accum) {
+    if (f.ok && f.tall && f.D == 0) { tall_spmv_pow(f, pw, x, out, accum); return; }
     SLP_REQUIRE(f.ok && !f.wide && !f.tall && f.D == 0, "strip_spmv_pow: not an fp64 strip copy");
     SLP_WITH_ACC(accum, hipLaunchKernelGGL((k_strip_spmv<0, true, false, true, ACC>), dim3((unsigned)f.B, (unsigned)f.S), dim3(kStripT), 0,
                                            ctx().stream, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p, f.soff.p, f.val.p, f.col.p, x,
@@ -1195,14 +1196,15 @@ void strip_spmv_with_dict(const StripJds &f, const double *table, const double *
     strip_spmv_with_dict_one(f, table, x, out, 0);
 }
 
-// Can strip_spmv_abs_pow run on this copy?  Dictionary copies of every kind, and fp64 LDS strips.
+// Can strip_spmv_abs_pow run on this copy?  Dictionary copies of every kind, fp64 LDS strips and fp64 tall cells (not the
+// fp64 wide strips, the fallback of the fallback).
 bool strip_abs_pow_supported(const StripJds &f) {
     if (!f.parts.empty()) {
         for (const StripJds *g : f.parts)
             if (!strip_abs_pow_supported(*g)) return false;
         return true;
     }
-    return f.ok && (f.D > 0 || (!f.wide && !f.tall));
+    return f.ok && (f.D > 0 || !f.wide);
 }
 
 // out = |A|^pw x: every stored value v enters as |v|^pw * 1.0 (the sums behind the Chambolle-Pock preconditioners,

@@ -497,10 +497,12 @@ struct TallRegs {
 };
 
 // DICT: depth 4 (20 KB of payload per packet); fp64 entries: depth 2 (48 KB per packet, 16 more registers per packet)
-template <bool DICT, bool ACC>
+// POW (fp64 entries only): every stored value v enters as |v|^pw * 1.0 -- the sums behind the Chambolle-Pock preconditioners
+// (slp_cp.hip, strip_spmv_abs_pow) over a copy without a value table; the same chain of additions as the CSR walk.
+template <bool DICT, bool ACC, bool POW = false>
 __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, int S, const TallWg *__restrict__ wgs,
                                                       const double *__restrict__ dict, int D, const double *__restrict__ x,
-                                                      double *__restrict__ out) {
+                                                      double *__restrict__ out, double pw) {
     constexpr int kDepth = DICT ? kTallDepth : 2;
     __shared__ double acc[kTallRmax];
     __shared__ double dv[kTallDictMax];
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 pr[k] = DICT ? dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)]
-                             : g.val[DICT ? 0 : k0 + k] * tile[w[k] & (kTallC - 1)];
+                             : (POW ? abs_pow(g.val[DICT ? 0 : k0 + k], pw) * 1.0 : g.val[DICT ? 0 : k0 + k]) * tile[w[k] & (kTallC - 1)];
 #endif
             t[0] = ar[0] + pr[0];
 #pragma unroll
@@ -894,10 +896,26 @@ void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
     const bool acc = accum && f.S == 1;
 #define SLP_TALL_LAUNCH(DICT, ACC)                                                                                                   \
     hipLaunchKernelGGL((k_tall_spmv<DICT, ACC>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_wg.p, \
-                       DICT ? f.dict : (const double *)nullptr, DICT ? f.D : 0, x, dst)
+                       DICT ? f.dict : (const double *)nullptr, DICT ? f.D : 0, x, dst, 0.0)
     if (f.D > 0) { if (acc) SLP_TALL_LAUNCH(true, true); else SLP_TALL_LAUNCH(true, false); }
     else { if (acc) SLP_TALL_LAUNCH(false, true); else SLP_TALL_LAUNCH(false, false); }
 #undef SLP_TALL_LAUNCH
+    if (f.S > 1)
+        hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
+    SLP_HIP(hipGetLastError());
+}
+
+// out = |A|^pw x over a tall-cell copy with fp64 entries (strip_spmv_abs_pow)
+void tall_spmv_pow(const StripJds &f, double pw, const double *x, double *out, int accum) {
+    SLP_REQUIRE(f.ok && f.tall && f.D == 0, "tall_spmv_pow: not a tall-cell copy with fp64 entries");
+    double *dst = f.S > 1 ? f.part.p : out;
+    const unsigned grid = (unsigned)(f.B * f.S);
+    if (accum && f.S == 1)
+        hipLaunchKernelGGL((k_tall_spmv<false, true, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S,
+                           f.tall_wg.p, (const double *)nullptr, 0, x, dst, pw);
+    else
+        hipLaunchKernelGGL((k_tall_spmv<false, false, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S,
+                           f.tall_wg.p, (const double *)nullptr, 0, x, dst, pw);
     if (f.S > 1)
         hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());

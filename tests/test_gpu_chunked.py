@@ -215,3 +215,17 @@ def test_chunked_api_errors():
     with pytest.raises(SlpError, match="chunked"):
         a.random_lp_vectors(1e-3, 1, 0)             # b_upper needs the CSR: chunk by chunk, before the append
     a.close()
+
+
+def test_randomised_chunkings_match_the_oracle_bit_for_bit():
+    """A slim run of tools/fuzz_chunked.py (random shapes in the tall-cell and LDS-strip regimes, 2-6 chunks with random even cuts,
+    empty rows, forced block heights, value dictionary or fp64 entries): products and Chambolle-Pock iterates against the oracle."""
+    import importlib.util
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_chunked", os.path.join(repo, "tools", "fuzz_chunked.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen, skipped, solved = mod.run(24, seed=21)
+    os.environ["SLP_STRIP_MIN_NNZ"] = "1"   # (the fixture removes it again)
+    assert sum(seen.values()) >= 2 * 12 and solved >= 3, (seen, skipped, solved)
