@@ -405,6 +405,7 @@ def run_workload(lib, args, rank, world, distributed):
             "bytes_per_launch": ax["bytes_per_launch"],
             "matrix_copy_bytes_per_launch": ax["matrix_copy_bytes_per_launch"],
             "ms_per_launch": ax["ms_per_launch"],
+            "launches_per_product": ax["launches_per_product"],   # a chunked matrix: one launch per row chunk; "per launch" = per product
             "csr_equivalent": ax["csr_equivalent"],
             "spmv_transposed": aty,
             "iteration": {"bytes": iter_bytes, "achieved": iter_bytes / (ms_step * 1e-3) / 1e9,
