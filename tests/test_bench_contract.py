@@ -114,11 +114,11 @@ def test_live_bench_line(method):
     assert d["steps"] == 4 and d["warmup"] == 1 and d["n_gpus"] == 1
 
 
-def _launch(nproc, extra_env, port):
+def _launch(nproc, extra_env, port, more=()):
     env = dict(os.environ, **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(nproc), "--steps", "4", "--warmup", "2",
-           "--vars", "30000", "--rows", "40000", "--density", "0.001", "--no-cpu-baseline", "--no-general"]
+           "--vars", "30000", "--rows", "40000", "--density", "0.001", "--no-cpu-baseline", "--no-general"] + list(more)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
@@ -144,6 +144,18 @@ def test_bench_under_the_launcher_two_ranks_on_one_gpu():
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["collectives_per_iteration"] == 2.0
     one = _launch(1, {"SLP_STRIP_MIN_NNZ": "1"}, 29651)
     assert two["config"]["nnz"] == one["config"]["nnz"]
+    assert abs(two["objective_after_run"] - one["objective_after_run"]) <= 1e-9 * (1 + abs(one["objective_after_run"]))
+
+
+@pytest.mark.gpu
+def test_bench_under_the_launcher_two_ranks_with_chunked_row_blocks():
+    """What the driver's `--gpus 2` run does on the default workload, in small: every rank's row block is itself generated,
+    converted and released in row chunks (`--chunks 3`); same objective as the single-process unchunked run."""
+    two = _launch(2, {"SLP_DEVICE": "0", "SLP_COMM_TRANSPORT": "host", "SLP_STRIP_MIN_NNZ": "1"}, 29681, more=("--chunks", "3"))
+    check_line(two, need_cpu_baseline=False)
+    assert two["n_gpus"] == 2 and two["config"]["chunks_per_rank"] == 3 and "row chunks" in two["config"]["workload"]
+    one = _launch(1, {"SLP_STRIP_MIN_NNZ": "1"}, 29691)
+    assert one["config"]["chunks_per_rank"] == 1 and two["config"]["nnz"] == one["config"]["nnz"]
     assert abs(two["objective_after_run"] - one["objective_after_run"]) <= 1e-9 * (1 + abs(one["objective_after_run"]))
 
 
