@@ -24,6 +24,10 @@
 namespace slp {
 bool comm_active();
 void comm_allreduce_dev(double *buf, i64 count, int op);
+void comm_reduce_scatter_dev(double *buf, i64 cnt);
+void comm_all_gather_dev(double *buf, i64 cnt);
+int comm_rank();
+int comm_size();
 
 constexpr int kCgPartials = 2048;
 constexpr int kCgTail = 8;       // doubles reserved behind u / u2 for the packed exchange
@@ -80,6 +84,7 @@ struct CgVecs {
     int carry_md;  // reuse level 4: E_PAP stores M r (in y), E_UPDATE advances M dir = step M dir + a_cg M r
     const double *scal;
     i64 n_o, N;
+    i64 o0, o1;  // the original variables this launch walks: [0, n_o), or this rank's slice of them (sharded updates)
     double gamma_eq, gamma_ineq, alpha, one_minus_alpha;
 };
 
@@ -104,8 +109,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_elem(CgVecs a, double *__restrict
         step = fabs(t) > 0.0 ? t / (a.scal[S_DMD] + a.scal[S_DMD + 1]) : 0.0;
     }
     const bool slack = (int)blockIdx.x >= go;
-    const i64 j_begin = slack ? a.n_o + ((i64)blockIdx.x - go) * kBlock + threadIdx.x : (i64)blockIdx.x * kBlock + threadIdx.x;
-    const i64 j_end = slack ? a.N : a.n_o;
+    const i64 j_begin = slack ? a.n_o + ((i64)blockIdx.x - go) * kBlock + threadIdx.x : a.o0 + (i64)blockIdx.x * kBlock + threadIdx.x;
+    const i64 j_end = slack ? a.N : a.o1;
     const i64 j_stride = (slack ? (i64)gridDim.x - go : (i64)go) * kBlock;
     for (i64 j = j_begin; j < j_end; j += j_stride) {
         double term = 0.0;
@@ -229,6 +234,35 @@ __global__ __launch_bounds__(kBlock) void k_cg_finish2(int go, int nparts, const
             scal[slot] = ra;
             scal[slot + 1] = tail_mode == 1 ? tail[which] : rb;
         }
+    }
+}
+
+// ---- sharded updates (SLP_SHARD_UPDATES=1, rows partitioned, level 4): every rank runs the elementwise passes over ITS slice of
+// the original variables only; the slice's share of a dot product goes into a small exchange vector `ex` that is all-reduced:
+//   ex[0] dir.g  ex[1] dir.Md   (this rank's slice)        ex[2..7) the five rank-local slack sums of k_cg_slack_pre
+//   ex[8] r.r    ex[9] r.Mr     (this rank's slice)        ex[10]   the rank-local slack part of r.Mr (k_cg_slack_pap)
+__global__ __launch_bounds__(kBlock) void k_cg_ex_finish(int go, const double *__restrict__ part, double *__restrict__ ex, int i0, int two) {
+    __shared__ double lds[kBlock / kWave];
+    for (int which = 0; which <= two; ++which) {
+        double a = 0.0;
+        for (int i = threadIdx.x; i < go; i += kBlock) a += part[which * kCgPartials + i];
+        const double r = block_reduce<false>(a, lds);
+        if (threadIdx.x == 0) ex[i0 + which] = r;
+    }
+}
+
+// the iteration's scalars from the all-reduced exchange vector: mode 0 after ex[0..7), mode 1 after ex[8..11)
+__global__ void k_cg_scal_from_ex(const double *__restrict__ ex, double *__restrict__ scal, int mode) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (mode == 0) {
+        scal[S_T] = ex[0]; scal[S_T + 1] = ex[2];
+        scal[S_DMD] = ex[1]; scal[S_DMD + 1] = ex[3];
+    } else {
+        const double t = -(scal[S_T] + scal[S_T + 1]);
+        const double f = t / (scal[S_DMD] + scal[S_DMD + 1]);
+        scal[S_RS] = ex[8];   // r = -(g + step M dir): r.r over the slack unknowns from the three reduced coefficients (k_cg_finish, mode 2)
+        scal[S_RS + 1] = fabs(t) > 0.0 ? (ex[4] + 2.0 * f * ex[5]) + (f * f) * ex[6] : ex[4];
+        scal[S_PAP] = ex[9]; scal[S_PAP + 1] = ex[10];
     }
 }
 
@@ -502,6 +536,12 @@ struct slp_admm_cg {
     DevBuf<double> part, rowpart, colpart, scal, out;
     DevBuf<double> wx, wd, u2, v1;   // batched form: A x, A dir, g_eq A x + lambda (rows) and the two A^T products (2 n_o)
     bool have_w = false;
+    // sharded updates (cg_xstep_sharded): this rank's slice [o0, o1) of the original variables; slice_on: the elementwise
+    // launches walk the slice only; shard_dirty: the slice-only vectors (dir, md, g, xprev, xp, lin -- and x between the two
+    // halves of an iteration) are current on their owner only (cg_gather_state makes them whole again)
+    bool sharded = false, slice_on = false, shard_dirty = false;
+    i64 o0 = 0, o1 = 0, scnt = 0;
+    DevBuf<double> ex;
     bool started = false;   // at least one full iteration done: the steady-state kernel sequence can be replayed
     IterGraph graph;        // launch-bound problems: iterations replayed as a captured graph
 };
@@ -625,6 +665,7 @@ static CgVecs cg_vecs(slp_admm_cg *s, const double *u, const double *w) {
     v.x = s->x.p; v.xp = s->xp.p; v.y = s->y.p; v.dir = s->dir.p; v.xprev = s->xprev.p; v.r = s->r.p; v.lin = s->lin.p;
     v.mx = s->mx.p; v.md = s->md.p; v.keep = s->reuse ? 1 : 0; v.carry_md = s->reuse >= 4 ? 1 : 0;
     v.scal = s->scal.p; v.n_o = s->n_o; v.N = s->N;
+    v.o0 = s->slice_on ? s->o0 : 0; v.o1 = s->slice_on ? s->o1 : s->n_o;
     v.gamma_eq = s->gamma_eq; v.gamma_ineq = s->gamma_ineq; v.alpha = s->alpha; v.one_minus_alpha = 1.0 - s->alpha;
     return v;
 }
@@ -703,8 +744,73 @@ static void cg_refresh_products(slp_admm_cg *s) {  // wx = A x, wd = A dir
     s->have_w = true;
 }
 
+// Every slice-only vector whole again on every rank (before anything that reads them outside the sharded steady state: the
+// refresh iteration, a report, a change of mode).  Collective: every rank calls it at the same points.
+static void cg_gather_state(slp_admm_cg *s) {
+    if (!s->sharded || !s->shard_dirty) return;
+    for (double *v : {s->x.p, s->dir.p, s->md.p, s->mx.p, s->xprev.p, s->xp.p, s->lin.p}) comm_all_gather_dev(v, s->scnt);
+    s->shard_dirty = false;
+}
+
+template <int OP>
+static void cg_elem_launch(slp_admm_cg *s, const double *u, const double *w) {
+    int go, gs;
+    cg_grids(s, &go, &gs);
+    hipLaunchKernelGGL((k_cg_elem<OP>), dim3(go + gs), dim3(kBlock), 0, ctx().stream, cg_vecs(s, u, w), s->part.p, go);
+    SLP_HIP(hipGetLastError());
+}
+
+static void cg_ex_finish(slp_admm_cg *s, int i0, int two) {
+    int go, gs;
+    cg_grids(s, &go, &gs);
+    hipLaunchKernelGGL(k_cg_ex_finish, dim3(1), dim3(kBlock), 0, ctx().stream, go, s->part.p, s->ex.p, i0, two);
+    SLP_HIP(hipGetLastError());
+}
+
+// The level-4 steady-state x-step with the replicated work SHARDED: the two all-reduces of the variable
+// vector become reduce-scatter ... all-gather pairs (the same bytes over the links) and the elementwise passes between them
+// run over n / N variables instead of n; the slice-partial dot products travel in two small all-reduces.  Six collectives
+// per iteration instead of two.  Replicas stay bit-identical by construction: a slice is computed by its owner alone and
+// gathered; every scalar is the result of an all-reduce.
+static void cg_xstep_sharded(slp_admm_cg *s) {
+    hipStream_t st = ctx().stream;
+    double *ex = s->ex.p;
+    cg_slack_pre(s, false, ex + 2);                                   // five rank-local slack sums
+    cg_cols(s, s->v1.p, s->u2.p, false);                              // this rank's partial A^T v1 ...
+    comm_reduce_scatter_dev(s->u2.p, s->scnt);                        // ... summed, my slice of it
+    s->slice_on = true;
+    cg_elem_launch<E_GRAD_DMD>(s, s->u2.p, s->v1.p);                  // g, xprev, and the slice's dir.g / dir.Md
+    cg_ex_finish(s, 0, 1);
+    comm_allreduce_dev(ex, 7, 0);
+    hipLaunchKernelGGL(k_cg_scal_from_ex, dim3(1), dim3(64), 0, st, ex, s->scal.p, 0);
+    cg_elem_launch<E_STEP_RESID>(s, nullptr, nullptr);                // x += step dir ; r = -(g + step M dir) ; the slice's r.r
+    cg_ex_finish(s, 8, 0);
+    s->slice_on = false;
+    comm_all_gather_dev(s->r.p, s->scnt);                             // A r needs all of r
+    cg_rows(s, s->r.p);
+    cg_slack_pap(s, s->w.p, ex + 10);
+    cg_cols(s, s->w.p, nullptr, false);
+    comm_reduce_scatter_dev(s->u.p, s->scnt);
+    s->slice_on = true;
+    cg_elem_launch<E_PAP>(s, nullptr, nullptr);                       // M r on the slice, the slice's r.Mr
+    cg_ex_finish(s, 9, 0);
+    comm_allreduce_dev(ex + 8, 3, 0);
+    hipLaunchKernelGGL(k_cg_scal_from_ex, dim3(1), dim3(64), 0, st, ex, s->scal.p, 1);
+    cg_elem_launch<E_UPDATE>(s, nullptr, nullptr);
+    s->slice_on = false;
+    hipLaunchKernelGGL(k_cg_wd_update, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, s->scal.p, s->w.p, s->wd.p);
+    SLP_HIP(hipGetLastError());
+    s->have_w = false;
+    s->shard_dirty = true;
+}
+
 // first half of an iteration: everything up to (and including) the over-relaxed x (:148-201)
 static void cg_xstep(slp_admm_cg *s) {
+    if (s->sharded && s->reuse >= 4 && !s->need_md && s->have_w && cg_batched(s)) {
+        cg_xstep_sharded(s);
+        return;
+    }
+    cg_gather_state(s);
     if (s->reuse >= 2 && cg_batched(s)) {
         // fused: [A^T (g_eq A x + lambda), A^T (A dir)] in one two-vector pass; y is never formed
         if (!s->have_w) {
@@ -770,7 +876,15 @@ static void cg_xstep(slp_admm_cg *s) {
 
 // second half: projection step and both multiplier updates (:253-263)
 static void cg_multipliers(slp_admm_cg *s) {
-    cg_elem<E_PROJECT>(s, -1);
+    if (s->sharded && s->shard_dirty) {     // the projection on my slice, then x whole again for A x
+        s->slice_on = true;
+        cg_elem_launch<E_PROJECT>(s, nullptr, nullptr);
+        s->slice_on = false;
+        comm_all_gather_dev(s->x.p, s->scnt);
+        if (!(s->reuse >= 3 && cg_batched(s) && s->u2.p && s->since_refresh + 1 < 64)) cg_gather_state(s);  // the refresh walks whole vectors
+    } else {
+        cg_elem<E_PROJECT>(s, -1);
+    }
     const double *ax = s->w.p;
     if (s->reuse >= 3 && cg_batched(s) && s->u2.p && ++s->since_refresh < 64) {
         cg_rows(s, s->x.p, s->wx.p);  // A dir came from the recurrence (k_cg_wd_update): one product, one vector
@@ -801,6 +915,18 @@ static void cg_alloc_state(slp_admm_cg *s) {
     s->part.alloc((size_t)kCgPartials * 2); s->rowpart.alloc((size_t)kCgPartials * 3); s->colpart.alloc((size_t)kCgPartials * 8);
     s->scal.alloc(S_COUNT); s->scal.zero(); s->out.alloc(16);
     s->distributed = comm_active();
+    {
+        const char *es = getenv("SLP_SHARD_UPDATES");
+        const int nr = comm_size();
+        s->sharded = s->distributed && es && es[0] == '1' && nr > 1 && s->ns > 0 && s->n_o > 0 && s->n_o % nr == 0;
+        if (s->sharded) {
+            s->scnt = s->n_o / nr;
+            s->o0 = (i64)comm_rank() * s->scnt;
+            s->o1 = s->o0 + s->scnt;
+            s->ex.alloc(16);
+            s->ex.zero();
+        }
+    }
     s->lanes_rows = lanes_for(s->a->a, s->order);
     s->lanes_cols = lanes_for(s->a->at, s->order);
     hipStream_t st = ctx().stream;
@@ -984,6 +1110,7 @@ int slp_admm_cg_iterate(slp_admm_cg *s, int64_t k) {
 int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse) {
     SLP_API_INT({
         SLP_REQUIRE(s, "NULL handle");
+        cg_gather_state(s);
         if (reuse && s->mx.n < (size_t)s->N) { s->mx.alloc((size_t)s->N); s->md.alloc((size_t)s->N); s->mx.zero(); s->md.zero(); }
         s->reuse = reuse < 0 ? 0 : (reuse > 4 ? 4 : reuse);
         s->since_refresh = 0;
@@ -994,7 +1121,13 @@ int slp_admm_cg_set_reuse(slp_admm_cg *s, int reuse) {
     })
 }
 
-int slp_admm_cg_xstep(slp_admm_cg *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cg_xstep(s); }) }
+int slp_admm_cg_xstep(slp_admm_cg *s) {
+    SLP_API_INT({
+        SLP_REQUIRE(s, "NULL handle");
+        cg_xstep(s);
+        if (s->sharded && s->shard_dirty) comm_all_gather_dev(s->x.p, s->scnt);  // the caller may read x between the halves (report, callback)
+    })
+}
 
 int slp_admm_cg_multiplier_step(slp_admm_cg *s) {
     SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cg_multipliers(s); s->started = true; })
@@ -1004,6 +1137,10 @@ int slp_admm_cg_report(slp_admm_cg *s, double out[3]) {
     SLP_API_INT({
         SLP_REQUIRE(s && out, "slp_admm_cg_report: NULL argument");
         hipStream_t st = ctx().stream;
+        if (s->sharded && s->shard_dirty) {   // x is whole (slp_admm_cg_xstep gathered it); the sums below also walk xp and lin
+            comm_all_gather_dev(s->xp.p, s->scnt);
+            comm_all_gather_dev(s->lin.p, s->scnt);
+        }
         cg_rows(s, s->x.p);
         int gr = std::min(grid_for(s->m, kBlock), kCgPartials), gc = std::min(grid_for(s->N, kBlock), kCgPartials);
         hipLaunchKernelGGL(k_cg_report_rows, dim3(gr), dim3(kBlock), 0, st, s->m, s->w.p, s->b.p, s->lam.p, s->rowpart.p);

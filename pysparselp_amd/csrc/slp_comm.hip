@@ -42,6 +42,8 @@ static struct {
     decltype(&ncclGetUniqueId) get_unique_id = nullptr;
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclReduceScatter) reduce_scatter = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
     ncclComm_t comm = nullptr;
@@ -153,9 +155,11 @@ static void load_rccl() {
     g.get_unique_id = (decltype(g.get_unique_id))dlsym(g.lib, "ncclGetUniqueId");
     g.comm_init_rank = (decltype(g.comm_init_rank))dlsym(g.lib, "ncclCommInitRank");
     g.all_reduce = (decltype(g.all_reduce))dlsym(g.lib, "ncclAllReduce");
+    g.reduce_scatter = (decltype(g.reduce_scatter))dlsym(g.lib, "ncclReduceScatter");
+    g.all_gather = (decltype(g.all_gather))dlsym(g.lib, "ncclAllGather");
     g.comm_destroy = (decltype(g.comm_destroy))dlsym(g.lib, "ncclCommDestroy");
     g.error_string = (decltype(g.error_string))dlsym(g.lib, "ncclGetErrorString");
-    SLP_REQUIRE(g.get_unique_id && g.comm_init_rank && g.all_reduce && g.comm_destroy, "RCCL symbols missing");
+    SLP_REQUIRE(g.get_unique_id && g.comm_init_rank && g.all_reduce && g.comm_destroy && g.reduce_scatter && g.all_gather, "RCCL symbols missing");
 }
 
 static void check(ncclResult_t rc, const char *what) {
@@ -179,6 +183,10 @@ void comm_allreduce_dev(double *buf, i64 count, int op) {
     ++g.collectives;
     hipStream_t st = ctx().stream;
     if (g.host_fn) {
+        // lab (tools/shard_compute_only.py): SLP_COMM_NULL=1 skips the exchange altogether -- WRONG results, for timing the
+        // compute side of one rank of N on one GPU without the host transport's PCIe copies in the way
+        static const bool null_comm = [] { const char *e = getenv("SLP_COMM_NULL"); return e && e[0] == '1'; }();
+        if (null_comm) return;
         if (hw.running) host_worker_drain(true);  // (collectives reach the callback in issue order)
         if (g.host_buf.size() < (size_t)count) g.host_buf.resize((size_t)count);
         SLP_HIP(hipMemcpyAsync(g.host_buf.data(), buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -190,6 +198,43 @@ void comm_allreduce_dev(double *buf, i64 count, int op) {
         return;
     }
     check(g.all_reduce(buf, buf, (size_t)count, ncclFloat64, op == 1 ? ncclMax : ncclSum, g.comm, st), "ncclAllReduce");
+}
+
+int comm_rank() { return g.active ? g.rank : 0; }
+int comm_size() { return g.active ? g.nranks : 1; }
+
+__global__ void k_comm_keep_slice(i64 total, i64 lo, i64 hi, double *__restrict__ buf) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (i64)gridDim.x * blockDim.x)
+        if (j < lo || j >= hi) buf[j] = 0.0;
+}
+
+// In-place sum reduce-scatter over `cnt * nranks` doubles at `buf`: afterwards rank k's slice buf[k cnt .. (k+1) cnt) holds the
+// sums (the other slices are unspecified), and the in-place all-gather of those slices -- the two halves of an all-reduce, used
+// by the sharded ADMM updates (slp_admm_cg.hip): the same bytes over the links, the elementwise work between them on 1/N of the
+// variables.  On the compute stream.  Host transport: an all-reduce (of the whole buffer / of the buffer with the foreign slices
+// zeroed: x + 0 is exact).
+void comm_reduce_scatter_dev(double *buf, i64 cnt) {
+    SLP_REQUIRE(g.active, "slp_comm_init has not been called");
+    if (cnt <= 0) return;
+    if (g.host_fn) { comm_allreduce_dev(buf, cnt * g.nranks, 0); return; }
+    ++g.collectives;
+    check(g.reduce_scatter(buf, buf + (i64)g.rank * cnt, (size_t)cnt, ncclFloat64, ncclSum, g.comm, ctx().stream), "ncclReduceScatter");
+}
+
+void comm_all_gather_dev(double *buf, i64 cnt) {
+    SLP_REQUIRE(g.active, "slp_comm_init has not been called");
+    if (cnt <= 0) return;
+    if (g.host_fn) {
+        const i64 total = cnt * g.nranks;
+        { const char *e = getenv("SLP_COMM_NULL"); if (e && e[0] == '1') { ++g.collectives; return; } }
+        hipLaunchKernelGGL(k_comm_keep_slice, dim3(grid_for(total, 256)), dim3(256), 0, ctx().stream, total, (i64)g.rank * cnt,
+                           (i64)(g.rank + 1) * cnt, buf);
+        SLP_HIP(hipGetLastError());
+        comm_allreduce_dev(buf, total, 0);
+        return;
+    }
+    ++g.collectives;
+    check(g.all_gather(buf + (i64)g.rank * cnt, buf, (size_t)cnt, ncclFloat64, g.comm, ctx().stream), "ncclAllGather");
 }
 
 // The same all-reduce, but on the library's second stream: it starts once everything enqueued so far on the compute stream
