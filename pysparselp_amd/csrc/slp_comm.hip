@@ -255,6 +255,8 @@ void comm_allreduce_dev_async(double *buf, i64 count, int op) {
         hipEvent_t ev = g.ready[g.next_ready++ % 8];
         SLP_HIP(hipEventRecord(ev, ctx().stream));
         if (!hw.running) {
+            static const bool at_exit = (atexit([] { host_worker_stop(); }), true);  // a joinable std::thread must not reach its destructor
+            (void)at_exit;
             hw.th = std::thread(host_worker_main, ctx().device);
             hw.running = true;
         }
