@@ -596,19 +596,24 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #endif
             cur ^= 1;
         }
+        auto stage_tile = [&]() {
 #if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 5 || SLP_TALL_ABL == 7)   // lab: no x-tile LDS write
-        if (false) {
+            if (false) {
 #else
-        if ((xw & 0x7fffffffu) != kNoTile) {
+            if ((xw & 0x7fffffffu) != kNoTile) {
 #endif
-            // (Bringing the tile in by LDS-DMA -- __builtin_amdgcn_global_load_lds, no registers, no ds_write -- was built and
-            // measured: 4.71 ms against 3.99.  With two tile buffers the DMA can only start at the cell's barrier and must have
-            // landed by the next one, 1.6 us later; the register path issues the loads four cells ahead.  A third buffer does
-            // not fit beside 78 KB of running sums.)
-            double *dst = &xt[cur ^ 1][2 * p];
-            *reinterpret_cast<double2 *>(dst) = make_double2(g.x[0], g.x[1]);
-            *reinterpret_cast<double2 *>(dst + kTallC / 2) = make_double2(g.x[2], g.x[3]);
-        }
+                // (Bringing the tile in by LDS-DMA -- __builtin_amdgcn_global_load_lds, no registers, no ds_write -- was built and
+                // measured: 4.71 ms against 3.99.  With two tile buffers the DMA can only start at the cell's barrier and must
+                // have landed by the next one, 1.6 us later; the register path issues the loads four cells ahead.  A third buffer
+                // does not fit beside 78 KB of running sums.)
+                double *dst = &xt[cur ^ 1][2 * p];
+                *reinterpret_cast<double2 *>(dst) = make_double2(g.x[0], g.x[1]);
+                *reinterpret_cast<double2 *>(dst + kTallC / 2) = make_double2(g.x[2], g.x[3]);
+            }
+        };
+#ifdef SLP_TALL_WRITE_FIRST   // lab: the order of rounds 3-4a -- every wave stores its share of the tile right behind the barrier
+        stage_tile();
+#endif
         const double *__restrict__ tile = xt[cur];
         // Four slots at a time: all twelve LDS reads (running sums, values, x) are issued together, the products do not
         // depend on the sums, and a sum that the lane has just updated is carried in a register (a lane's items of one
@@ -659,6 +664,12 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
             group(0);
             if (wbase < c[4]) group(4);
         }
+        // The x-tile of the NEXT cell goes into the other buffer AFTER this packet's items (it only has to be there by the next
+        // cell's barrier): right behind the barrier all 16 waves would store at once and every wave's gathers would queue behind
+        // 32 KB of stores; behind the items the waves' stores spread over the cell.
+#ifndef SLP_TALL_WRITE_FIRST
+        stage_tile();
+#endif
     };
 
     // prologue: headers of the first 2 x depth packets, payload of the first depth
