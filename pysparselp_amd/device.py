@@ -172,6 +172,27 @@ class ChunkedDeviceMatrix(DeviceMatrix):
         self.shape = (self.shape[0] + chunk.shape[0], self.shape[1])
         return self
 
+    @classmethod
+    def from_csr(cls, a, chunk_entries=2_500_000_000):
+        """A host scipy CSR matrix uploaded in row chunks of about ``chunk_entries`` stored entries (even inner cuts): the way a
+        host LP whose CSR does not fit the device twice over gets resident.  Every chunk must qualify for strip copies."""
+        indptr = np.asarray(a.indptr, dtype=np.int64)
+        m = a.shape[0]
+        cuts, r0 = [0], 0
+        while r0 < m:
+            r1 = int(np.searchsorted(indptr, indptr[r0] + chunk_entries, side="right")) - 1
+            r1 = min(m, max(r1, r0 + 2))
+            if r1 < m:
+                r1 &= ~1
+                if m - r1 < 2:
+                    r1 = m
+            cuts.append(r1)
+            r0 = r1
+        g = cls(a.shape[1], expect_chunks=len(cuts) - 1)
+        for r0, r1 in zip(cuts, cuts[1:]):
+            g.append(DeviceMatrix.from_csr(a[r0:r1]))
+        return g
+
     @property
     def chunks(self):
         return int(self._l.slp_matrix_chunks(self._h))

@@ -191,6 +191,27 @@ def test_build_passes_and_strip_range_split_do_not_change_the_copy():
         assert float(np.max(np.abs(g - r) / (1 + np.abs(r)))) <= 1e-13
 
 
+def test_a_host_matrix_uploaded_in_chunks():
+    """``ChunkedDeviceMatrix.from_csr``: a scipy CSR handed over in row chunks of a given entry count."""
+    import scipy.sparse
+
+    from pysparselp_amd.device import ChunkedDeviceMatrix
+
+    rng = np.random.RandomState(12)
+    m, n, k = 30_001, 200_000, 1_500_000
+    a = scipy.sparse.coo_matrix((np.round(rng.randn(k), 1) + 0.05, (rng.randint(0, m, size=k), rng.randint(0, n, size=k))), shape=(m, n)).tocsr()
+    a.sum_duplicates()
+    a.sort_indices()
+    g = ChunkedDeviceMatrix.from_csr(a, chunk_entries=400_000)
+    try:
+        assert g.chunks == 4 and g.shape == a.shape and g.nnz == a.nnz
+        x, y = rng.randn(n), rng.randn(m)
+        assert np.array_equal(g.matvec(x), oracle.matvec(oracle.as_csr(a), x))
+        assert np.array_equal(g.rmatvec(y), oracle.rmatvec(oracle.as_csr(a), y))
+    finally:
+        g.close()
+
+
 def test_chunked_api_errors():
     from pysparselp_amd._lib import SlpError
     from pysparselp_amd.device import ChunkedDeviceMatrix, DeviceMatrix
