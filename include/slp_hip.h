@@ -70,6 +70,12 @@ int64_t slp_matrix_nnz(const slp_matrix *a);
 int slp_matrix_spmv(slp_matrix *a, const double *x, double *y, int order);
 /* out[ncol] = A^T y[nrow] */
 int slp_matrix_spmv_t(slp_matrix *a, const double *y, double *out, int order);
+/* y = |A|^p x (transposed = 0) or |A|^p^T x (transposed = 1), entry-wise power: the products whose results with a vector
+ * of ones are the sums behind Chambolle-Pock's diagonal preconditioners (ChambollePockPPD.py:122-179: np.abs(A) ** p,
+ * column sums in row order, row sums in storage order).  Runs on the strip / tall-cell copy of that orientation with its
+ * value table raised to the power (what slp_cp_create_on does at set-up); an error when the copy cannot (no copy, or fp64
+ * wide strips).  A checker's entry point: lets the set-up sums of a matrix without CSR be verified slice by slice. */
+int slp_matrix_spmv_abs_pow(slp_matrix *a, int transposed, double p, const double *x, double *y);
 /* Copies of the device arrays: CSR (transposed = 0) or the device-built
  * transposed CSR, i.e. CSC of A (transposed = 1).  Any pointer may be NULL. */
 int slp_matrix_download(slp_matrix *a, int transposed, int64_t *indptr,

@@ -110,9 +110,24 @@ class Csr:
         )
 
 
+class ProductsOnly:
+    """A matrix this oracle knows only through its products -- for sizes whose CSR no host holds (BASELINE config 4: 240 GB
+    per orientation).  The caller supplies ``A x``, ``y A`` and the same for ``|A| ** p`` (device copies, AFTER the caller has
+    checked exactly those products against ``matvec`` / ``rmatvec`` below on row slices); the iteration that consumes them
+    stays this file's restatement of the reference.  Only ``chambolle_pock_ppd`` on one-sided rows takes it."""
+
+    def __init__(self, shape, matvec, rmatvec, abs_pow_matvec=None, abs_pow_rmatvec=None):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self._matvec, self._rmatvec = matvec, rmatvec
+        self._abs_pow_matvec, self._abs_pow_rmatvec = abs_pow_matvec, abs_pow_rmatvec
+
+    def powered(self, p):
+        return ProductsOnly(self.shape, lambda x: self._abs_pow_matvec(x, p), lambda y: self._abs_pow_rmatvec(y, p))
+
+
 def as_csr(a):
     """Accept a Csr, a scipy CSR matrix or None; entry order is preserved."""
-    if a is None or isinstance(a, Csr):
+    if a is None or isinstance(a, (Csr, ProductsOnly)):
         return a
     return Csr(a.indptr, a.indices, a.data, a.shape)
 
@@ -124,6 +139,8 @@ def matvec(a, x):
     """``a * x`` (csr_matvec)."""
     x = _f64(x)
     assert x.size == a.shape[1]
+    if isinstance(a, ProductsOnly):
+        return a._matvec(x)
     y = np.empty(a.shape[0])
     _lib().orc_csr_matvec(a.shape[0], _p(a.indptr), _p(a.indices), _p(a.data), _p(x), _p(y))
     return y
@@ -133,6 +150,8 @@ def rmatvec(a, y):
     """``y * a`` for a CSR ``a`` (csc_matvec over the transposed view)."""
     y = _f64(y)
     assert y.size == a.shape[0]
+    if isinstance(a, ProductsOnly):
+        return a._rmatvec(y)
     out = np.empty(a.shape[1])
     if get_threads() > 1 and a.nnz > 1_000_000:
         # columns are independent: the same chain of additions per column from the (stable) CSC arrays
@@ -314,6 +333,8 @@ def one_sided(a_ineq, b_lower, b_upper):
 def cp_setup(a_eq, a_ineq, alpha=1):
     """Diagonal preconditioners T, Sigma_eq, Sigma_ineq (ChambollePockPPD.py:122-179)."""
     def powered(a, p):
+        if isinstance(a, ProductsOnly):
+            return a.powered(p)
         cp = Csr(a.indptr, a.indices, np.abs(a.data) ** p, a.shape)
         if get_threads() > 1 and a.nnz > 1_000_000:  # the CSC arrays of |A|^p are those of A with the same map applied
             if a._csc is None:
@@ -331,7 +352,8 @@ def cp_setup(a_eq, a_ineq, alpha=1):
     def sigma(a):
         if a is None:
             return None
-        s = matvec(Csr(a.indptr, a.indices, np.abs(a.data) ** alpha, a.shape), np.ones(a.shape[1]))  # :161,172
+        s = matvec(a.powered(alpha) if isinstance(a, ProductsOnly) else Csr(a.indptr, a.indices, np.abs(a.data) ** alpha, a.shape),
+                   np.ones(a.shape[1]))  # :161,172
         s[s == 0] = 1
         return 1 / s
 

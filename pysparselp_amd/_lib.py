@@ -42,6 +42,7 @@ _SIGNATURES = {
     "slp_matrix_nnz": (c_i64, [c_vp]),
     "slp_matrix_spmv": (c_int, [c_vp, c_vp, c_vp, c_int]),
     "slp_matrix_spmv_t": (c_int, [c_vp, c_vp, c_vp, c_int]),
+    "slp_matrix_spmv_abs_pow": (c_int, [c_vp, c_int, c_dbl, c_vp, c_vp]),
     "slp_matrix_download": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
     "slp_matrix_download_rows": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "slp_matrix_bench_spmv": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),

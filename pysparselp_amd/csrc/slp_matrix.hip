@@ -641,6 +641,21 @@ int slp_matrix_spmv_t(slp_matrix *m, const double *y, double *out, int order) {
     })
 }
 
+int slp_matrix_spmv_abs_pow(slp_matrix *m, int transposed, double p, const double *x, double *y) {
+    SLP_API_INT({
+        SLP_REQUIRE(m && x && y, "slp_matrix_spmv_abs_pow: NULL argument");
+        const StripJds *f = fast_format(m, transposed != 0);
+        SLP_REQUIRE(f && strip_abs_pow_supported(*f), "slp_matrix_spmv_abs_pow: needs a strip / tall-cell copy of this orientation that can "
+                                                     "raise its entries to a power (slp_matrix_spmv_kernel 1-4, 6, 7)");
+        const size_t nin = (size_t)(transposed ? m->a.nrow : m->a.ncol), nout = (size_t)(transposed ? m->a.ncol : m->a.nrow);
+        DevBuf<double> vx(nin), vo(nout);
+        vx.upload(x, nin);
+        strip_spmv_abs_pow(*f, p, vx.p, vo.p);
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+        vo.download(y, nout);
+    })
+}
+
 int slp_matrix_download(slp_matrix *m, int transposed, int64_t *indptr, int32_t *indices, double *data) {
     SLP_API_INT({
         SLP_REQUIRE(m, "slp_matrix_download: NULL matrix");

@@ -63,6 +63,15 @@ class DeviceMatrix:
         _lib.check(self._l.slp_matrix_spmv_t(self._h, _lib.ptr(y), _lib.ptr(out), int(order)))
         return out
 
+    def abs_pow_matvec(self, x, p, transposed=False):
+        """``(|A| ** p) x`` or, ``transposed``, ``(|A| ** p)^T x`` on the strip / tall-cell copy of that orientation (the sums
+        behind Chambolle-Pock's preconditioners, ChambollePockPPD.py:122-179)."""
+        x = _lib.f64(x)
+        assert x.size == self.shape[0 if transposed else 1]
+        out = np.empty(self.shape[1 if transposed else 0])
+        _lib.check(self._l.slp_matrix_spmv_abs_pow(self._h, int(bool(transposed)), float(p), _lib.ptr(x), _lib.ptr(out)))
+        return out
+
     def download(self, transposed=False):
         """scipy CSR copy of the device arrays (``transposed=True``: the device-built A^T)."""
         nrow, ncol = (self.shape[1], self.shape[0]) if transposed else self.shape

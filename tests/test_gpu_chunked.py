@@ -250,3 +250,37 @@ def test_randomised_chunkings_match_the_oracle_bit_for_bit():
     seen, skipped, solved = mod.run(24, seed=21)
     os.environ["SLP_STRIP_MIN_NNZ"] = "1"   # (the fixture removes it again)
     assert sum(seen.values()) >= 2 * 12 and solved >= 3, (seen, skipped, solved)
+
+
+def _device_products(a):
+    """The chunked / unchunked device matrix as the oracle's products-only operand (oracle.ProductsOnly)."""
+    return oracle.ProductsOnly(a.shape, a.matvec, a.rmatvec, lambda x, p: a.abs_pow_matvec(x, p), lambda y, p: a.abs_pow_matvec(y, p, transposed=True))
+
+
+@pytest.mark.parametrize("shape_name, chunks", [("tall", 1), ("tall", 3), ("strips", 1), ("strips", 4)])
+def test_abs_power_products_and_the_oracle_iterating_over_device_products(tall_reference, shape_name, chunks):
+    """``slp_matrix_spmv_abs_pow`` (the sums behind Chambolle-Pock's preconditioners, ChambollePockPPD.py:122-179) against the
+    oracle's products with ``|A| ** p``, bit for bit; and the construction tests/test_gpu_c4_full.py uses at a size whose CSR
+    no host holds: the ORACLE's Chambolle-Pock iteration fed with the device's products gives, bit for bit, what the oracle
+    gives on the host CSR -- and what the device solver gives."""
+    from pysparselp_amd.scale import DeviceCP
+
+    shape = TALL if shape_name == "tall" else STRIPS
+    a, xf, c, lb, ub, b = _lp(shape, chunks)
+    host = tall_reference["host"] if shape_name == "tall" else _lp(shape, 1)[0].download()
+    oa = oracle.as_csr(host)
+    rng = np.random.RandomState(3)
+    x, y = rng.randn(shape["n"]), rng.randn(shape["m"])
+    for p in (1.0, 2.0, 0.5):
+        powered = oracle.Csr(oa.indptr, oa.indices, np.abs(oa.data) ** p, oa.shape)
+        assert np.array_equal(a.abs_pow_matvec(x, p), oracle.matvec(powered, x)), p
+        assert np.array_equal(a.abs_pow_matvec(y, p, transposed=True), oracle.rmatvec(powered, y)), p
+    iters = 5
+    want, _ = oracle.chambolle_pock_ppd(c, None, None, oa, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9)
+    through, _ = oracle.chambolle_pock_ppd(c, None, None, _device_products(a), None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9)
+    assert np.array_equal(through, want)
+    s = DeviceCP(a, b, c, lb, ub)
+    s.iterate(iters)
+    assert np.array_equal(s.x(), want)
+    s.close()
+    a.close()
