@@ -91,12 +91,19 @@ static void host_worker_main(int device) {
         }
         std::string err;
         if (stage.size() < (size_t)job.count) stage.resize((size_t)job.count);
-        hipError_t e = hipEventSynchronize(job.ready);
-        if (e == hipSuccess) e = hipMemcpyAsync(stage.data(), job.buf, (size_t)job.count * sizeof(double), hipMemcpyDeviceToHost, g.side);
-        if (e == hipSuccess) e = hipStreamSynchronize(g.side);
+        // (capture_mutex: none of these calls while the main thread has a stream capture open, slp_common.h; `ready` was recorded
+        // before the job was queued, so waiting for it under the lock cannot wait for the main thread)
+        hipError_t e;
+        {
+            std::lock_guard<std::mutex> no_capture(capture_mutex());
+            e = hipEventSynchronize(job.ready);
+            if (e == hipSuccess) e = hipMemcpyAsync(stage.data(), job.buf, (size_t)job.count * sizeof(double), hipMemcpyDeviceToHost, g.side);
+            if (e == hipSuccess) e = hipStreamSynchronize(g.side);
+        }
         if (e != hipSuccess) err = std::string("host all-reduce worker: ") + hipGetErrorString(e);
         else if (g.host_fn(stage.data(), job.count, job.op, g.host_user) != 0) err = "host all-reduce callback failed";
         else {
+            std::lock_guard<std::mutex> no_capture(capture_mutex());
             e = hipMemcpyAsync(job.buf, stage.data(), (size_t)job.count * sizeof(double), hipMemcpyHostToDevice, g.side);
             if (e == hipSuccess) e = hipStreamSynchronize(g.side);
             if (e != hipSuccess) err = std::string("host all-reduce worker: ") + hipGetErrorString(e);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -129,6 +130,15 @@ struct DevBuf {
     }
 };
 
+// Held while a stream capture is open, and by the library's helper threads (the host transport's asynchronous worker,
+// slp_comm.hip) around their HIP calls: a copy or a synchronisation issued by ANOTHER thread while this one captures
+// invalidates the capture on ROCm 7.2 even in hipStreamCaptureModeThreadLocal ("operation failed due to a previous error
+// during capture" at the next launch: seen once in ~10 runs of tests/test_gpu_two_ranks.py's block-group test).
+inline std::mutex &capture_mutex() {
+    static std::mutex m;
+    return m;
+}
+
 // Launch-bound inner loops (cache-resident LPs: Potts, netlib) are captured once into a hipGraph of
 // `unroll` iterations and replayed: a kernel boundary inside a graph costs ~1.5 us instead of a host launch.
 struct IterGraph {
@@ -150,6 +160,7 @@ struct IterGraph {
         if (want_unroll > k) want_unroll = (int)k;
         const char *off = getenv("SLP_NO_GRAPH");  // eager launches, e.g. under a profiler
         if (!exec && k >= 2 && want_unroll >= 1 && !(off && off[0] == '1')) {
+            std::lock_guard<std::mutex> no_helper_calls(capture_mutex());
             SLP_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             try {
                 for (int u = 0; u < want_unroll; ++u) body();
