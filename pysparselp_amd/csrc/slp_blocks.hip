@@ -161,6 +161,7 @@ bool comm_active();
 void comm_allreduce_dev(double *buf, i64 count, int op);
 void comm_allreduce_dev_async(double *buf, i64 count, int op);
 void comm_join();
+bool comm_library_collective_pending();
 void comm_sync_side();
 
 // v = xp - lambda / gamma  (original part)
@@ -380,7 +381,9 @@ static void blk_cg(slp_blocks *s, Apply apply, i64 len = -1, double *sol = nullp
             }
         };
         const int chunk = std::min(s->check_every, s->max_cg - it);
-        if (s->a->a.nnz <= 20000000) s->cg_graph.run(chunk, s->check_every, step);  // all kernel arguments are fixed pointers
+        // all kernel arguments are fixed pointers.  Not while an asynchronous RCCL all-reduce of the previous block is in flight: what
+        // the library's own threads call meanwhile is not ours to order against an open capture (see capture_mutex, slp_common.h)
+        if (s->a->a.nnz <= 20000000 && !comm_library_collective_pending()) s->cg_graph.run(chunk, s->check_every, step);
         else for (int k = 0; k < chunk; ++k) step();
         it += chunk;
         s->cg_steps += chunk;

@@ -293,6 +293,9 @@ void comm_sync_side() {
     g.pending = false;
 }
 
+// an asynchronous all-reduce of the COLLECTIVE LIBRARY (not the host transport's worker, which takes capture_mutex) may be running
+bool comm_library_collective_pending() { return g.active && g.pending && !g.host_fn; }
+
 void comm_join() {
     if (!g.pending) return;
     if (g.host_fn) {  // the worker has synchronised the second stream behind every copy: nothing left for the compute stream to wait for
