@@ -520,6 +520,10 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
                iterate_hook=None):
     n = np.asarray(c).size
     c = _f64(c)
+    if isinstance(a_ineq, ProductsOnly):
+        assert a_eq is None and b_lower is None and use_preconditioning and not explicit_m
+        return _lp_admm_cg_over_products(c, a_ineq, b_upper, lb, ub, x0, gamma_eq, gamma_ineq, nb_iter, callback_func, max_time,
+                                         nb_iter_plot, iterate_hook)
     a_eq, a_ineq = as_csr(a_eq), as_csr(a_ineq)
     if x0 is None:
         x0 = np.zeros(c.size)
@@ -530,31 +534,73 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
     c, a, b, lb, ub, x = convert_to_standard_form_with_bounds(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0)
     if use_preconditioning:
         a, b = precondition_constraints(a, b)
-    atb = rmatvec(a, b)
-    if explicit_m:
-        m = normal_matrix(a, gamma_eq, gamma_ineq)
+    m = normal_matrix(a, gamma_eq, gamma_ineq) if explicit_m else None
+    return _admm_cg_iterations(n, c, lambda v: matvec(a, v), lambda y: rmatvec(a, y), a.shape[0], b, lb, ub, x, gamma_eq, gamma_ineq,
+                               nb_iter, callback_func, max_time, nb_iter_plot, iterate_hook,
+                               (lambda v: matvec(m, v)) if explicit_m else None)
 
-        def m_apply(v):
-            return matvec(m, v)
+
+def _lp_admm_cg_over_products(c, ops, b_upper, lb, ub, x0, gamma_eq, gamma_ineq, nb_iter, callback_func, max_time, nb_iter_plot,
+                              iterate_hook):
+    """``lp_admm_cg`` for an all-inequality LP ``A x <= b_upper`` known through its products only (``ProductsOnly``: a size whose
+    CSR no host holds).  The same set-up and the same iteration, with the two row scalings of ADMM.py:82,91 (tools.py:272-290)
+    and the slack columns of tools.py:88-127 carried BESIDE the products instead of inside stored entries:
+        a v   = s2 * (s1 * (A v[:n]) - v[n:])          a^T y = [A^T (s1 * s2 * y) ; -(s2 * y)]
+    with s1 = 1 / |row of A|, s2 = 1 / |row of [s1 A, -I]|.  Equal to the stored-entry form in exact arithmetic; in fp64 the
+    roundings differ (s * (sum of a x) for sum of (s a) x; the norms from one sum of squares), as the device's deferred row
+    scaling does.  Pinned against the stored-entry form on host CSRs by tests/test_oracle_golden.py (1e-12)."""
+    m, n = ops.shape
+    ones = np.ones(n)
+    rowsq = ops._abs_pow_matvec(ones, 2.0)  # sum_j a_ij^2, storage order (orc_row_scale_l2)
+    norm1 = np.sqrt(rowsq)
+    norm1[norm1 == 0] = 1
+    s1 = 1 / norm1
+    bu1 = s1 * _f64(b_upper)
+    norm2 = np.sqrt((s1 * s1) * rowsq + 1.0)   # rows of [s1 A, -I]
+    s2 = 1 / norm2
+    s12 = s1 * s2
+    x0 = np.zeros(n) if x0 is None else _f64(x0)
+    x = np.hstack((x0, s1 * ops._matvec(x0)))            # tools.py:125  [x0 ; Ai x0]
+    c2 = np.hstack((c, np.zeros(m)))
+    lb2 = np.hstack((_f64(lb), np.full(m, -np.inf)))
+    ub2 = np.hstack((_f64(ub), bu1))
+    b = s2 * np.zeros(m)
+
+    def a_mv(v):
+        return s2 * (s1 * ops._matvec(np.ascontiguousarray(v[:n])) - v[n:])
+
+    def a_rmv(y):
+        return np.hstack((ops._rmatvec(s12 * y), -(s2 * y)))
+
+    return _admm_cg_iterations(n, c2, a_mv, a_rmv, m, b, lb2, ub2, x, gamma_eq, gamma_ineq, nb_iter, callback_func, max_time,
+                               nb_iter_plot, iterate_hook, None)
+
+
+def _admm_cg_iterations(n, c, a_mv, a_rmv, nrows, b, lb, ub, x, gamma_eq, gamma_ineq, nb_iter, callback_func, max_time, nb_iter_plot,
+                        iterate_hook, m_explicit):
+    """The iteration of ``lp_admm_cg`` (ADMM.py:143-268 with the use_cg flags) over the standard-form operator ``a``."""
+    atb = a_rmv(b)
+    if m_explicit is not None:
+        m_apply = m_explicit
     else:
         def m_apply(v):
-            return gamma_eq * rmatvec(a, matvec(a, v)) + gamma_ineq * v
+            return gamma_eq * a_rmv(a_mv(v)) + gamma_ineq * v
 
     xp = np.maximum(x, 0)  # :98
-    lambda_eq = np.zeros(a.shape[0])
+    lambda_eq = np.zeros(nrows)
     lambda_ineq = np.zeros(x.shape)
     speed = np.zeros(x.shape)  # :136
     alpha = 1.4  # :140
 
     def energy(x, xp, lambda_eq, lambda_ineq):  # :124-132
-        r = matvec(a, x) - b
+        r = a_mv(x) - b
         return (c.dot(x) + 0.5 * gamma_eq * np.sum(r ** 2) + 0.5 * gamma_ineq * np.sum((x - xp) ** 2)
-                + lambda_eq.dot(matvec(a, x) - b) + lambda_ineq.dot(x - xp))
+                + lambda_eq.dot(a_mv(x) - b) + lambda_ineq.dot(x - xp))
 
     start = time.perf_counter()
     i = 0
     while i <= nb_iter:  # :143
-        y = -c + gamma_eq * atb + gamma_ineq * xp - rmatvec(a, lambda_eq) - lambda_ineq  # :148
+        y = -c + gamma_eq * atb + gamma_ineq * xp - a_rmv(lambda_eq) - lambda_ineq  # :148
         xprev = x.copy()  # :184
         direction = speed  # :190-194: exact line search along the previous displacement
         t = -direction.dot(m_apply(x) - y)
@@ -577,7 +623,7 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
             if max_time is not None and elapsed > max_time:
                 break
             energy1 = energy(x, xp, lambda_eq, lambda_ineq)
-            r = matvec(a, x) - b
+            r = a_mv(x) - b
             max_violated_equality = np.max(np.abs(r))
             max_violated_inequality = max(0, -np.min(x))
             if callback_func is not None:
@@ -586,7 +632,7 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
         xp = np.maximum(xp, lb)
         xp = np.minimum(xp, ub)
         lambda_ineq = lambda_ineq + gamma_ineq * (x - xp)
-        lambda_eq = lambda_eq + gamma_eq * (matvec(a, x) - b)  # :261-263
+        lambda_eq = lambda_eq + gamma_eq * (a_mv(x) - b)  # :261-263
         i += 1
     return x[0:n]
 

@@ -283,4 +283,15 @@ def test_abs_power_products_and_the_oracle_iterating_over_device_products(tall_r
     s.iterate(iters)
     assert np.array_equal(s.x(), want)
     s.close()
+    # matrix-free ADMM: the oracle on the CSR, the oracle over the device's products (scalings beside the products) and the device
+    from pysparselp_amd.admm_cg import DeviceADMM
+
+    want = oracle.lp_admm_cg(c, None, None, oa, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
+    through = oracle.lp_admm_cg(c, None, None, _device_products(a), None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9)
+    s = DeviceADMM(a, b, c, lb, ub)
+    s.iterate(iters)
+    got = s.x(shape["n"])
+    s.close()
+    for u, v in ((through, want), (got, want), (got, through)):
+        assert np.max(np.abs(u - v) / (1 + np.abs(v))) <= 1e-9
     a.close()
