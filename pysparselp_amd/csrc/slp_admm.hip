@@ -645,7 +645,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
     { const char *es = getenv("SLP_GS_BANDS_SAFE"); g.bands_safe = es && es[0] == '1'; }
     const auto plan_t0 = std::chrono::steady_clock::now();
     auto plan_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - plan_t0).count(); };
-    double ms_levels = 0, ms_bands = 0;
+    double ms_levels = 0, ms_bands = 0, ms_permute = 0, ms_pack = 0;
     // dependency levels over the symmetrised pattern, lower part only
     std::vector<i32> level((size_t)n, 0);
     // need(j): the largest level among rows i < j that READ x[j] (anti-dependence: j must wait for i)
@@ -923,6 +923,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         g.idx.upload(j2.data(), j2.size());
         g.val.upload(v2.data(), v2.size());
     }
+    ms_permute = plan_ms() - ms_levels - ms_bands;
     g.rows.upload(rows.data(), (size_t)n);
     g.lptr_dev.upload(g.lptr.data(), g.lptr.size());
     g.invd.alloc((size_t)n);
@@ -1206,6 +1207,7 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
                 segs.push_back(sg);
             }
         }
+        ms_pack = plan_ms() - ms_levels - ms_bands - ms_permute;
         if (!slots.empty() && slots.size() < ((size_t)1 << 31)) {
             g.pipelined = true;
             g.one_block = false;
@@ -1244,8 +1246,8 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         }
     }
     if (getenv("SLP_GS_VERBOSE"))
-        fprintf(stderr, "gauss-seidel plan: n %lld, %lld entries, %lld levels: levels %.1f ms, bands %.1f ms, all %.1f ms (host)\n", (long long)n,
-                (long long)g.nnz, (long long)g.nlevels, ms_levels, ms_bands, plan_ms());
+        fprintf(stderr, "gauss-seidel plan: n %lld, %lld entries, %lld levels: levels %.1f ms, bands %.1f ms, permute + upload %.1f ms, lane records %.1f ms, all %.1f ms (host)\n",
+                (long long)n, (long long)g.nnz, (long long)g.nlevels, ms_levels, ms_bands, ms_permute, ms_pack, plan_ms());
 }
 
 // bounded = false: plain SOR sweep (no bounds); the kernels then read the diagonal through the `lo` argument
