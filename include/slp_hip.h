@@ -97,7 +97,7 @@ slp_matrix *slp_matrix_gather_rows(slp_matrix *a, int64_t count, const int64_t *
  * 3 = k_qstrip_spmv (4096-row blocks, 3-byte entries), 2 = k_dstrip_spmv (2048-row blocks, 4-byte entries;
  * SLP_DICT_VARIANT=1), 4 / 5 = wide strips (k_wstrip_spmv: strips of 131072 columns, x gathered from L2; rows too sparse
  * for the LDS tile over a width far beyond an L2) with value-dictionary / fp64 entries -- since round 3 only the fallback of
- * 6 / 7 = tall cells (k_tall_spmv<true / false>, csrc/slp_tall.hip: row blocks of ~1e4 rows x strips of 4096 columns, running
+ * 6 / 7 = tall cells (k_tall_spmv<true / false>, csrc/slp_tall_spmv.hip; format: csrc/slp_tall.hip: row blocks of ~1e4 rows x strips of 4096 columns, running
  * sums and x-tile in LDS, 5-byte value-dictionary items / 4-byte items + fp64 values; 0.05 - 2.5 entries per (row, 4096
  * columns): the per-rank slice of a 1e7-variable LP and its transpose),
  * 0 = row-per-lane-group CSR kernel (k_spmv), -1 = error. */

@@ -49,7 +49,7 @@ static std::thread g_reserve_thread;
 static double g_background_seconds = 0.0;
 
 static size_t size_class(size_t bytes) {
-    // (+ 16: a kernel may fetch the 16-byte piece that holds a vector's last element -- slp_tall.hip's x-tile pieces)
+    // (+ 16: a kernel may fetch the 16-byte piece that holds a vector's last element -- slp_tall_spmv.hip's x-tile pieces)
     size_t want = (bytes + 16 + 255) & ~(size_t)255;
     if (want > ((size_t)64 << 20)) {
         // large blocks in size classes of 1/32 .. 1/64 of their size: the CSR arrays, sort buffers and packet streams of

@@ -24,7 +24,7 @@
 // row sum, bit for bit, for ANY number of row blocks -- R is chosen so that the row blocks are a multiple of the CU
 // count (no strips split over workgroups, no partial sums re-associated).
 //
-// The kernel is a software pipeline over packets (typically one per cell): the payload of packet j + 4 and the header
+// The kernel (slp_tall_spmv.hip) is a software pipeline over packets (typically one per cell): the payload of packet j + 4 and the header
 // of packet j + 8 are being loaded while packet j is consumed; every global load is unconditional (lanes without work
 // address past the end of the buffer descriptor: no memory request), so the compiler counts what is in flight
 // (s_waitcnt vmcnt(N), never 0), and the x-tile of the NEXT cell rides on the first packet of the current one.
@@ -38,39 +38,10 @@
 
 #include "slp_common.h"
 #include "slp_kernels.h"
+#include "slp_tall.h"
 
 namespace slp {
 
-constexpr int kTallC = 4096;       // columns per strip (12-bit column inside the strip); 32 KB of x
-constexpr int kTallT = 1024;       // threads per workgroup = lanes a cell's rows are dealt to
-constexpr int kTallSlots = 8;      // list positions per packet
-constexpr int kTallDepth = 4;      // packets of payload in flight per lane; headers run 2 x this ahead
-constexpr int kTallDictMax = 2048;
-constexpr int kTallBuckets = 6;    // rows are ordered by min(entries in the cell, 6), descending
-constexpr int kTallIdBits = 11, kTallColBits = 12, kTallRowBits = 14;
-constexpr int kTallCellShift = kTallIdBits + kTallColBits + kTallRowBits;  // sort key: cell | row | column | id
-static_assert(kTallBuckets * 32 == 3 * kWave, "k_tall_build scans the (count, bank class) buckets three per lane of one wave");
-static_assert(kTallRmax < (1 << kTallRowBits) && kTallC == (1 << kTallColBits) && kTallDictMax == (1 << kTallIdBits), "tall geometry");
-// LDS of the product kernel: sums + value table + two x-tiles
-static_assert(kTallRmax * 8 + kTallDictMax * 8 + 2 * kTallC * 8 <= 160 * 1024, "tall cells: LDS budget");
-
-constexpr unsigned int kPktNewCell = 0x80000000u;  // first packet of a cell: barrier, then the other x-tile
-constexpr unsigned int kNoTile = 0x7fffffffu;
-constexpr unsigned int kOob = 0xffffff00u;         // byte offset past every buffer descriptor: the load returns 0, no request
-
-// 32-byte packet header (8 dwords; lane l & 7 of a wave loads dword l & 7)
-struct TallPkt {
-    unsigned int off;     // payload offset of the packet inside its row block (words)
-    unsigned int xsrc;    // kPktNewCell | first column of the strip whose x-tile this packet carries for the NEXT cell (or kNoTile)
-    unsigned int c[4];    // c[i] = w[2i] | w[2i+1] << 16,  w[k] = lanes whose list is longer than slot k of this packet
-    unsigned int strip;   // strip index (diagnostics)
-    unsigned int pad;
-};
-static_assert(sizeof(TallPkt) == 32, "packet header");
-
-__host__ __device__ inline unsigned long long tall_value_key(unsigned long long bits) {  // as value_key() of slp_strip.hip
-    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
-}
 
 // ---- build, step 1: one 64-bit key per stored entry of the pass, in CSR order ------------------------------------------
 // The copy is built in PASSES over ranges of its row blocks, so that the temporaries (keys, sorted keys, sort scratch) are a
@@ -486,213 +457,6 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
     for (int i = 0; i < 2 * kTallDepth; ++i) empty_packet(kNoTile);
     if (!WRITE && p == 0) { sizes[2 * v] = woff; sizes[2 * v + 1] = npk; }
 }
-
-// ---- the product -------------------------------------------------------------------------------------------------------
-template <bool DICT>
-struct TallRegs {
-    unsigned int lo[kTallSlots];
-    unsigned int hi[DICT ? 2 : 1];
-    double val[DICT ? 1 : kTallSlots];
-    double x[4];
-};
-
-// DICT: depth 4 (20 KB of payload per packet); fp64 entries: depth 2 (48 KB per packet, 16 more registers per packet)
-// POW (fp64 entries only): every stored value v enters as |v|^pw * 1.0 -- the sums behind the Chambolle-Pock preconditioners
-// (slp_cp.hip, strip_spmv_abs_pow) over a copy without a value table; the same chain of additions as the CSR walk.
-template <bool DICT, bool ACC, bool POW = false>
-__global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, int S, const TallWg *__restrict__ wgs,
-                                                      const double *__restrict__ dict, int D, const double *__restrict__ x,
-                                                      double *__restrict__ out, double pw) {
-    constexpr int kDepth = DICT ? kTallDepth : 2;
-    __shared__ double acc[kTallRmax];
-    __shared__ double dv[kTallDictMax];
-    __shared__ double xt[2][kTallC];
-    const int p = threadIdx.x;
-    const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
-    const i64 v = blockIdx.x, b = v / S;  // workgroup v walks the strips of range v % S of row block b
-    // ACC (S == 1): the sums continue from what `out` holds -- a row chunk of a chunked matrix carrying on the column sums of
-    // the chunks before it, the chain of additions of the unchunked product (S > 1: taken in k_tall_combine).  A template
-    // parameter: loads under a run-time condition in front of the pipeline made the compiler wait for vmcnt(0) in the loop.
-    for (int r = p; r < R; r += kTallT) acc[r] = (ACC && S == 1 && b * (i64)R + r < nrow) ? out[b * (i64)R + r] : 0.0;
-    if (DICT)
-        for (int q = p; q < D; q += kTallT) dv[q] = dict[q];
-    const TallWg wg = wgs[v];
-    // this lane's dword of every header -- through a GLOBAL-address-space pointer: a pointer read from a structure in memory is
-    // a generic one to the compiler, its loads become flat_load (complete out of order: every wait a vmcnt(0), the pipeline gone)
-#ifdef SLP_TALL_FLAT  // lab: the generic-pointer form (drains the pipeline at every packet group), for re-measurement
-    const unsigned int *hd = wg.dir + (p & 7);
-#else
-    typedef const unsigned int __attribute__((address_space(1))) *gptr_t;
-    const gptr_t hd = (gptr_t)(unsigned long long)wg.dir + (p & 7);
-#endif
-    const int npk = (int)wg.npk - 2 * kTallDepth;                             // the last 2 x depth packets are prefetch targets only
-    // buffer descriptors: lanes without work address past num_records (the load returns 0 without a memory request)
-    const __amdgpu_buffer_rsrc_t rs_pay =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(wg.pay), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)(ncol * 8), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_val =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : wg.val), 0, 0x7fffffff, 0x00020000);
-    int cur = 0;
-
-    TallRegs<DICT> regs[kDepth];
-    unsigned int hw[2 * kDepth];
-
-    auto widths = [&](unsigned int h, unsigned int *c) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned int v = (unsigned int)__builtin_amdgcn_readlane((int)h, 2 + i);
-            c[2 * i] = v & 0xffffu;
-            c[2 * i + 1] = v >> 16;
-        }
-    };
-
-    auto issue = [&](TallRegs<DICT> &g, unsigned int h) {
-        const unsigned int off = (unsigned int)__builtin_amdgcn_readlane((int)h, 0);
-        const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
-        unsigned int c[kTallSlots];
-        widths(h, c);
-        unsigned int so = off * 4u;
-        const unsigned int mine = (unsigned int)p * 4u;
-#pragma unroll
-        for (int k = 0; k < kTallSlots; ++k) {
-            g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);  // streamed once
-            if (!DICT) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_val, (unsigned)p < c[k] ? 2u * mine : kOob, 2u * so, 2);
-                g.val[k] = __hiloint2double((int)v[1], (int)v[0]);
-            }
-            so += c[k] * 4u;
-        }
-        if (DICT) {
-            g.hi[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[0] ? mine : kOob, so, 2);
-            so += c[0] * 4u;
-            g.hi[DICT ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4] ? mine : kOob, so, 2);
-        }
-        // columns past ncol read 0: the displacement of each double is part of the voffset, which the descriptor's range check
-        // covers (an soffset is not checked on gfx9 raw buffers)
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 6 || SLP_TALL_ABL == 7)   // lab (wrong results): no x-tile loads
-        const unsigned int xo = kOob + 0u * xs;
-#else
-        // lane p carries doubles 2p, 2p + 1 of the tile's first half and of its second half: consecutive lanes then write
-        // consecutive 16-byte pieces of the LDS tile (no bank conflicts; with 4p .. 4p + 3 per lane the two 16-byte writes of a
-        // lane pair collided -- the tile write was the largest single item of the kernel's ablation, 0.9 of 4.1 ms)
-        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)(i & 1) + (i >> 1) * (unsigned int)(kTallC * 4), 0, 0);
-            g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
-        }
-    };
-
-    auto consume = [&](const TallRegs<DICT> &g, unsigned int h) {
-        const unsigned int xw = (unsigned int)__builtin_amdgcn_readlane((int)h, 1);
-        unsigned int c[kTallSlots];
-        widths(h, c);
-        if (xw & kPktNewCell) {
-            // sums of the previous cell (other lanes owned these rows there) and the x-tile: LDS only, loads stay in flight
-#if !defined(SLP_TALL_ABL) || (SLP_TALL_ABL != 4 && SLP_TALL_ABL != 7)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-            cur ^= 1;
-        }
-        auto stage_tile = [&]() {
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 5 || SLP_TALL_ABL == 7)   // lab: no x-tile LDS write
-            if (false) {
-#else
-            if ((xw & 0x7fffffffu) != kNoTile) {
-#endif
-                // (Bringing the tile in by LDS-DMA -- __builtin_amdgcn_global_load_lds, no registers, no ds_write -- was built and
-                // measured: 4.71 ms against 3.99.  With two tile buffers the DMA can only start at the cell's barrier and must
-                // have landed by the next one, 1.6 us later; the register path issues the loads four cells ahead.  A third buffer
-                // does not fit beside 78 KB of running sums.)
-                double *dst = &xt[cur ^ 1][2 * p];
-                *reinterpret_cast<double2 *>(dst) = make_double2(g.x[0], g.x[1]);
-                *reinterpret_cast<double2 *>(dst + kTallC / 2) = make_double2(g.x[2], g.x[3]);
-            }
-        };
-#ifdef SLP_TALL_WRITE_FIRST   // lab: the order of rounds 3-4a -- every wave stores its share of the tile right behind the barrier
-        stage_tile();
-#endif
-        const double *__restrict__ tile = xt[cur];
-        // Four slots at a time: all twelve LDS reads (running sums, values, x) are issued together, the products do not
-        // depend on the sums, and a sum that the lane has just updated is carried in a register (a lane's items of one
-        // row are consecutive) -- the LDS latency is paid once per group, not once per item.  The additions of a row
-        // stay one chain in list order.
-        auto group = [&](const int k0) {
-            unsigned int w[4], hb[4], row[4];
-            double ar[4], pr[4], t[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                w[k] = g.lo[k0 + k];
-                if (DICT) {
-                    hb[k] = (g.hi[DICT ? (k0 >> 2) : 0] >> (8 * k)) & 0xffu;
-                    row[k] = (w[k] >> 23) | ((hb[k] & 0x1fu) << 9);
-                } else {
-                    hb[k] = (w[k] >> 24) & 0x80u;   // bit 31: skip item
-                    row[k] = (w[k] >> kTallColBits) & ((1u << kTallRowBits) - 1);
-                }
-            }
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)   // lab: no running-sum traffic
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ar[k] = (double)row[k];
-#else
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ar[k] = acc[row[k]];
-#endif
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 1 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)   // lab: no value / x gathers
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pr[k] = (double)(w[k] & 0x7fffffu) * tile[p];
-#else
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                pr[k] = DICT ? dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)]
-                             : (POW ? abs_pow(g.val[DICT ? 0 : k0 + k], pw) * 1.0 : g.val[DICT ? 0 : k0 + k]) * tile[w[k] & (kTallC - 1)];
-#endif
-            t[0] = ar[0] + pr[0];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) t[k] = ((row[k] == row[k - 1]) ? t[k - 1] : ar[k]) + pr[k];
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)
-            if ((unsigned)p < c[k0 + 3] && !(hb[3] & 0x80u)) acc[p] = ((t[0] + t[1]) + t[2]) + t[3];   // one store per group keeps the work alive
-#else
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((unsigned)p < c[k0 + k] && !(hb[k] & 0x80u)) acc[row[k]] = t[k];
-#endif
-        };
-        if (wbase < c[0]) {
-            group(0);
-            if (wbase < c[4]) group(4);
-        }
-        // The x-tile of the NEXT cell goes into the other buffer AFTER this packet's items (it only has to be there by the next
-        // cell's barrier): right behind the barrier all 16 waves would store at once and every wave's gathers would queue behind
-        // 32 KB of stores; behind the items the waves' stores spread over the cell.
-#ifndef SLP_TALL_WRITE_FIRST
-        stage_tile();
-#endif
-    };
-
-    // prologue: headers of the first 2 x depth packets, payload of the first depth
-#pragma unroll
-    for (int u = 0; u < 2 * kDepth; ++u) hw[u] = hd[(i64)u * 8];
-#pragma unroll
-    for (int u = 0; u < kDepth; ++u) issue(regs[u], hw[u]);
-    __syncthreads();
-    for (int jj = 0; jj < npk; jj += 2 * kDepth) {
-#pragma unroll
-        for (int u = 0; u < 2 * kDepth; ++u) {
-            consume(regs[u % kDepth], hw[u]);                               // packet jj + u
-            issue(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)]);       // payload of packet jj + u + depth
-            hw[u] = hd[(i64)(jj + u + 2 * kDepth) * 8];                     // header of packet jj + u + 2 depth
-        }
-    }
-    __syncthreads();
-    for (int r = p; r < R; r += kTallT) {
-        const i64 row = b * (i64)R + r;
-        if (row < nrow) out[(v % S) * nrow + row] = acc[r];  // (S > 1: partial sums of this strip range, added up in range order)
-    }
-}
-
 // ---- host side ---------------------------------------------------------------------------------------------------------
 // Rows per block: as tall as the LDS allows, and such that the blocks are (nearly) a multiple of the CU count -- every
 // CU then walks the same number of row blocks and no strip is ever split over workgroups.
@@ -891,45 +655,6 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     if (S > 1) f.part.alloc((size_t)S * (size_t)nrowF);
     f.ok = true;
     return true;
-}
-
-__global__ void k_tall_combine(i64 nrow, int S, const double *__restrict__ part, double *__restrict__ out, int accum) {
-    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (i64)gridDim.x * blockDim.x) {
-        double a = accum ? out[r] + part[r] : part[r];
-        for (int s = 1; s < S; ++s) a += part[(i64)s * nrow + r];  // strip ranges in order: deterministic
-        out[r] = a;
-    }
-}
-
-void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
-    double *dst = f.S > 1 ? f.part.p : out;
-    const unsigned grid = (unsigned)(f.B * f.S);
-    const bool acc = accum && f.S == 1;
-#define SLP_TALL_LAUNCH(DICT, ACC)                                                                                                   \
-    hipLaunchKernelGGL((k_tall_spmv<DICT, ACC>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_wg.p, \
-                       DICT ? f.dict : (const double *)nullptr, DICT ? f.D : 0, x, dst, 0.0)
-    if (f.D > 0) { if (acc) SLP_TALL_LAUNCH(true, true); else SLP_TALL_LAUNCH(true, false); }
-    else { if (acc) SLP_TALL_LAUNCH(false, true); else SLP_TALL_LAUNCH(false, false); }
-#undef SLP_TALL_LAUNCH
-    if (f.S > 1)
-        hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
-    SLP_HIP(hipGetLastError());
-}
-
-// out = |A|^pw x over a tall-cell copy with fp64 entries (strip_spmv_abs_pow)
-void tall_spmv_pow(const StripJds &f, double pw, const double *x, double *out, int accum) {
-    SLP_REQUIRE(f.ok && f.tall && f.D == 0, "tall_spmv_pow: not a tall-cell copy with fp64 entries");
-    double *dst = f.S > 1 ? f.part.p : out;
-    const unsigned grid = (unsigned)(f.B * f.S);
-    if (accum && f.S == 1)
-        hipLaunchKernelGGL((k_tall_spmv<false, true, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S,
-                           f.tall_wg.p, (const double *)nullptr, 0, x, dst, pw);
-    else
-        hipLaunchKernelGGL((k_tall_spmv<false, false, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S,
-                           f.tall_wg.p, (const double *)nullptr, 0, x, dst, pw);
-    if (f.S > 1)
-        hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
-    SLP_HIP(hipGetLastError());
 }
 
 // Long rows over a width far beyond an L2, too sparse for the LDS strips: 0.05 .. 2.5 entries per (row, 4096 columns).
