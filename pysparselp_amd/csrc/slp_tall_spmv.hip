@@ -35,6 +35,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     __shared__ double acc[kTallRmax];
     __shared__ double dv[kTallDictMax];
     __shared__ double xt[2][kTallC];
+    __shared__ double dump;   // where the slots that are not a lane's store (never read)
     const int p = threadIdx.x;
     const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
     const i64 v = blockIdx.x, b = v / S;  // workgroup v walks the strips of range v % S of row block b
@@ -183,9 +184,20 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)
             if ((unsigned)p < c[k0 + 3] && !(hb[3] & 0x80u)) acc[p] = ((t[0] + t[1]) + t[2]) + t[3];   // one store per group keeps the work alive
 #else
+#ifdef SLP_TALL_BRANCHY_STORES   // lab: the stores of rounds 3-4 -- each under its own exec mask, i.e. eight small basic blocks per packet
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if ((unsigned)p < c[k0 + k] && !(hb[k] & 0x80u)) acc[row[k]] = t[k];
+#else
+            // Unconditional stores: a slot that is not this lane's stores into a scratch cell instead of being skipped under an exec
+            // mask -- a packet's items stay ONE basic block, which the instruction scheduler may interleave with the loads of the
+            // packets ahead (with a branch around every store it could not move anything past them).
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double *dst = ((unsigned)p < c[k0 + k] && !(hb[k] & 0x80u)) ? &acc[row[k]] : &dump;
+                *dst = t[k];
+            }
+#endif
 #endif
         };
         if (wbase < c[0]) {
