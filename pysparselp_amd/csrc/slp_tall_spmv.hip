@@ -114,7 +114,37 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
         }
     };
 
-    auto consume = [&](const TallRegs<DICT> &g, unsigned int h) {
+#ifndef SLP_TALL_WHOLE_ISSUE   // (lab: SLP_TALL_WHOLE_ISSUE = all loads of a packet behind all of its items, as in rounds 3-4)
+    // issue() in two halves: the registers of slots 0-3 are free once the first four items are done, so their loads for the packet
+    // `depth` ahead go out BETWEEN the two groups of items (in the shadow of the LDS latency) instead of behind all of them
+    auto issue_part = [&](TallRegs<DICT> &g, unsigned int h, const int part) {
+        const unsigned int off = (unsigned int)__builtin_amdgcn_readlane((int)h, 0);
+        unsigned int c[kTallSlots];
+        widths(h, c);
+        const unsigned int mine = (unsigned int)p * 4u;
+        unsigned int so = off * 4u;
+        if (part == 1) so += (c[0] + c[1] + c[2] + c[3]) * 4u;
+#pragma unroll
+        for (int k = 4 * part; k < 4 * part + 4; ++k) {
+            g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);
+            so += c[k] * 4u;
+        }
+        if (part == 0) so += (c[4] + c[5] + c[6] + c[7]) * 4u;   // the fifth bytes follow the eight slots: slots 0-3, then slots 4-7
+        else so += c[0] * 4u;
+        g.hi[part] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4 * part] ? mine : kOob, so, 2);
+        if (part == 1) {
+            const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
+            const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)(i & 1) + (i >> 1) * (unsigned int)(kTallC * 4), 0, 0);
+                g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
+            }
+        }
+    };
+#endif
+
+    auto consume = [&](const TallRegs<DICT> &g, unsigned int h, auto &&between) {
         const unsigned int xw = (unsigned int)__builtin_amdgcn_readlane((int)h, 1);
         unsigned int c[kTallSlots];
         widths(h, c);
@@ -200,10 +230,17 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #endif
 #endif
         };
+#ifndef SLP_TALL_WHOLE_ISSUE
+        group(0);   // (a wave without items -- nearly never -- reads cell 0 of the arrays and stores into the scratch cell)
+        between();
+        if (wbase < c[4]) group(4);
+#else
         if (wbase < c[0]) {
             group(0);
             if (wbase < c[4]) group(4);
         }
+        between();
+#endif
         // The x-tile of the NEXT cell goes into the other buffer AFTER this packet's items (it only has to be there by the next
         // cell's barrier): right behind the barrier all 16 waves would store at once and every wave's gathers would queue behind
         // 32 KB of stores; behind the items the waves' stores spread over the cell.
@@ -221,8 +258,16 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     for (int jj = 0; jj < npk; jj += 2 * kDepth) {
 #pragma unroll
         for (int u = 0; u < 2 * kDepth; ++u) {
-            consume(regs[u % kDepth], hw[u]);                               // packet jj + u
+#ifndef SLP_TALL_WHOLE_ISSUE
+            if (DICT) {
+                consume(regs[u % kDepth], hw[u], [&]() { issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 0); });
+                issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 1);
+            } else
+#endif
+            {
+            consume(regs[u % kDepth], hw[u], []() {});                      // packet jj + u
             issue(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)]);       // payload of packet jj + u + depth
+            }
             hw[u] = hd[(i64)(jj + u + 2 * kDepth) * 8];                     // header of packet jj + u + 2 depth
         }
     }
