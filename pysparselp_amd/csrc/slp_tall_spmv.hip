@@ -127,11 +127,17 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #pragma unroll
         for (int k = 4 * part; k < 4 * part + 4; ++k) {
             g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);
+            if (!DICT) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_val, (unsigned)p < c[k] ? 2u * mine : kOob, 2u * so, 2);
+                g.val[DICT ? 0 : k] = __hiloint2double((int)v[1], (int)v[0]);
+            }
             so += c[k] * 4u;
         }
-        if (part == 0) so += (c[4] + c[5] + c[6] + c[7]) * 4u;   // the fifth bytes follow the eight slots: slots 0-3, then slots 4-7
-        else so += c[0] * 4u;
-        g.hi[part] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4 * part] ? mine : kOob, so, 2);
+        if (DICT) {
+            if (part == 0) so += (c[4] + c[5] + c[6] + c[7]) * 4u;   // the fifth bytes follow the eight slots: slots 0-3, then slots 4-7
+            else so += c[0] * 4u;
+            g.hi[DICT ? part : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4 * part] ? mine : kOob, so, 2);
+        }
         if (part == 1) {
             const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
             const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
@@ -259,15 +265,12 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #pragma unroll
         for (int u = 0; u < 2 * kDepth; ++u) {
 #ifndef SLP_TALL_WHOLE_ISSUE
-            if (DICT) {
-                consume(regs[u % kDepth], hw[u], [&]() { issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 0); });
-                issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 1);
-            } else
-#endif
-            {
+            consume(regs[u % kDepth], hw[u], [&]() { issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 0); });   // packet jj + u
+            issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 1);                                               // (payload of packet jj + u + depth)
+#else
             consume(regs[u % kDepth], hw[u], []() {});                      // packet jj + u
             issue(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)]);       // payload of packet jj + u + depth
-            }
+#endif
             hw[u] = hd[(i64)(jj + u + 2 * kDepth) * 8];                     // header of packet jj + u + 2 depth
         }
     }
