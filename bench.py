@@ -48,7 +48,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # the HIP library first: bench never needs torch on one GPU
 from pysparselp_amd import _lib  # noqa: E402
-from pysparselp_amd.device import DeviceMatrix  # noqa: E402
+from pysparselp_amd.device import ChunkedDeviceMatrix, DeviceMatrix  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a plain copy achieves)
 
@@ -76,9 +76,15 @@ PMC_FILES = {   # newest record first
 # config 4's per-rank shape at a density that fits (the 1e-3 of config 4 is 2.4 TB of CSR)
 # c4 = the metric's named LP, 1e7 x 2e7 at the density that fits one node (1e-4: 2e10 stored entries): this rank's row block is
 # generated, converted and released in row chunks (ChunkedDeviceMatrix), so it is resident on 1, 2, 4 or 8 GPUs alike
-CONFIGS = {"c3": (1_000_000, 2_000_000, 1e-3), "c4slice": (10_000_000, 2_500_000, 1e-4), "c4": (10_000_000, 20_000_000, 1e-4)}
+# c5 = BASELINE config 5: block-splitting ADMM (ADMMBlocks.py) on a 5e7-variable LP at density 1e-4 -- eight row blocks of 5e5
+# rows (2e10 stored entries, as many as c4), 8 / N blocks per rank; every block is generated, converted and released on its own
+# (DeviceBlocksGroup.from_generator), so the whole LP is resident on ONE GPU as 8 x 26 GB of tall cells
+CONFIGS = {"c3": (1_000_000, 2_000_000, 1e-3), "c4slice": (10_000_000, 2_500_000, 1e-4), "c4": (10_000_000, 20_000_000, 1e-4),
+           "c5": (50_000_000, 4_000_000, 1e-4)}
+CONFIG_BLOCKS = {"c5": 8}   # row blocks of the whole LP (admm_blocks)
 PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: (("r04_tall_slice_pmc_hbm.json", "r03_tall_slice_pmc_hbm.json"), "slp::k_tall_spmv")},
-                      (10_000_000, 20_000_000, 1e-4): {6: (("r04_c4_pmc_hbm.json",), "slp::k_tall_spmv")}}
+                      (10_000_000, 20_000_000, 1e-4): {6: (("r05_c4_pmc_hbm.json", "r04_c4_pmc_hbm.json"), "slp::k_tall_spmv")},
+                      (50_000_000, 4_000_000, 1e-4): {6: (("r05_c5_pmc_hbm.json", "r04_c5shape_pmc_hbm.json"), "slp::k_tall_spmv")}}
 CHUNK_ENTRIES = 2.6e9   # a chunk's CSR (12 B per entry) + its conversion temporaries must fit beside the copies already built
 
 
@@ -94,11 +100,14 @@ def parse():
     p.add_argument("--density", type=float, default=None)
     p.add_argument("--no-secondary", action="store_true", help="skip the config-3 block the default N = 1 run appends")
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--method", default="admm", choices=["admm", "chambolle_pock_ppd", "admm_blocks"])
+    p.add_argument("--method", default=None, choices=["admm", "chambolle_pock_ppd", "admm_blocks"],
+                   help="default: admm (admm_blocks for --config c5)")
     p.add_argument("--eq-frac", type=float, default=0.0,
                    help="fraction of the constraint rows turned into equalities a_i x = a_i x_feasible (randomLP.py:62-68); "
                         "the default all-inequality LP is the primary workload")
-    p.add_argument("--blocks-per-rank", type=int, default=1, help="admm_blocks: row blocks on every rank (DeviceBlocksGroup)")
+    p.add_argument("--blocks-per-rank", type=int, default=0,
+                   help="admm_blocks: row blocks on every rank (DeviceBlocksGroup; default 1, for --config c5: 8 / gpus)")
+    p.add_argument("--chunks-per-block", type=int, default=1, help="admm_blocks with block groups: row chunks every block is converted in")
     p.add_argument("--jacobi", action="store_true", help="admm_blocks: Jacobi-preconditioned conjugate gradients (slp_blocks_set_precond)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-general", action="store_true", help="skip the general (fp64 strip entries) block")
@@ -112,6 +121,15 @@ def parse():
                    help="slp_matrix_set_format policy of the timed run: 0 best available, 1 no value dictionary, 2 CSR kernels")
     args = p.parse_args()
     args.default_workload = args.config is None and args.n is None and args.m is None and args.density is None
+    if args.method is None:
+        args.method = "admm_blocks" if args.config == "c5" else "admm"
+    args.blocks_total = CONFIG_BLOCKS.get(args.config, 0) if args.method == "admm_blocks" else 0
+    if args.blocks_total and not args.blocks_per_rank:
+        if args.blocks_total % args.gpus:
+            raise SystemExit(f"--config {args.config}: {args.blocks_total} row blocks do not divide over {args.gpus} ranks")
+        args.blocks_per_rank = args.blocks_total // args.gpus
+    args.blocks_per_rank = max(1, args.blocks_per_rank)
+    args.block_group = args.method == "admm_blocks" and (args.blocks_total > 0 or args.blocks_per_rank > 1)
     if args.config or args.default_workload:
         args.n, args.m, args.density = CONFIGS[args.config or "c4"]
     else:  # free shape: what is not given comes from config 3
@@ -148,7 +166,7 @@ def pmc_traffic(kernel_id, shape):
 
 def spmv_block(lib, a, transposed, shape, reps=5):
     """Roofline figures of one SpMV orientation of the resident matrix, timed with HIP events on the library's stream.
-    A chunked matrix runs one launch per chunk: "per launch" figures are per PRODUCT (all of its launches)."""
+    Figures are per PRODUCT (y = A x once); a chunked matrix may take several launches for one (``launches_per_product``)."""
     rows, cols = (a.shape[1], a.shape[0]) if transposed else a.shape
     ms = a.bench_spmv(transposed, reps=reps)
     which = int(lib.slp_matrix_spmv_kernel(a._h, int(transposed)))
@@ -156,18 +174,19 @@ def spmv_block(lib, a, transposed, shape, reps=5):
     moved = copy_bytes + 8 * cols + 8 * rows  # the matrix copy streamed once + x read once + y written once
     alg = spmv_bytes(a.nnz, rows, cols)
     traffic, src = pmc_traffic(which, shape) if not transposed else (None, None)
-    launches = max(1, int(lib.slp_matrix_chunks(a._h)))
+    launches = max(1, int(lib.slp_matrix_product_launches(a._h, int(transposed))))
     if traffic is not None:
-        traffic *= launches   # the PMC summary is per kernel launch
+        traffic *= max(1, int(lib.slp_matrix_chunks(a._h)))   # the PMC summary is per chunk-sized launch
     out = {
         "kernel": KERNEL_NAMES.get(which, "?"),
         "achieved": moved / (ms * 1e-3) / 1e9,
         "frac": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "ms_per_launch": ms,
+        "ms_per_product": ms,
         "launches_per_product": launches,
-        "bytes_per_launch": moved,
-        "matrix_copy_bytes_per_launch": copy_bytes,
-        "csr_equivalent": {"algorithmic_bytes_per_launch": alg, "gbps": alg / (ms * 1e-3) / 1e9,
+        "ms_per_launch": ms / launches,
+        "bytes_per_product": moved,
+        "matrix_copy_bytes_per_product": copy_bytes,
+        "csr_equivalent": {"algorithmic_bytes_per_product": alg, "gbps": alg / (ms * 1e-3) / 1e9,
                            "x_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
     if not transposed:
@@ -241,6 +260,85 @@ def cpu_baseline(args, method):
     return out
 
 
+def mem_total_bytes(lib):
+    free, total = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64)
+    _lib.check(lib.slp_device_memory(_lib.ptr(free), _lib.ptr(total)))
+    return float(total[0])
+
+
+def exchange_block(args, world, distributed, coll, exch, exch_max, ms_step):
+    """How much of a step was exchange.  ``exch`` = slp_comm_timing_read of rank 0, ``exch_max`` the
+    max over the ranks of (ms in collectives, slowest collective, ms on the second stream, -ms in collectives)."""
+    n_rec = int(exch[0])
+    ms_it = float(exch_max[0]) / args.steps
+    side_it = float(exch_max[2]) / args.steps
+    out = {
+        "transport": os.environ.get("SLP_COMM_TRANSPORT", "rccl") if distributed else None,
+        "collectives_per_iteration": (coll / args.steps) if distributed else 0,
+        "collectives_timed": n_rec,
+        "ms_per_iteration": ms_it,                                   # max over the ranks
+        "ms_per_iteration_min_over_ranks": -float(exch_max[3]) / args.steps,
+        "ms_overlapped_per_iteration": side_it,                      # issued on the second stream beside the next block's projection
+        "slowest_collective_ms": float(exch_max[1]),
+        "bytes_per_collective": (float(exch[2]) / n_rec) if n_rec else 0.0,
+        "algbw_gbps": (float(exch[2]) / 1e9) / (float(exch[1]) * 1e-3) if exch[1] > 0 else None,   # rank 0: payload / time
+        "busbw_gbps_allreduce": ((float(exch[2]) / 1e9) / (float(exch[1]) * 1e-3) * 2.0 * (world - 1) / world) if exch[1] > 0 and world > 1 else None,
+        "collectives_not_timed": int(exch[5]),
+        # serial collectives sit on the compute stream: the step minus them is what the kernels took (the overlapped ones do not
+        # extend the step unless they outlast the projection beside them)
+        "compute_ms_per_step": ms_step - (ms_it - side_it),
+        "fraction_of_step": (ms_it - side_it) / ms_step if ms_step > 0 else None,
+    }
+    return out
+
+
+def cpu_baseline_blocks(args, rows_per_block, cg_steps_full):
+    """The oracle's matrix-free form of the block iteration (oracle.lp_admm_blocks_cg: ADMMBlocks.py:264-307 with the per-block
+    KKT solve of :268-284 done by conjugate gradients -- the reference's sparse LU of a block with 5e5 rows x 5e7 columns cannot
+    run) on ONE block cut down to a sample of its rows, all n columns, 1 thread; iterations only.  Scaled to the whole LP by the
+    rows (cost per product is linear in them at fixed n) and by the products per block update measured on the GPU at full size
+    (the sample's short block is better conditioned and needs fewer CG steps)."""
+    from oracle import oracle
+
+    rows = args.cpu_sample_rows or max(1, min(rows_per_block, int(2.5e7 / max(args.n * args.density, 1.0))))
+    a = DeviceMatrix.random(rows, args.n, args.density, args.seed)
+    xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed)
+    s = a.download()
+    a.close()
+    stamps, steps_at = [time.perf_counter()], [0]
+    state = {}
+
+    def hook(i):
+        stamps.append(time.perf_counter())
+
+    iters = 3
+    t_start = time.perf_counter()
+    _, steps = oracle.lp_admm_blocks_cg(c, [(oracle.as_csr(s), None, b)], lb, ub, nb_iter=iters, iterate_hook=hook)
+    per_iter = (stamps[-1] - stamps[1]) / (len(stamps) - 2)       # iterations 1 .. (warm-started projections, like the timed GPU steps)
+    passes_sample = 3 + 2 * steps / iters
+    passes_full = 3 + 2 * cg_steps_full
+    blocks_total = args.m // rows_per_block
+    scale = (rows_per_block / rows) * (passes_full / passes_sample) * blocks_total
+    return {
+        "value": 1.0 / (per_iter * scale),
+        "unit": "it/s",
+        "cores": 1,
+        "kind": "port",
+        "extrapolated": True,
+        "form": "matrix-free (conjugate-gradient) per-block projection -- oracle.lp_admm_blocks_cg; the reference's per-block sparse LU "
+                "(ADMMBlocks.py:178-243) cannot factorise a 5e5 x 5e7 block",
+        "sample": f"ONE block cut to its first {rows} of {rows_per_block} rows (all {args.n} columns, density {args.density}: {s.nnz} stored "
+                  f"entries), iterations 1..{iters - 1} of {iters} timed: {per_iter:.3f} s per block update at {passes_sample:.1f} products; "
+                  f"value = 1 / (that x {rows_per_block}/{rows} rows x {passes_full:.1f}/{passes_sample:.1f} products per block update "
+                  f"(the GPU's count at full size) x {blocks_total} blocks)",
+        "seconds_per_block_update_on_sample": per_iter,
+        "products_per_block_update_on_sample": passes_sample,
+        "products_per_block_update_full_size": passes_full,
+        "sample_seconds_total": time.perf_counter() - t_start,
+        "host_cores_present": os.cpu_count(),
+    }
+
+
 def timed_steps(lib, solver, warmup, steps):
     solver.iterate(warmup)
     _lib.check(lib.slp_comm_barrier())
@@ -299,34 +397,45 @@ def main():
         from pysparselp_amd.parallel import init_comm_from_env
 
         init_comm_from_env(rank, world)
+    oom = None
     try:
         out = run_workload(lib, args, rank, world, distributed)
     except _lib.SlpError as e:
-        # Config 4 on one GPU peaks at ~280 of the device's 309 GB while a chunk is converted.  Should a box offer less, the SAME LP
-        # is built from twice as many (half as large) chunks -- results do not depend on the chunking, bit for bit
+        # Config 4 / 5 on one GPU peak at ~280 of the device's 309 GB while a chunk is converted.  Should a box offer less, the
+        # SAME LP is built from twice as many (half as large) chunks -- results do not depend on the chunking, bit for bit
         # (tests/test_gpu_chunked.py) -- before giving up.
-        if world != 1 or "hipMalloc" not in str(e) or args.chunks:
+        if world != 1 or "hipMalloc" not in str(e) or args.chunks or args.chunks_per_block > 1:
             raise
+        oom = str(e)   # only the message leaves the block: the exception's traceback keeps the failed attempt's frames -- and
+        #                through their locals up to ~200 GB of device copies -- alive for as long as `e` is
+    if oom is not None:
         import gc
 
-        print(f"bench.py: {e}; retrying with twice the row chunks", file=sys.stderr, flush=True)
+        print(f"bench.py: {oom}; retrying with twice the row chunks", file=sys.stderr, flush=True)
         gc.collect()
         _lib.check(lib.slp_trim())
-        args.chunks = 2 * max(1, int(np.ceil(args.m * args.n * args.density / CHUNK_ENTRIES)))
+        if args.block_group:
+            args.chunks_per_block = 2
+        else:
+            args.chunks = 2 * max(1, int(np.ceil(args.m * args.n * args.density / CHUNK_ENTRIES)))
         out = run_workload(lib, args, rank, world, distributed)
-        out["config"]["chunks_doubled_after"] = str(e)
+        out["config"]["chunks_doubled_after"] = oom
     if rank == 0:
         if world == 1 and args.default_workload and not args.no_secondary and args.method != "admm_blocks":
-            # BASELINE config 3 through the same code: the headline workload of rounds 1-3, for continuity
+            # BASELINE config 3 through the same code: the headline workload of rounds 1-3, for continuity.  The headline line
+            # does not depend on it: whatever goes wrong here is recorded, the line is printed all the same.
             import copy
 
             a3 = copy.copy(args)
             a3.n, a3.m, a3.density = CONFIGS["c3"]
             a3.chunks = 0
             a3.no_cpu_baseline = True
-            sec = run_workload(lib, a3, rank, world, distributed)
-            out["secondary"] = {"c3": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "objective_after_run",
-                                                           "setup_seconds", "setup_breakdown", "device_memory")}}
+            try:
+                sec = run_workload(lib, a3, rank, world, distributed)
+                out["secondary"] = {"c3": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline",
+                                                               "objective_after_run", "setup_seconds", "setup_breakdown", "device_memory")}}
+            except Exception as e:  # noqa: BLE001
+                out["secondary"] = {"c3": {"error": f"{type(e).__name__}: {e}"}}
         print(json.dumps(out), flush=True)
     if distributed:
         _lib.check(lib.slp_comm_barrier())
@@ -347,28 +456,40 @@ def run_workload(lib, args, rank, world, distributed):
     t_gen = time.perf_counter()
     from pysparselp_amd.problems import random_lp_on_device
 
-    a, xf, c, lb, ub, b = random_lp_on_device(args.n, args.m, args.density, seed=args.seed, row_offset=r0, rows=rows, chunks=chunks)
-    nnz_local = a.nnz
-    _lib.check(lib.slp_synchronize())
-    t_generate = time.perf_counter() - t_gen  # the synthetic LP itself (randomLP.py's part); the rest of setup_seconds is the solver's
-    if args.format:
-        _lib.check(lib.slp_matrix_set_format(a._h, args.format))
-    from pysparselp_amd.scale import make_solver
+    from pysparselp_amd.scale import DeviceBlocksGroup, make_solver
 
-    m_eq_local = 0
-    if args.eq_frac > 0:  # the first eq_frac * m GLOBAL rows are equalities b_eq = A x_feasible; this rank holds its share
-        m_eq_global = int(round(args.eq_frac * args.m))
-        m_eq_local = max(0, min(rows, m_eq_global - r0))
-        if m_eq_local:
-            b[:m_eq_local] = a.matvec(xf)[:m_eq_local]
-    solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local, blocks_per_rank=args.blocks_per_rank, jacobi=args.jacobi)
+    if args.block_group:
+        # block-splitting ADMM over several row blocks of this rank: every block generated from its own row range, converted,
+        # its CSR released before the next one is generated -- no resident matrix to cut the blocks out of
+        chunks = args.chunks_per_block
+        cuts = [rows * g // args.blocks_per_rank for g in range(args.blocks_per_rank + 1)]
+        solver, xf, c, lb, ub, b = DeviceBlocksGroup.from_generator(args.n, args.m, args.density, args.seed, cuts, row_offset=r0,
+                                                                    chunks_per_block=chunks)
+        a, owns_a = solver._mats[0], False   # the products are timed on the first block
+        nnz_local = solver.nnz
+        t_generate = solver.seconds_generating
+    else:
+        a, xf, c, lb, ub, b = random_lp_on_device(args.n, args.m, args.density, seed=args.seed, row_offset=r0, rows=rows, chunks=chunks)
+        owns_a = True
+        nnz_local = a.nnz
+        _lib.check(lib.slp_synchronize())
+        t_generate = time.perf_counter() - t_gen  # the synthetic LP itself (randomLP.py's part); the rest of setup_seconds is the solver's
+        if args.format:
+            _lib.check(lib.slp_matrix_set_format(a._h, args.format))
+        m_eq_local = 0
+        if args.eq_frac > 0:  # the first eq_frac * m GLOBAL rows are equalities b_eq = A x_feasible; this rank holds its share
+            m_eq_global = int(round(args.eq_frac * args.m))
+            m_eq_local = max(0, min(rows, m_eq_global - r0))
+            if m_eq_local:
+                b[:m_eq_local] = a.matvec(xf)[:m_eq_local]
+        solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local, jacobi=args.jacobi)
     _lib.check(lib.slp_synchronize())
     t_gen = time.perf_counter() - t_gen
     # Steady state keeps only what the iteration reads: when both orientations run on strip copies, the two CSR copies
     # (48 GB at config 3) are dropped and the cached temporaries of the setup returned to the driver.
     _lib.check(lib.slp_alloc_stats(_lib.ptr(alloc), 0))
     mem = {"in_use_after_setup_gb": device_memory_in_use(lib), "peak_held_by_the_library_gb": alloc[1] / 1e9}
-    released = args.release_csr and args.blocks_per_rank == 1 and a.spmv_kernel(False) >= 1 and a.spmv_kernel(True) >= 1
+    released = args.release_csr and not args.block_group and chunks == 1 and a.spmv_kernel(False) >= 1 and a.spmv_kernel(True) >= 1
     if released:
         a.release_csr()
     _lib.check(lib.slp_trim())
@@ -380,14 +501,20 @@ def run_workload(lib, args, rank, world, distributed):
     cg0 = solver.cg_steps() if args.method == "admm_blocks" else 0
     _lib.check(lib.slp_comm_barrier())
     coll0 = int(lib.slp_comm_collectives())
+    _lib.check(lib.slp_comm_timing(1))   # HIP event pairs around every collective: recorded now, read after the timed region
     t0 = time.perf_counter()
     solver.iterate(args.steps)
+    _lib.check(lib.slp_comm_timing(0))   # (the closing barrier's all-reduce is not part of an iteration)
     _lib.check(lib.slp_comm_barrier())
     dt = time.perf_counter() - t0
     coll = int(lib.slp_comm_collectives()) - coll0 - 1  # the closing barrier is one
     tmax = np.array([dt])
     _lib.check(lib.slp_comm_allreduce_host(_lib.ptr(tmax), 1, 1))
     dt = float(tmax[0])
+    exch = np.zeros(6)
+    _lib.check(lib.slp_comm_timing_read(_lib.ptr(exch)))
+    exch_max = np.array([exch[1], exch[3], exch[4], -exch[1]])   # ms in collectives (max / -min over the ranks), slowest one, overlapped part
+    _lib.check(lib.slp_comm_allreduce_host(_lib.ptr(exch_max), 4, 1))
 
     nnz = np.array([float(nnz_local)])
     _lib.check(lib.slp_comm_allreduce_host(_lib.ptr(nnz), 1, 0))
@@ -400,10 +527,13 @@ def run_workload(lib, args, rank, world, distributed):
         ax, which = spmv_block(lib, a, False, shape)
         aty, _ = spmv_block(lib, a, True, shape)
         passes = solver.matrix_passes_per_iteration()
-        if args.method == "admm_blocks":  # 3 products + 2 per conjugate-gradient step (rank 0's count)
-            passes = 3 + 2 * (solver.cg_steps() - cg0) / args.steps
+        if args.method == "admm_blocks":  # per block: 3 products + 2 per conjugate-gradient step (rank 0's count over its blocks)
+            passes = 3 * args.blocks_per_rank + 2 * (solver.cg_steps() - cg0) / args.steps
+            if args.block_group:   # the products were timed on ONE block: bytes per iteration = passes x that block's bytes
+                pass
         # one iteration = `passes` single-vector sweeps, alternating orientations: bytes the iteration has to move
-        iter_bytes = passes / 2.0 * (ax["bytes_per_launch"] + aty["bytes_per_launch"])
+        # (block groups: every block of the rank runs its own `passes`; the products are timed on the first block)
+        iter_bytes = passes / 2.0 * (ax["bytes_per_product"] + aty["bytes_per_product"])
         roofline = {
             "bound": "hbm",
             "kernel": ax["kernel"] + " -- rank 0's row block",
@@ -414,13 +544,14 @@ def run_workload(lib, args, rank, world, distributed):
             "traffic": ax["traffic"],
             "traffic_source": ax["traffic_source"],
             "traffic_measured_in_this_run": False,  # a committed rocprofv3 PMC summary of this command, not a counter of this run
-            "definition": "achieved = bytes the kernel has to move per launch (the matrix copy it streams + x read once + y "
-                          "written once) / HIP-event time per launch on the library's stream; traffic = rocprofv3 PMC "
-                          "(FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of the same kernel on the same workload",
-            "bytes_per_launch": ax["bytes_per_launch"],
-            "matrix_copy_bytes_per_launch": ax["matrix_copy_bytes_per_launch"],
-            "ms_per_launch": ax["ms_per_launch"],
-            "launches_per_product": ax["launches_per_product"],   # a chunked matrix: one launch per row chunk; "per launch" = per product
+            "definition": "achieved = bytes the kernel has to move per product y = A x (the matrix copy it streams + x read once + y "
+                          "written once) / HIP-event time per product on the library's stream; traffic = rocprofv3 PMC "
+                          "(FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of the same kernel on the same workload, per product",
+            "bytes_per_product": ax["bytes_per_product"],
+            "matrix_copy_bytes_per_product": ax["matrix_copy_bytes_per_product"],
+            "ms_per_product": ax["ms_per_product"],
+            "launches_per_product": ax["launches_per_product"],   # a chunked matrix may take one launch per row chunk
+            "ms_per_launch": ax["ms_per_launch"],                 # = ms_per_product / launches_per_product
             "csr_equivalent": ax["csr_equivalent"],
             "spmv_transposed": aty,
             "iteration": {"bytes": iter_bytes, "achieved": iter_bytes / (ms_step * 1e-3) / 1e9,
@@ -444,6 +575,8 @@ def run_workload(lib, args, rank, world, distributed):
                 "workload": f"randomLP synthetic: {args.n} vars, {args.m} inequality rows, density {args.density}, "
                             f"{nnz_total} stored entries, method {args.method} ({solver.describe()}), "
                             f"rows partitioned over {world} GPU(s)"
+                            + (f", {args.blocks_per_rank} row block(s) of the block-splitting ADMM per rank, each generated from its own "
+                               "row range, converted and its CSR released before the next (no resident matrix)" if args.block_group else "")
                             + (f", every rank's block built in {chunks} row chunks whose CSR never coexists" if chunks > 1 else "")
                             + (f", SLP_TALL_SPLIT={os.environ['SLP_TALL_SPLIT']} (strip ranges of a tall row block shared by several "
                                "workgroups, partial sums added in range order)" if os.environ.get("SLP_TALL_SPLIT") else ""),
@@ -451,9 +584,15 @@ def run_workload(lib, args, rank, world, distributed):
                 "n": args.n, "m": args.m, "density": args.density, "seed": args.seed, "nnz": nnz_total, "eq_frac": args.eq_frac,
                 "method": args.method, "matrix_passes_per_iteration": passes,
                 "collectives_per_iteration": (coll / args.steps) if distributed else 0,
-                **({"cg_steps_per_iteration": (solver.cg_steps() - cg0) / args.steps, "jacobi": bool(args.jacobi)}
+                **({"cg_steps_per_iteration": (solver.cg_steps() - cg0) / args.steps, "jacobi": bool(args.jacobi),
+                    "blocks_per_rank": args.blocks_per_rank, "blocks_total": args.blocks_per_rank * world,
+                    "cg_steps_per_block_update": (solver.cg_steps() - cg0) / args.steps / args.blocks_per_rank}
                    if args.method == "admm_blocks" else {}),
+                "shard_updates": os.environ.get("SLP_SHARD_UPDATES") == "1",
             },
+            # what of a step was exchange: HIP event pairs around every collective of the timed region (slp_comm_timing), max over
+            # the ranks; under RCCL a pair brackets the collective's kernel, whose duration includes the wait for the slowest peer
+            "exchange": exchange_block(args, world, distributed, coll, exch, exch_max, ms_step),
             "roofline": roofline,
             "objective_after_run": obj,
             "setup_seconds": t_gen,
@@ -472,13 +611,32 @@ def run_workload(lib, args, rank, world, distributed):
                 a.close()
                 a = DeviceMatrix.random(rows, args.n, args.density, args.seed, r0)
             roofline["general_fp64"] = general_block(lib, args, a, b, c, lb, ub, shape)
-        if world == 1 and not args.no_cpu_baseline and args.method != "admm_blocks":
-            # (admm_blocks: the reference's per-block sparse LU of a KKT matrix with 5e5+ unknowns does not finish in
-            # bench time even on the sample; tools/bench_blocks.py times the LU form on the Potts LP instead)
+        if world == 1 and not args.no_general and args.format == 0 and which == 6 and args.method != "admm_blocks" and chunks > 1:
+            # The metric's LP with ARBITRARY coefficients: fp64 entries are 12.4 B per stored entry as tall cells -- both
+            # orientations of all chunks would be 2.4 x the 5.2 B dictionary copies and do not fit one GPU.  What one GPU holds
+            # of it is measured instead: ONE row chunk (the per-rank share of `chunks` GPUs) with the dictionary ruled out.
+            a.close()
+            _lib.check(lib.slp_trim())
+            cuts = ChunkedDeviceMatrix.cuts(rows, chunks)
+            a = DeviceMatrix.random(cuts[1] - cuts[0], args.n, args.density, args.seed, r0)
+            share = general_block(lib, args, a, b[:cuts[1] - cuts[0]], c, lb, ub, shape)
+            fp64_bytes = 2.0 * share["spmv"]["matrix_copy_bytes_per_product"] * chunks
+            share.update({"resident_on_one_gpu": False, "share_of_rows": (cuts[1] - cuts[0]) / rows,
+                          "fp64_copies_of_the_whole_lp_gb": fp64_bytes / 1e9,
+                          "min_gpus": int(np.ceil(fp64_bytes / (0.9 * mem_total_bytes(lib)))),
+                          "note": f"measured on the first of {chunks} row chunks ({cuts[1] - cuts[0]} rows, the row block of one of {chunks} "
+                                  "ranks); rates of the whole LP on that many GPUs = these per-rank rates (plus the exchange)"})
+            roofline["general_fp64"] = share
+        if world == 1 and not args.no_cpu_baseline:
             a.close()
             a = None
             _lib.check(lib.slp_trim())
-            out["cpu_baseline"] = cpu_baseline(args, args.method)
+            if args.method == "admm_blocks":
+                # (the reference's per-block sparse LU of a KKT matrix with 5e5+ unknowns does not finish in bench time even on a
+                # sample: the oracle's matrix-free form of the same iteration is timed, oracle.lp_admm_blocks_cg)
+                out["cpu_baseline"] = cpu_baseline_blocks(args, rows // args.blocks_per_rank, out["config"]["cg_steps_per_block_update"])
+            else:
+                out["cpu_baseline"] = cpu_baseline(args, args.method)
     if solver is not None:
         solver.close()
     if a is not None:

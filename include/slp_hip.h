@@ -150,6 +150,9 @@ int slp_matrix_chunked_append(slp_matrix *chunked, slp_matrix *chunk);
 int slp_matrix_chunked_expect(slp_matrix *chunked, int64_t chunks);
 /* Chunks appended so far; 0 for an ordinary matrix, -1 for NULL. */
 int64_t slp_matrix_chunks(const slp_matrix *a);
+/* Product-kernel launches one y = A x (transposed: A^T y) takes: 1 for an ordinary matrix, up to one per row chunk for a
+ * chunked one (bench.py: "per product" vs "per launch" figures). */
+int64_t slp_matrix_product_launches(const slp_matrix *a, int transposed);
 
 /* ---- Chambolle-Pock: replaces chambolle_pock_ppd's loop ----------------- *
  * ChambollePockPPD.py:122-179 (preconditioners T, Sigma) and :195-343 (loop).
@@ -413,6 +416,16 @@ int slp_comm_barrier(void);
 /* All-reduces this process has issued since slp_comm_init (0 without a communicator): the data-path exchange steps
  * can be counted per iteration (Chambolle-Pock 1, matrix-free ADMM at reuse level 4: 2, block-splitting ADMM 1). */
 long long slp_comm_collectives(void);
+/* Exchange timing for the bench line (no reference counterpart: the reference is single-process).  slp_comm_timing(1) resets and
+ * starts recording: every collective issued from then on is bracketed by a pair of HIP events on the stream it is issued on
+ * (events are only recorded -- nothing synchronises inside the timed region); slp_comm_timing(0) stops.  slp_comm_timing_read
+ * (after the stop; synchronises) fills out[6] = { collectives recorded, ms inside them, payload bytes (this rank), the slowest
+ * single collective in ms, the part of the ms spent on the second stream (block groups: overlapped with the next block's
+ * projection), collectives that did not fit the ring of 16384 event pairs }.  Under RCCL a pair brackets the collective's
+ * kernel, whose duration includes the wait for the slowest peer.  (The host transport's asynchronous worker -- tests only -- is
+ * timed with the host clock around each job.) */
+int slp_comm_timing(int on);
+int slp_comm_timing_read(double out[6]);
 /* The communicator of this process: *nranks / *rank (1 / 0 without one); returns 1 when slp_comm_init* is active, else 0.
  * The host-API solvers (SparseLP.solve -> lp_admm(xstep="cg") / chambolle_pock_ppd) consult it: under a communicator every
  * rank holds the whole LP, hands over only its row block (equal stored entries) and returns the same x. */

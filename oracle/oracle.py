@@ -770,3 +770,99 @@ def lp_admm_block_decomposition(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, 
                 callback_func(i, xp[0:n], en, en, elapsed, 0, 0)
         i += 1
     return xp[0:n]
+
+
+# ---------------------------------------------------------------------------------------------------
+# The same block iteration with the per-block KKT solve done MATRIX-FREE (what exists at BASELINE config 5: a block of 5e5
+# rows x 5e7 columns has no sparse LU).  The solve of ADMMBlocks.py:268-284 is the projection of
+# v = xp[ids] - lambda / gamma onto {A_g x - s = 0} in the block's standard form [A_g, -I] (tools.py:88-127); eliminating it:
+#   dual form    (A_g A_g^T + I) nu = A_g v - v_s ,  x = v - A_g^T nu , s = v_s + nu
+#   primal form  (I + A_g^T A_g) x  = v + A_g^T v_s , s = A_g x                   (taken when a block has at least as many rows as columns)
+# solved by conjugate gradients warm-started from the previous iteration's solution, stopping test |r|^2 <= tol^2 |rhs|^2
+# looked at every `check_every` steps.  This is the CPU restatement of csrc/slp_blocks.hip's row-block form (same order of the
+# elementwise operations); it agrees with lp_admm_block_decomposition's LU form to the CG tolerance
+# (tests/test_oracle_golden.py) and is what bench.py times as the cpu_baseline of `--method admm_blocks`.
+# All rows are inequalities  b_lower <= A_g x <= b_upper.
+def lp_admm_blocks_cg(c, blocks, lb, ub, gamma=0.7, alpha=1.95, nb_iter=10, cg_tol=1e-13, cg_max_steps=500, check_every=10,
+                      primal=None, iterate_hook=None):
+    """``blocks``: list of ``(a_g, b_lower_g or None, b_upper_g)`` with ``a_g`` the block's rows over all n variables.
+    Runs ``nb_iter`` iterations from x0 = 0; returns ``(xp, cg_steps)``; ``iterate_hook(i)`` is called after iteration i."""
+    c, lb, ub = _f64(c), _f64(lb), _f64(ub)
+    n = c.size
+    st = []
+    copies = np.zeros(n)
+    for a, bl, bu in blocks:
+        a = as_csr(a)
+        m = a.shape[0]
+        bu = _f64(bu)
+        bl = np.full(m, -np.inf) if bl is None else _f64(bl)
+        used = np.zeros(n, dtype=bool)
+        used[a.indices] = True   # a copy exists only for the variables the block uses (:183-185)
+        copies += used
+        st.append({"a": a, "m": m, "slo": bl, "shi": bu, "used": used, "lam": np.zeros(n), "nu": np.zeros(m), "xsol": np.zeros(n),
+                   "xps": np.minimum(np.maximum(0.0, bl), bu), "lams": np.zeros(m),
+                   "primal": (m >= n and m > 0) if primal is None else bool(primal)})
+    xp = np.minimum(np.maximum(0.0, lb), ub)   # :84-86 with x0 = 0
+    steps = 0
+
+    def cg(apply, rhs, r, sol):
+        nonlocal steps
+        rhs2, rs = float(rhs.dot(rhs)), float(r.dot(r))
+        d = r.copy()
+        it = 0
+        while it < cg_max_steps:
+            if not rs > cg_tol * cg_tol * rhs2:
+                break
+            chunk = min(check_every, cg_max_steps - it)
+            for _ in range(chunk):
+                q = apply(d)
+                pq = float(d.dot(q))
+                al = rs / pq if (rs > 0.0 and pq > 0.0) else 0.0
+                sol += al * d
+                r -= al * q
+                rsn = float(r.dot(r))
+                be = rsn / rs if rs > 0.0 else 0.0
+                rs = rsn
+                d = r + be * d
+            it += chunk
+            steps += chunk
+
+    for i in range(nb_iter):
+        total = np.zeros(n)
+        xs_all = []
+        for k, s in enumerate(st):
+            a, m = s["a"], s["m"]
+            v = xp - s["lam"] / gamma
+            vs = s["xps"] - s["lams"] / gamma
+            if s["primal"]:
+                u = rmatvec(a, vs)
+                rhs = v + u
+                r = rhs - (s["xsol"] + rmatvec(a, matvec(a, s["xsol"])))
+                cg(lambda d: rmatvec(a, matvec(a, d)) + d, rhs, r, s["xsol"])
+                w = matvec(a, s["xsol"])
+                x = alpha * s["xsol"] + (1.0 - alpha) * xp
+                xs = alpha * w + (1.0 - alpha) * s["xps"]
+            elif m > 0:
+                rhs = matvec(a, v) - vs
+                r = rhs - (matvec(a, rmatvec(a, s["nu"])) + s["nu"])
+                cg(lambda d: matvec(a, rmatvec(a, d)) + d, rhs, r, s["nu"])
+                x = alpha * (v - rmatvec(a, s["nu"])) + (1.0 - alpha) * xp
+                xs = alpha * (vs + s["nu"]) + (1.0 - alpha) * s["xps"]
+            else:
+                x = alpha * v + (1.0 - alpha) * xp
+                xs = np.zeros(0)
+            s["x"] = x
+            acc = np.where(s["used"], x + s["lam"] / gamma, 0.0)
+            total = acc if k == 0 else total + acc   # summands added in block order
+            # the slack copies belong to this block alone: consensus, clamp and multiplier at once (:290-307 for one copy, cost 0)
+            t = np.minimum(np.maximum(xs + s["lams"] / gamma, s["slo"]), s["shi"])
+            s["lams"] = s["lams"] + gamma * (xs - t)
+            s["xps"] = t
+        t = np.where(copies > 0, total, xp) - c / gamma
+        t = t / np.maximum(copies, 1.0)
+        xp = np.minimum(np.maximum(t, lb), ub)
+        for s in st:
+            s["lam"] = np.where(s["used"], s["lam"] + gamma * (s["x"] - xp), s["lam"])
+        if iterate_hook is not None:
+            iterate_hook(i)
+    return xp, steps

@@ -16,6 +16,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import ORDER_AUTO
+from .parallel import collective_elapsed
 
 
 def _take_rows(a, rows, sign):
@@ -202,7 +203,7 @@ def chambolle_pock_ppd(
             if niter % nb_iter_plot == 0:
                 state.primal_step()
                 elapsed = time.perf_counter() - start
-                if (max_time is not None) and elapsed > max_time:
+                if (max_time is not None) and collective_elapsed(elapsed) > max_time:  # the same decision on every rank
                     break
                 energy1, energy2, max_violated_equality, max_violated_inequality, max_eq_at_x = state.report()[:5]
                 if a_ineq is None:

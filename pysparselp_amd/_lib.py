@@ -57,6 +57,7 @@ _SIGNATURES = {
     "slp_matrix_chunked_create": (c_vp, [c_i64]),
     "slp_matrix_chunked_append": (c_int, [c_vp, c_vp]),
     "slp_matrix_chunks": (c_i64, [c_vp]),
+    "slp_matrix_product_launches": (c_i64, [c_vp, c_int]),
     "slp_matrix_chunked_expect": (c_int, [c_vp, c_i64]),
     "slp_cp_create": (c_vp, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_cp_create_on": (c_vp, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
@@ -124,6 +125,8 @@ _SIGNATURES = {
     "slp_comm_barrier": (c_int, []),
     "slp_comm_info": (c_int, [c_vp, c_vp]),
     "slp_comm_collectives": (ctypes.c_longlong, []),
+    "slp_comm_timing": (c_int, [c_int]),
+    "slp_comm_timing_read": (c_int, [c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

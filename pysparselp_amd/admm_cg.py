@@ -130,7 +130,7 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
         a, b = precondition_constraints(a, b, alpha=2)
     # under a communicator (parallel.init_comm_from_env): every rank ran the (cheap, deterministic) transforms above on the
     # whole LP and hands over only its block of the standard-form rows; the N unknowns are replicated
-    from .parallel import local_rows
+    from .parallel import collective_elapsed, local_rows
 
     r0, r1, _ = local_rows(a.indptr)
     if (r0, r1) != (0, a.shape[0]):
@@ -148,7 +148,8 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
             if i % nb_iter_plot == 0:
                 state.xstep()
                 elapsed = time.perf_counter() - start
-                if max_time is not None and elapsed > max_time:
+                # (under a communicator the decision is the same on every rank: the max over the ranks' clocks)
+                if max_time is not None and collective_elapsed(elapsed) > max_time:
                     break
                 energy1, max_violated_equality, max_violated_inequality = state.report()[:3]
                 if callback_func is not None:

@@ -283,6 +283,19 @@ __global__ void k_rb_used(i64 n, const i64 *__restrict__ tptr, unsigned char *__
     }
 }
 
+// the same from the column counts (|A|^0)^T 1 -- a matrix whose CSR entries are gone (chunked, released) only has its products
+__global__ void k_rb_used_counts(i64 n, const double *__restrict__ cnt, unsigned char *__restrict__ used, double *__restrict__ copies) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+        const unsigned char u = cnt[j] > 0.0 ? 1 : 0;
+        used[j] = u;
+        copies[j] = (double)u;
+    }
+}
+
+__global__ void k_rb_fill(i64 n, double v, double *__restrict__ out) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) out[j] = v;
+}
+
 // energy terms of this rank's block: part = sum_{used j} 0.5 g d^2 + lambda d  +  the same over the slacks
 __global__ __launch_bounds__(kBlock) void k_rb_energy(i64 n, i64 m, i64 m_eq, const unsigned char *__restrict__ used,
                                                       const double *__restrict__ x, const double *__restrict__ xp,
@@ -523,17 +536,25 @@ slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lo
     SLP_API_PTR({
         SLP_REQUIRE(a && b_upper && c && lb && ub, "slp_blocks_create_on: NULL argument");
         SLP_REQUIRE(m_eq >= 0 && m_eq <= a->a.nrow, "slp_blocks_create_on: m_eq out of range");
-        require_csr(a, "slp_blocks_create_on");
         SLP_REQUIRE(gamma > 0.0, "slp_blocks_create_on: gamma must be positive");
+        // A matrix without CSR entries (a chunked matrix, or one whose CSR was released) serves as long as both products run on
+        // its strip / tall-cell copies: the block ADMM only ever multiplies (BASELINE config 5: eight 5e5 x 5e7 blocks on one
+        // GPU exist as 26 GB of tall cells each, never as 60 GB of CSR).
+        const bool csrless = !a->chunks.empty() || a->csr_released;
+        if (csrless)
+            SLP_REQUIRE(fast_format(a, false) && fast_format(a, true),
+                        "slp_blocks_create_on: the CSR entries of this matrix are gone and it has no strip copies in both orientations");
         auto *s = new slp_blocks();
         try {
             hipStream_t st = ctx().stream;
             const i64 m = a->a.nrow, n = a->a.ncol;
             s->a = a; s->row_block = true; s->m = m; s->N = n; s->P = n; s->m_eq = m_eq; s->gamma = gamma;
             s->distributed = comm_active();
-            build_transpose(a);
-            fast_format(a, false);
-            fast_format(a, true);
+            if (!csrless) {
+                ensure_transposed(a);  // a copy of A^T (tall cells come straight from the CSR of A), else the transposed CSR
+                fast_format(a, false);
+                fast_format(a, true);
+            }
             const size_t sn = (size_t)n, sm = (size_t)m;
             // standard form (tools.py:88-127): b = [b_eq; 0], slack bounds [b_lower, b_upper]; x0 = 0 so xp0 = clamp(0) (:84-86)
             std::vector<double> hb(sm, 0.0), hlo(sm, 0.0), hhi(sm, 0.0), hx(sn), hs(sm, 0.0);
@@ -551,13 +572,25 @@ slp_blocks *slp_blocks_create_on(slp_matrix *a, int64_t m_eq, const double *b_lo
             // all rows inequalities and m >= n: the better-conditioned primal form of the projection (SLP_BLOCKS_PRIMAL=0/1 forces)
             const char *ep = getenv("SLP_BLOCKS_PRIMAL");
             s->primal = m_eq == 0 && m > 0 && (ep ? ep[0] == '1' : m >= n);
-            const size_t sv = std::max(sn, sm);  // the CG vectors serve whichever form is used
+            const size_t sv = s->primal ? sn : sm;  // the CG runs over the rows (dual form) or over the original variables (primal form)
             s->nu.alloc(sm); s->nu.zero(); s->w.alloc(sm); s->q.alloc(sv); s->r.alloc(sv); s->dir.alloc(sv); s->rhs.alloc(sv);
             if (s->primal) { s->xsol.alloc(sn); s->xsol.zero(); s->zero_m.alloc(sm); s->zero_m.zero(); }
             s->vs.alloc(sm); s->xs.alloc(sm); s->xs.zero(); s->lams.alloc(sm); s->lams.zero();
             s->part.alloc(kBlkPartials); s->scal.alloc(B_COUNT); s->scal.zero();
             // which columns this row block uses (a copy exists only for those, :183-185) and in how many ranks' blocks
-            hipLaunchKernelGGL(k_rb_used, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, n, a->at.ptr.p, s->used.p, s->copies.p);
+            const StripJds *ft = a->a.nnz > 0 ? fast_format(a, true) : nullptr;
+            if (!(a->at.ptr.p && a->at.ptr.n == sn + 1) && ft && strip_abs_pow_supported(*ft)) {
+                // no transposed CSR: the column counts are the product (|A|^0)^T 1 over the copy of A^T (exact: sums of ones)
+                DevBuf<double> ones(sm), cnt(sn);
+                hipLaunchKernelGGL(k_rb_fill, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, st, m, 1.0, ones.p);
+                strip_spmv_abs_pow(*ft, 0.0, ones.p, cnt.p);
+                hipLaunchKernelGGL(k_rb_used_counts, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, n, cnt.p, s->used.p, s->copies.p);
+                SLP_HIP(hipGetLastError());
+                SLP_HIP(hipStreamSynchronize(st));  // (ones / cnt go back to the cache)
+            } else {
+                build_transpose(a);
+                hipLaunchKernelGGL(k_rb_used, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, n, a->at.ptr.p, s->used.p, s->copies.p);
+            }
             SLP_HIP(hipGetLastError());
             if (s->distributed) comm_allreduce_dev(s->copies.p, n, 0);
             SLP_HIP(hipStreamSynchronize(st));
@@ -621,6 +654,7 @@ int slp_blocks_set_precond(slp_blocks *s, int jacobi) {
         if (!s->precond) return 0;
         const i64 len = s->primal ? s->N : s->m;
         require_csr(s->a, "slp_blocks_set_precond");
+        if (s->primal) build_transpose(s->a);  // the column norms walk the transposed CSR
         s->dinv.alloc((size_t)len);
         s->z.alloc((size_t)len);
         const CsrDev &c = s->primal ? s->a->at : s->a->a;  // primal: 1 + column norms^2; dual: row norms^2 (+ 1 on inequality rows)

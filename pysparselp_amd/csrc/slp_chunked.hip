@@ -121,4 +121,10 @@ int slp_matrix_chunked_expect(slp_matrix *g, int64_t chunks) {
 
 int64_t slp_matrix_chunks(const slp_matrix *g) { return g ? (int64_t)g->chunks.size() : -1; }
 
+int64_t slp_matrix_product_launches(const slp_matrix *g, int transposed) {
+    if (!g) return -1;
+    (void)transposed;
+    return g->chunks.empty() ? 1 : (int64_t)g->chunks.size();
+}
+
 }  // extern "C"

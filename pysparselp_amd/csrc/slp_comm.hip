@@ -61,13 +61,56 @@ static struct {
     bool pending = false;
 } g;
 
+// Exchange timing (slp_comm_timing): every collective bracketed by a pair of HIP events on the stream it is issued on --
+// recorded only, read after the timed region (slp_comm_timing_read), so nothing synchronises inside it.  Under RCCL the pair
+// brackets the collective's kernel: its duration includes the wait for the slowest peer, which is what an iteration pays.
+static struct {
+    bool on = false;
+    std::vector<hipEvent_t> ev;       // 2 per recorded collective (created once, reused by later sessions)
+    std::vector<double> bytes;        // payload bytes of each recorded collective (per rank)
+    std::vector<int> side;            // issued on the second stream (overlapped with compute)
+    size_t used = 0;
+    long long dropped = 0;            // collectives beyond the ring
+    size_t kMax = 16384;
+} xt_;
+
+struct TimedCollective {
+    hipStream_t st;
+    bool live = false;
+    TimedCollective(hipStream_t stream, i64 count, bool on_side) : st(stream) {
+        if (!xt_.on) return;
+        if (xt_.used >= xt_.kMax) { ++xt_.dropped; return; }
+        if (xt_.ev.size() < 2 * (xt_.used + 1)) {
+            hipEvent_t a = nullptr, b = nullptr;
+            SLP_HIP(hipEventCreate(&a));
+            SLP_HIP(hipEventCreate(&b));
+            xt_.ev.push_back(a);
+            xt_.ev.push_back(b);
+        }
+        if (xt_.bytes.size() <= xt_.used) { xt_.bytes.resize(xt_.used + 1); xt_.side.resize(xt_.used + 1); }
+        xt_.bytes[xt_.used] = (double)count * sizeof(double);
+        xt_.side[xt_.used] = on_side ? 1 : 0;
+        SLP_HIP(hipEventRecord(xt_.ev[2 * xt_.used], st));
+        live = true;
+    }
+    void done() {
+        if (!live) return;
+        live = false;
+        SLP_HIP(hipEventRecord(xt_.ev[2 * xt_.used + 1], st));
+        ++xt_.used;
+    }
+    ~TimedCollective() { if (live) { (void)hipEventRecord(xt_.ev[2 * xt_.used + 1], st); ++xt_.used; } }
+};
+
 // Host transport, asynchronous form (tests: the block groups' overlapped exchange with several ranks on ONE GPU): a worker
 // thread takes the jobs in issue order -- waits for the compute stream to reach the point of the call, copies the buffer out on
 // the second stream, runs the callback, copies the result back -- while the caller goes on enqueueing the next block's
 // projection; comm_join() waits for the queue to drain.  The callback is only ever run by one thread at a time and in the order
 // the all-reduces were issued (synchronous ones drain the queue first), so the ranks' sequences of collectives stay aligned.
 static struct HostWorker {
-    struct Job { double *buf; i64 count; int op; hipEvent_t ready; };
+    struct Job { double *buf; i64 count; int op; hipEvent_t ready; bool timed; };
+    double timed_ms = 0.0, timed_bytes = 0.0, timed_worst = 0.0;   // slp_comm_timing: host clock around a job (copy out, callback, copy back)
+    long long timed_n = 0;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -91,12 +134,14 @@ static void host_worker_main(int device) {
         }
         std::string err;
         if (stage.size() < (size_t)job.count) stage.resize((size_t)job.count);
+        double t_job = 0.0;
         // (capture_mutex: none of these calls while the main thread has a stream capture open, slp_common.h; `ready` was recorded
         // before the job was queued, so waiting for it under the lock cannot wait for the main thread)
         hipError_t e;
         {
             std::lock_guard<std::mutex> no_capture(capture_mutex());
             e = hipEventSynchronize(job.ready);
+            t_job = trace_now();
             if (e == hipSuccess) e = hipMemcpyAsync(stage.data(), job.buf, (size_t)job.count * sizeof(double), hipMemcpyDeviceToHost, g.side);
             if (e == hipSuccess) e = hipStreamSynchronize(g.side);
         }
@@ -111,6 +156,13 @@ static void host_worker_main(int device) {
         {
             std::lock_guard<std::mutex> lk(hw.mu);
             if (!err.empty() && hw.error.empty()) hw.error = err;
+            if (job.timed) {
+                const double ms = (trace_now() - t_job) * 1e3;
+                hw.timed_ms += ms;
+                hw.timed_bytes += (double)job.count * sizeof(double);
+                hw.timed_worst = ms > hw.timed_worst ? ms : hw.timed_worst;
+                ++hw.timed_n;
+            }
             --hw.inflight;
         }
         hw.cv.notify_all();
@@ -194,6 +246,7 @@ void comm_allreduce_dev(double *buf, i64 count, int op) {
         // compute side of one rank of N on one GPU without the host transport's PCIe copies in the way
         static const bool null_comm = [] { const char *e = getenv("SLP_COMM_NULL"); return e && e[0] == '1'; }();
         if (null_comm) return;
+        TimedCollective timed(st, count, false);
         if (hw.running) host_worker_drain(true);  // (collectives reach the callback in issue order)
         if (g.host_buf.size() < (size_t)count) g.host_buf.resize((size_t)count);
         SLP_HIP(hipMemcpyAsync(g.host_buf.data(), buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -201,10 +254,13 @@ void comm_allreduce_dev(double *buf, i64 count, int op) {
         const int rc = g.host_fn(g.host_buf.data(), count, op, g.host_user);
         SLP_REQUIRE(rc == 0, "host all-reduce callback failed");
         SLP_HIP(hipMemcpyAsync(buf, g.host_buf.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
+        timed.done();
         SLP_HIP(hipStreamSynchronize(st));  // host_buf is reused by the next call
         return;
     }
+    TimedCollective timed(st, count, false);
     check(g.all_reduce(buf, buf, (size_t)count, ncclFloat64, op == 1 ? ncclMax : ncclSum, g.comm, st), "ncclAllReduce");
+    timed.done();
 }
 
 int comm_rank() { return g.active ? g.rank : 0; }
@@ -225,7 +281,9 @@ void comm_reduce_scatter_dev(double *buf, i64 cnt) {
     if (cnt <= 0) return;
     if (g.host_fn) { comm_allreduce_dev(buf, cnt * g.nranks, 0); return; }
     ++g.collectives;
+    TimedCollective timed(ctx().stream, cnt * g.nranks, false);
     check(g.reduce_scatter(buf, buf + (i64)g.rank * cnt, (size_t)cnt, ncclFloat64, ncclSum, g.comm, ctx().stream), "ncclReduceScatter");
+    timed.done();
 }
 
 void comm_all_gather_dev(double *buf, i64 cnt) {
@@ -241,7 +299,9 @@ void comm_all_gather_dev(double *buf, i64 cnt) {
         return;
     }
     ++g.collectives;
+    TimedCollective timed(ctx().stream, cnt * g.nranks, false);
     check(g.all_gather(buf + (i64)g.rank * cnt, buf, (size_t)cnt, ncclFloat64, g.comm, ctx().stream), "ncclAllGather");
+    timed.done();
 }
 
 // The same all-reduce, but on the library's second stream: it starts once everything enqueued so far on the compute stream
@@ -269,7 +329,7 @@ void comm_allreduce_dev_async(double *buf, i64 count, int op) {
         }
         {
             std::lock_guard<std::mutex> lk(hw.mu);
-            hw.jobs.push_back({buf, count, op, ev});
+            hw.jobs.push_back({buf, count, op, ev, xt_.on});
             ++hw.inflight;
         }
         hw.cv.notify_all();
@@ -281,7 +341,9 @@ void comm_allreduce_dev_async(double *buf, i64 count, int op) {
     hipEvent_t ev = g.ready[g.next_ready++ % 8];
     SLP_HIP(hipEventRecord(ev, ctx().stream));
     SLP_HIP(hipStreamWaitEvent(g.side, ev, 0));
+    TimedCollective timed(g.side, count, true);
     check(g.all_reduce(buf, buf, (size_t)count, ncclFloat64, op == 1 ? ncclMax : ncclSum, g.comm, g.side), "ncclAllReduce");
+    timed.done();
     g.pending = true;
 }
 
@@ -385,6 +447,49 @@ int slp_comm_allreduce_host(double *v, int64_t count, int op) {
 }
 
 long long slp_comm_collectives(void) { return g.collectives; }
+
+int slp_comm_timing(int on) {
+    SLP_API_INT({
+        if (on) {
+            if (hw.running) host_worker_drain(true);
+            xt_.used = 0; xt_.dropped = 0;
+            std::lock_guard<std::mutex> lk(hw.mu);
+            hw.timed_ms = hw.timed_bytes = hw.timed_worst = 0.0;
+            hw.timed_n = 0;
+        }
+        xt_.on = on != 0;
+    })
+}
+
+int slp_comm_timing_read(double out[6]) {
+    SLP_API_INT({
+        SLP_REQUIRE(out, "slp_comm_timing_read: NULL argument");
+        SLP_REQUIRE(!xt_.on, "slp_comm_timing_read: stop the recording first (slp_comm_timing(0))");
+        if (hw.running) host_worker_drain(true);
+        if (g.side) SLP_HIP(hipStreamSynchronize(g.side));
+        SLP_HIP(hipStreamSynchronize(ctx().stream));
+        double total = 0.0, bytes = 0.0, worst = 0.0, side_ms = 0.0;
+        for (size_t k = 0; k < xt_.used; ++k) {
+            float ms = 0.0f;
+            SLP_HIP(hipEventElapsedTime(&ms, xt_.ev[2 * k], xt_.ev[2 * k + 1]));
+            total += ms;
+            bytes += xt_.bytes[k];
+            if (ms > worst) worst = ms;
+            if (xt_.side[k]) side_ms += ms;
+        }
+        {   // the host transport's asynchronous worker (tests): host clock around each job, all of it beside the compute stream
+            std::lock_guard<std::mutex> lk(hw.mu);
+            total += hw.timed_ms; bytes += hw.timed_bytes; side_ms += hw.timed_ms;
+            worst = hw.timed_worst > worst ? hw.timed_worst : worst;
+        }
+        out[0] = (double)xt_.used + (double)hw.timed_n;       // collectives recorded
+        out[1] = total;                 // ms inside them (event pairs on the stream each was issued on)
+        out[2] = bytes;                 // payload bytes (per rank)
+        out[3] = worst;                 // the slowest single collective, ms
+        out[4] = side_ms;               // of [1]: issued on the second stream, overlapped with compute
+        out[5] = (double)xt_.dropped;    // collectives beyond the ring of event pairs
+    })
+}
 
 int slp_comm_info(int *nranks, int *rank) {
     if (nranks) *nranks = g.active ? g.nranks : 1;

@@ -185,22 +185,28 @@ class ChunkedDeviceMatrix(DeviceMatrix):
     def from_csr(cls, a, chunk_entries=2_500_000_000):
         """A host scipy CSR matrix uploaded in row chunks of about ``chunk_entries`` stored entries (even inner cuts): the way a
         host LP whose CSR does not fit the device twice over gets resident.  Every chunk must qualify for strip copies."""
-        indptr = np.asarray(a.indptr, dtype=np.int64)
-        m = a.shape[0]
-        cuts, r0 = [0], 0
-        while r0 < m:
-            r1 = int(np.searchsorted(indptr, indptr[r0] + chunk_entries, side="right")) - 1
-            r1 = min(m, max(r1, r0 + 2))
-            if r1 < m:
-                r1 &= ~1
-                if m - r1 < 2:
-                    r1 = m
-            cuts.append(r1)
-            r0 = r1
+        cuts = cls.balanced_cuts(a.indptr, chunk_entries)
         g = cls(a.shape[1], expect_chunks=len(cuts) - 1)
         for r0, r1 in zip(cuts, cuts[1:]):
             g.append(DeviceMatrix.from_csr(a[r0:r1]))
         return g
+
+    @staticmethod
+    def balanced_cuts(indptr, chunk_entries):
+        """Row boundaries of k = ceil(nnz / chunk_entries) chunks holding nnz / k stored entries each (even inner cuts).
+        Cutting greedily at ``chunk_entries`` would leave whatever remains for the last chunk -- for an entry count slightly
+        above a multiple of ``chunk_entries`` a sliver that does not qualify for strip copies, refused by the LAST append after
+        every other chunk had been uploaded and converted."""
+        indptr = np.asarray(indptr, dtype=np.int64)
+        m, nnz = indptr.size - 1, int(indptr[-1])
+        k = max(1, -(-nnz // int(chunk_entries)))
+        cuts = [0]
+        for i in range(1, k):
+            r = int(np.searchsorted(indptr, nnz * i // k, side="left")) & ~1
+            if cuts[-1] < r < m:
+                cuts.append(r)
+        cuts.append(m)
+        return cuts
 
     @property
     def chunks(self):

@@ -59,6 +59,20 @@ def comm_world():
     return int(w.value), int(r.value)
 
 
+def collective_elapsed(elapsed):
+    """The elapsed time every rank must compare with ``max_time``: the MAX over the ranks (one small all-reduce) under a
+    communicator, ``elapsed`` itself without one.  The host-API solvers are collective under a communicator (all-reduces inside
+    the x-step, the report and the multiplier step); a stop decision taken from each rank's own clock would let one rank leave
+    the loop while the others wait for it in the next all-reduce forever -- or return different iterates."""
+    if comm_world()[0] <= 1:
+        return elapsed
+    import numpy as np
+
+    v = np.array([float(elapsed)])
+    _lib.check(_lib.lib().slp_comm_allreduce_host(_lib.ptr(v), 1, 1))
+    return float(v[0])
+
+
 def local_rows(indptr, m_eq=0):
     """This rank's share of the stacked constraint rows of a host LP under the active communicator: ``(r0, r1, m_eq_local)`` --
     rows ``r0 .. r1`` (equal stored entries per rank, ``row_block_by_nnz``), of which the first ``m_eq_local`` are equalities
@@ -142,9 +156,15 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300
                     except (ConnectionError, socket.timeout, OSError):
                         continue
                     peer = int.from_bytes(hello[len(hello_tag):], "little")
-                    if hello[:len(hello_tag)] == hello_tag and 0 < peer < world and peer not in served:
-                        conn.sendall(hello_tag + bytes(uid))
-                        served.add(peer)
+                    if hello[:len(hello_tag)] == hello_tag and 0 < peer < world:
+                        # a peer counts as served once it ACKNOWLEDGES the id: a client that gave this connection up meanwhile
+                        # (it retries on a new one) leaves a dead socket whose sendall may well "succeed" -- answer its retry too
+                        try:
+                            conn.sendall(hello_tag + bytes(uid))
+                            if _recv_exact(conn, 2) == b"OK":
+                                served.add(peer)
+                        except (ConnectionError, socket.timeout, OSError):
+                            continue
         return bytes(uid)
     deadline = time.monotonic() + timeout
     while True:
@@ -155,6 +175,7 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300
                     conn.sendall(hello_tag + int(rank).to_bytes(4, "little"))
                     reply = _recv_exact(conn, len(hello_tag) + 128)
                     if reply[:len(hello_tag)] == hello_tag:
+                        conn.sendall(b"OK")
                         return reply[len(hello_tag):]
             except (ConnectionError, socket.timeout, OSError):
                 pass
@@ -185,21 +206,29 @@ class HostTcpAllreduce:
             srv.bind((addr, port))
             srv.listen(self.world)
             srv.settimeout(timeout)
+            # Connections are taken one after the other.  A client gives a connection up after 5 s without the tag echo and
+            # reconnects, so a socket accepted late may already be dead -- and a sendall into it may still "succeed": a
+            # connection is only kept once the client has ACKNOWLEDGED the echo (short timeouts on both reads); a newer
+            # connection from a peer replaces the stored one.
             while len(self.peers) < self.world - 1:
                 conn, _ = srv.accept()
-                conn.settimeout(timeout)
+                conn.settimeout(5.0)
                 try:
                     hello = _recv_exact(conn, len(hello_tag) + 4)
+                    peer = int.from_bytes(hello[len(hello_tag):], "little")
+                    if hello[:len(hello_tag)] != hello_tag or not 0 < peer < self.world:
+                        raise ConnectionError("not a rank of this job")
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.sendall(hello_tag)  # the client checks that it reached ITS job's rank 0
+                    if _recv_exact(conn, 2) != b"OK":
+                        raise ConnectionError("no acknowledgement")
                 except (ConnectionError, socket.timeout, OSError):
                     conn.close()
                     continue
-                peer = int.from_bytes(hello[len(hello_tag):], "little")
-                if hello[:len(hello_tag)] == hello_tag and 0 < peer < self.world and peer not in self.peers:
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    conn.sendall(hello_tag)  # the client checks that it reached ITS job's rank 0
-                    self.peers[peer] = conn
-                else:
-                    conn.close()
+                if peer in self.peers:
+                    self.peers[peer].close()
+                conn.settimeout(timeout)
+                self.peers[peer] = conn
             srv.close()
         else:
             # A listener of ANOTHER job on this port (or a stale rank 0) is treated like a refused connection: close, wait, try
@@ -214,6 +243,7 @@ class HostTcpAllreduce:
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     conn.sendall(hello_tag + self.rank.to_bytes(4, "little"))
                     if _recv_exact(conn, len(hello_tag)) == hello_tag:
+                        conn.sendall(b"OK")
                         break
                 except (OSError, ConnectionError, socket.timeout):
                     pass

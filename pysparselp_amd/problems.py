@@ -76,7 +76,7 @@ def potts_lp(image_size, coef_potts=0.5, coef_mul=500, seed=1):
     return lp, ground_truth, pix, unary
 
 
-def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1):
+def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1, chunked=False, columns=True):
     """Synthetic random LP ``min c.x  s.t.  A x <= b_upper, lb <= x <= ub`` (all inequalities).
 
     Generates rows ``row_offset .. row_offset + rows`` (default: all ``m``) of the
@@ -86,20 +86,24 @@ def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1
     ``chunks > 1``: the same LP as a ``ChunkedDeviceMatrix`` -- the rows are generated, converted and released ``chunks``
     row ranges at a time, so the CSR of the whole matrix never exists (the generator is keyed by the global row: every
     chunking draws the same matrix, and ``b_upper`` is taken from each chunk's CSR exactly as from the whole one).
+    ``chunked=True``: a ``ChunkedDeviceMatrix`` even for one chunk -- the rows are converted into their product copies and the
+    CSR is released at once (a row block of the block-splitting ADMM at BASELINE config 5: only ever multiplied).
+    ``columns=False``: only ``b_upper`` is formed (``feasible_x, c, lb, ub`` are ``None``): the column vectors do not depend on
+    the row range, a caller building several row blocks of one LP asks for them once.
     """
     rows = m if rows is None else rows
     assert 0 <= row_offset and row_offset + rows <= m
-    if chunks <= 1:
+    if chunks <= 1 and not chunked:
         a = DeviceMatrix.random(rows, n, density, seed, row_offset)
-        xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset)
+        xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset, columns=columns)
         return a, xf, c, lb, ub, b
-    cuts = ChunkedDeviceMatrix.cuts(rows, chunks)
+    cuts = ChunkedDeviceMatrix.cuts(rows, max(1, chunks))
     a = ChunkedDeviceMatrix(n, expect_chunks=len(cuts) - 1)
     b = np.empty(rows)
     xf = c = lb = ub = None
     for k, (r0, r1) in enumerate(zip(cuts, cuts[1:])):
         chunk = DeviceMatrix.random(r1 - r0, n, density, seed, row_offset + r0)
-        got = chunk.random_lp_vectors(density, seed, row_offset + r0, columns=(k == 0))
+        got = chunk.random_lp_vectors(density, seed, row_offset + r0, columns=(k == 0 and columns))
         if k == 0:
             xf, c, lb, ub = got[:4]
         b[r0:r1] = got[4]

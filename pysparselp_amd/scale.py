@@ -217,24 +217,80 @@ class DeviceBlocksGroup:
     All rows are inequalities ``b_lower <= a_i x <= b_upper`` (equality rows: give ``m_eq`` leading rows of block 0)."""
 
     def __init__(self, a, cuts, b_upper, c, lb, ub, gamma=0.7, b_lower=None, m_eq=0, cg_tol=1e-13, cg_max_steps=500):
+        cuts = [int(v) for v in cuts]
+        assert cuts[0] == 0 and cuts[-1] == a.shape[0] and all(x <= y for x, y in zip(cuts, cuts[1:]))
+        mats = [a.gather_rows(np.arange(r0, r1, dtype=np.int64)) for r0, r1 in zip(cuts, cuts[1:])]
+        self._link(mats, cuts, b_upper, c, lb, ub, gamma, b_lower, m_eq, cg_tol, cg_max_steps)
+
+    def _link(self, mats, cuts, b_upper, c, lb, ub, gamma, b_lower, m_eq, cg_tol, cg_max_steps):
         import ctypes
 
         self._l = _lib.lib()
-        self.n = a.shape[1]
+        self.n = mats[0].shape[1]
         self.c = _lib.f64(c)
-        cuts = [int(v) for v in cuts]
-        assert cuts[0] == 0 and cuts[-1] == a.shape[0] and all(x <= y for x, y in zip(cuts, cuts[1:]))
+        self._link_args = (cuts, b_upper, c, lb, ub, gamma, b_lower, m_eq, cg_tol, cg_max_steps)
         assert 0 <= m_eq <= cuts[1]
         b_upper = _lib.f64(b_upper)
         b_lower = None if b_lower is None else _lib.f64(b_lower)
-        self.blocks, self._mats = [], []
+        self.blocks, self._mats = [], list(mats)
         for g, (r0, r1) in enumerate(zip(cuts, cuts[1:])):
-            mat = a.gather_rows(np.arange(r0, r1, dtype=np.int64))
-            self._mats.append(mat)
-            self.blocks.append(DeviceBlocks(mat, b_upper[r0:r1], c, lb, ub, gamma=gamma, m_eq=m_eq if g == 0 else 0,
+            self.blocks.append(DeviceBlocks(mats[g], b_upper[r0:r1], c, lb, ub, gamma=gamma, m_eq=m_eq if g == 0 else 0,
                                             b_lower=None if b_lower is None else b_lower[r0:r1], cg_tol=cg_tol, cg_max_steps=cg_max_steps))
         self._handles = (ctypes.c_void_p * len(self.blocks))(*[blk._h for blk in self.blocks])
         _lib.check(self._l.slp_blocks_group_link(self._handles, len(self.blocks)))
+
+    @classmethod
+    def from_generator(cls, n, m, density, seed, cuts, row_offset=0, chunks_per_block=1, gamma=0.7, cg_tol=1e-13, cg_max_steps=500):
+        """The group over rows ``row_offset + cuts[0] .. row_offset + cuts[-1]`` of the synthetic ``m x n`` LP of
+        ``problems.random_lp_on_device`` WITHOUT a resident matrix: every block is generated from its own row range, converted
+        into its product copies for both orientations and its CSR released before the next block is generated
+        (``ChunkedDeviceMatrix`` of ``chunks_per_block`` chunks) -- BASELINE config 5 (5e7 variables, eight blocks of 5e5 rows at
+        1e-4: 2e10 stored entries, 240 GB of CSR per orientation) is resident on ONE GPU as 8 x 26 GB of tall cells.  The solvers'
+        vectors are allocated only after ALL blocks stand, so that a conversion's temporaries never sit beside them.
+        Returns ``(group, feasible_x, c, lb, ub, b_upper)`` (``b_upper`` over this rank's rows, block after block)."""
+        from .problems import random_lp_on_device
+
+        cuts = [int(v) for v in cuts]
+        assert cuts[0] == 0 and all(x < y for x, y in zip(cuts, cuts[1:])) and row_offset + cuts[-1] <= m
+        b = np.empty(cuts[-1])
+        xf = c = lb = ub = None
+        import time
+
+        self = cls.__new__(cls)
+        self.blocks, self._mats = [], []
+        t0 = time.perf_counter()
+        try:
+            for g, (r0, r1) in enumerate(zip(cuts, cuts[1:])):
+                got = random_lp_on_device(n, m, density, seed=seed, row_offset=row_offset + r0, rows=r1 - r0, chunks=chunks_per_block,
+                                          chunked=True, columns=(g == 0))
+                self._mats.append(got[0])
+                if g == 0:
+                    xf, c, lb, ub = got[1:5]
+                b[r0:r1] = got[5]
+            _lib.check(_lib.lib().slp_trim())   # the conversions' cached temporaries go back before the solvers' vectors are taken
+            _lib.check(_lib.lib().slp_synchronize())
+            self.seconds_generating = time.perf_counter() - t0   # generator + conversions (bench.py: setup_breakdown)
+            self._link(self._mats, cuts, b, c, lb, ub, gamma, None, 0, cg_tol, cg_max_steps)
+        except BaseException:
+            self.close()   # (blocks first: they borrow the matrices)
+            raise
+        return self, xf, c, lb, ub, b
+
+    @property
+    def nnz(self):
+        return sum(mat.nnz for mat in self._mats)
+
+    def restart(self):
+        """Fresh solver state (x0 = 0, zero multipliers) over the SAME block matrices: the copies of a 2e10-entry LP are built
+        once, a second run (determinism checks, another tolerance) starts from here."""
+        for blk in self.blocks:
+            blk.close()
+        self.blocks = []
+        self._link(self._mats, *self._link_args)
+
+    def projection_residuals(self):
+        """``(|| rhs - S sol ||, || rhs ||)`` of every block's last projection, operator applied afresh."""
+        return [blk.projection_residual() for blk in self.blocks]
 
     def close(self):
         for blk in getattr(self, "blocks", []):

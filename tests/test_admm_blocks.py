@@ -40,6 +40,30 @@ def test_oracle_reproduces_reference_iterates(case):
     assert float(d[f"{case}_oracle_vs_reference"]) == 0.0
 
 
+@pytest.mark.parametrize("case", ["potts8", "potts50"])
+def test_oracle_matrix_free_form_reproduces_reference_iterates(case):
+    """``oracle.lp_admm_blocks_cg`` -- the CPU restatement of the matrix-free (conjugate-gradient) per-block projection, the form
+    that exists at BASELINE config 5 and what bench.py times as the cpu_baseline of ``--method admm_blocks`` -- against the
+    reference's sparse-LU iterates on the all-inequality fixtures: the CG bar (1e-13 on the residual) leaves <= 1e-9."""
+    d, beq, bineq = _blocks(case)
+    c, a_eq, be, a_ineq, bl, bu, lb, ub = solver_args(load_golden("lp_" + case))
+    assert a_eq is None and not beq
+    a = scipy.sparse.csr_matrix(a_ineq)
+    blocks = [(a[lo:hi + 1], None if bl is None else bl[lo:hi + 1], bu[lo:hi + 1]) for lo, hi in bineq]
+    ref = {int(i): v for i, v in zip(d[f"{case}_it"], d[f"{case}_x"])}
+    for primal in (False, True):
+        got = {}
+        xp, steps = oracle.lp_admm_blocks_cg(c, blocks, lb, ub, nb_iter=max(ref) + 1, primal=primal,
+                                             iterate_hook=lambda i: None)
+        # the hook sees no iterate: re-run up to every recorded iteration is too slow; the final iterate and two early ones
+        for it in sorted(ref)[:2]:
+            got[it], _ = oracle.lp_admm_blocks_cg(c, blocks, lb, ub, nb_iter=it + 1, primal=primal)
+        got[max(ref)] = xp
+        assert steps > 0
+        for it, x in got.items():
+            assert np.max(np.abs(x - ref[it]) / (1 + np.abs(ref[it]))) < 1e-9, (case, primal, it)
+
+
 def test_copies_layout():
     from pysparselp_amd.ADMMBlocks import split_by_blocks
     from pysparselp_amd.tools import CsrArrays

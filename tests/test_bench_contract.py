@@ -15,6 +15,12 @@ ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic")
 CPU = ("value", "unit", "cores", "kind", "sample")
 
 
+def _per_product(r, what):
+    """``bytes`` / ``matrix_copy_bytes`` / ``ms`` of one product: round 5 renamed the ``*_per_launch`` keys, which had always
+    meant per PRODUCT (a chunked matrix takes several launches for one)."""
+    return r.get(what + "_per_product", r.get(what + "_per_launch"))
+
+
 def check_line(d, need_cpu_baseline):
     for key, typ in TOP.items():
         assert key in d, key
@@ -28,9 +34,21 @@ def check_line(d, need_cpu_baseline):
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    if "bytes_per_launch" in r:  # round 2 on: bytes the kernel has to move / time -- a fraction of the peak, never above it
+    if _per_product(r, "bytes") is not None:  # round 2 on: bytes the kernel has to move / time -- a fraction of the peak, never above it
         assert 0.0 < r["frac"] <= 1.0
-        assert r["bytes_per_launch"] >= r["matrix_copy_bytes_per_launch"] > 0
+        assert _per_product(r, "bytes") >= _per_product(r, "matrix_copy_bytes") > 0
+    if "exchange" in d:   # round 5 on: what of a step was exchange
+        e = d["exchange"]
+        for key in ("ms_per_iteration", "collectives_per_iteration", "bytes_per_collective", "algbw_gbps", "compute_ms_per_step",
+                    "collectives_timed", "slowest_collective_ms"):
+            assert key in e, key
+        assert e["collectives_per_iteration"] == d["config"]["collectives_per_iteration"] and "shard_updates" in d["config"]
+        assert 0.0 <= e["ms_per_iteration"] <= d["ms_per_step"] * 1.001 + e["ms_overlapped_per_iteration"]
+        if d["config"]["collectives_per_iteration"] > 0:
+            assert e["collectives_timed"] == round(e["collectives_per_iteration"] * d["steps"]) and e["bytes_per_collective"] > 0
+            assert e["ms_per_iteration"] > 0 and e["algbw_gbps"] > 0 and e["compute_ms_per_step"] < d["ms_per_step"]
+        else:
+            assert e["ms_per_iteration"] == 0 and abs(e["compute_ms_per_step"] - d["ms_per_step"]) < 1e-9
     if need_cpu_baseline:
         c = d["cpu_baseline"]
         for key in CPU:
@@ -47,7 +65,7 @@ def test_committed_bench_lines(name):
     assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic"] > 1e9                # PMC bytes per launch
     if name.startswith("r02"):  # round 2: admissible fraction, the general path in the same line, an honest CPU baseline
         r = d["roofline"]
-        assert r["frac"] <= 1.0 and abs(r["traffic"] / r["bytes_per_launch"] - 1.0) < 0.1          # PMC agrees with the bytes moved
+        assert r["frac"] <= 1.0 and abs(r["traffic"] / _per_product(r, "bytes") - 1.0) < 0.1          # PMC agrees with the bytes moved
         g = r["general_fp64"]
         assert 0.5 < g["spmv"]["frac"] <= 1.0 and 0.5 < g["spmv_transposed"]["frac"] <= 1.0
         assert g["admm_it_per_s"] > 0 and g["chambolle_pock_it_per_s"] > 0
@@ -65,7 +83,7 @@ def test_committed_round3_bench_lines(name):
     if "c4slice" in name:
         assert (d["config"]["n"], d["config"]["m"], d["config"]["density"]) == (10_000_000, 2_500_000, 1e-4)
         assert "k_tall_spmv" in r["kernel"] and r["frac"] >= 0.30          # >= 0.30 of the HBM peak
-        assert r["traffic"] is not None and abs(r["traffic"] / r["bytes_per_launch"] - 1.0) < 0.15
+        assert r["traffic"] is not None and abs(r["traffic"] / _per_product(r, "bytes") - 1.0) < 0.15
     else:
         assert d["steps"] == 500 and d["config"]["n"] == 1_000_000
         assert r["traffic_measured_in_this_run"] is False
@@ -86,7 +104,7 @@ def test_committed_round4_bench_lines(name):
         assert d["config"]["chunks_per_rank"] == 8 and d["config"]["nnz"] > 1.9e10 and "row chunks" in d["config"]["workload"]
         assert "k_tall_spmv" in r["kernel"] and r["frac"] >= 0.40                       # north_star: >= 40 % of the HBM roofline on the SpMV
         assert r.get("launches_per_product", 8) == 8                                      # one launch per row chunk
-        assert r["traffic"] is not None and abs(r["traffic"] / r["bytes_per_launch"] - 1.0) < 0.15   # PMC bytes = the copy, per PRODUCT
+        assert r["traffic"] is not None and abs(r["traffic"] / _per_product(r, "bytes") - 1.0) < 0.15   # PMC bytes = the copy, per PRODUCT
         assert d["device_memory"]["in_use_in_timed_region_gb"] < 288 and d["setup_breakdown"]["peak_device_gb"] < 300
         assert d["cpu_baseline"]["extrapolated"] is True and d["cpu_baseline"]["cores"] == 1
         if "admm" in name:                                                                # the default line carries config 3 too

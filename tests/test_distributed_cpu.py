@@ -354,3 +354,60 @@ def test_rendezvous_rejects_a_rank_of_another_job():
         assert uid == bytes(range(128)) == got["server"] and tag_a is not None
     finally:
         del os.environ["SLP_JOB_TOKEN"]
+
+
+@pytest.mark.timeout(120)
+def test_host_transport_survives_a_connection_its_client_gave_up():
+    """a client abandons a connection after 5 s without the tag echo and reconnects; rank 0, accepting strictly one
+    after the other, may later pick up the ABANDONED socket (whose echo can still "succeed").  A connection only counts once
+    the client has acknowledged the echo, so the dead one is dropped and the live retry is kept -- and rank 0 is not killed by
+    a reset connection."""
+    import ctypes
+    import socket
+    import threading
+
+    from pysparselp_amd import parallel
+
+    port = _free_port()
+    os.environ["SLP_JOB_TOKEN"] = "abandoned-%d" % port
+    try:
+        tag = parallel.MAGIC + parallel.job_token(2)
+        ends = {}
+
+        def serve():
+            ends[0] = parallel.HostTcpAllreduce(0, 2, addr="127.0.0.1", port=port, timeout=60.0)
+
+        # the abandoned connection first: a valid hello of rank 1, then closed before rank 0 ever accepts it
+        import time
+
+        lst = threading.Thread(target=serve)
+        lst.start()
+        ghost = None
+        for _ in range(100):
+            try:
+                ghost = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+                break
+            except OSError:
+                time.sleep(0.05)
+        assert ghost is not None
+        ghost.sendall(tag + (1).to_bytes(4, "little"))
+        ghost.close()
+        ends[1] = parallel.HostTcpAllreduce(1, 2, addr="127.0.0.1", port=port, timeout=60.0)
+        lst.join(timeout=60)
+        assert 0 in ends and len(ends[0].peers) == 1
+        out = {}
+
+        def reduce(rank):
+            arr = np.array([1.0 + rank, 10.0 * (rank + 1)])
+            assert ends[rank]._allreduce(arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 2, 0, None) == 0
+            out[rank] = arr
+
+        th = threading.Thread(target=reduce, args=(0,))
+        th.start()
+        reduce(1)
+        th.join(timeout=30)
+        assert np.array_equal(out[0], [3.0, 30.0]) and np.array_equal(out[1], [3.0, 30.0])
+        for e in ends.values():
+            e.close()
+    finally:
+        del os.environ["SLP_JOB_TOKEN"]

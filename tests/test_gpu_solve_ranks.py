@@ -28,8 +28,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank(rank, world, port, fixture, method, xstep, nb_iter, q):
+def _rank(rank, world, port, fixture, method, xstep, nb_iter, q, max_time=None, slow_clock_rank=-1):
     try:
+        if rank == slow_clock_rank:   # this rank's clock runs at a quarter of the speed: it would cross max_time four reports later
+            import time
+
+            real, t0 = time.perf_counter, time.perf_counter()
+            time.perf_counter = lambda: t0 + 0.25 * (real() - t0)
         sys.path.insert(0, REPO)
         sys.path.insert(0, os.path.join(REPO, "tests"))
         os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
@@ -48,7 +53,7 @@ def _rank(rank, world, port, fixture, method, xstep, nb_iter, q):
         lp = from_golden(d, SparseLP)
         gt = d["c"] * 0.0
         x, _ = lp.solve(method=method, nb_iter=nb_iter, nb_iter_plot=10, ground_truth=gt, ground_truth_indices=np.arange(gt.size),
-                        **({"xstep": xstep} if method == "admm" else {}))
+                        max_time=max_time, **({"xstep": xstep} if method == "admm" else {}))
         out = {"x": np.asarray(x), "collectives": int(lib.slp_comm_collectives())}
         for name in CURVES:
             out[name] = np.asarray(getattr(lp, name), dtype=np.float64)
@@ -61,11 +66,12 @@ def _rank(rank, world, port, fixture, method, xstep, nb_iter, q):
         q.put((rank, {"error": traceback.format_exc() + repr(e)}))
 
 
-def _run(world, fixture, method, xstep, nb_iter):
+def _run(world, fixture, method, xstep, nb_iter, max_time=None, slow_clock_rank=-1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, world, port, fixture, method, xstep, nb_iter, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, fixture, method, xstep, nb_iter, q, max_time, slow_clock_rank))
+             for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -93,6 +99,19 @@ def test_solve_with_two_ranks_on_one_gpu_equals_the_single_process_run(fixture, 
         assert ref.shape == got.shape and ref.size > 0, name
         err = float(np.max(np.abs(got - ref) / (1 + np.abs(ref))))
         assert err <= 1e-9, (name, err)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("method,xstep", [("chambolle_pock_ppd", None), ("admm", "cg")])
+def test_max_time_stops_every_rank_at_the_same_report(method, xstep):
+    """under a communicator the solvers are collective (all-reduces inside the x-step, the report, the multiplier
+    step); ``max_time`` compared with each rank's OWN clock would let one rank leave the loop while the other waits for it in the
+    next all-reduce forever.  The decision is the max over the ranks' clocks (``parallel.collective_elapsed``): with rank 1's
+    clock running at a quarter of the speed both ranks stop at the same report and return the same x (the old form deadlocks
+    here -- the test's timeout would catch it)."""
+    two = _run(2, "lp_sc105", method, xstep, 10 ** 7, max_time=0.5, slow_clock_rank=1)
+    assert np.array_equal(two[0]["itrn_curve"], two[1]["itrn_curve"]) and 1 <= two[0]["itrn_curve"].size < 10 ** 5
+    assert np.array_equal(two[0]["x"], two[1]["x"]) and two[0]["collectives"] == two[1]["collectives"]
 
 
 def test_solve_reaches_the_matrix_free_admm():

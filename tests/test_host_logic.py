@@ -211,3 +211,23 @@ def test_standard_form_sums_duplicate_entries_like_scipy():
         for m in (got, orc):
             assert np.array_equal(ref.indptr, m.indptr) and np.array_equal(ref.indices, m.indices)
             assert np.array_equal(ref.data, m.data)
+
+
+def test_chunk_cuts_are_balanced():
+    """ChunkedDeviceMatrix.from_csr: an entry count slightly above a multiple of the chunk size must not leave a sliver for the
+    last chunk (it would fail the strip-copy minimum on the final append): k = ceil(nnz / chunk) nearly equal chunks,
+    every inner boundary even."""
+    from pysparselp_amd.device import ChunkedDeviceMatrix
+
+    rng = np.random.RandomState(0)
+    lens = rng.randint(0, 40, size=10001)
+    indptr = np.concatenate(([0], np.cumsum(lens)))
+    nnz = int(indptr[-1])
+    for chunk in (nnz // 3 - 5, nnz // 3 + 5, nnz // 7, nnz, 10 * nnz, 37):
+        cuts = ChunkedDeviceMatrix.balanced_cuts(indptr, chunk)
+        k = -(-nnz // chunk)
+        assert cuts[0] == 0 and cuts[-1] == lens.size and all(a < b for a, b in zip(cuts, cuts[1:])) and len(cuts) - 1 <= k
+        assert all(c % 2 == 0 for c in cuts[1:-1])
+        sizes = np.diff(indptr[cuts])
+        if k <= 100:
+            assert sizes.min() >= nnz / k - 80 and sizes.max() <= nnz / k + 80, (chunk, sizes)   # within two rows of the share

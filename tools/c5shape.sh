@@ -6,6 +6,6 @@ for g in 1 4; do
   tail -3 gpurun_out/r03_bench_blocks_c5shape_split_g$g.err
   python -c "
 import json
-d=json.load(open('gpurun_out/r03_bench_blocks_c5shape_split_g$g.json')); r=d['roofline']; print(d['metric'], d['value'], d['ms_per_step'], r['kernel'][:14], r['frac'], r['ms_per_launch'], r['spmv_transposed']['ms_per_launch'], d['setup_seconds'], d['config'].get('cg_steps_per_iteration'), d['device_memory'])
+d=json.load(open('gpurun_out/r03_bench_blocks_c5shape_split_g$g.json')); r=d['roofline']; print(d['metric'], d['value'], d['ms_per_step'], r['kernel'][:14], r['frac'], r['ms_per_product'], r['spmv_transposed']['ms_per_product'], d['setup_seconds'], d['config'].get('cg_steps_per_iteration'), d['device_memory'])
 "
 done

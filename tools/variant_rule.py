@@ -17,8 +17,8 @@ def run(rows, variant):
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-general", "--steps", "20", "--warmup", "3",
                           "--m", str(rows)], capture_output=True, text=True, check=True, env=env).stdout.strip().splitlines()[-1]
     d = json.loads(out)
-    return {"ms_per_step": round(d["ms_per_step"], 4), "Ax_ms": round(d["roofline"]["ms_per_launch"], 4),
-            "ATy_ms": round(d["roofline"]["spmv_transposed"]["ms_per_launch"], 4), "objective": d["objective_after_run"]}
+    return {"ms_per_step": round(d["ms_per_step"], 4), "Ax_ms": round(d["roofline"]["ms_per_product"], 4),
+            "ATy_ms": round(d["roofline"]["spmv_transposed"]["ms_per_product"], 4), "objective": d["objective_after_run"]}
 
 
 res = {}
