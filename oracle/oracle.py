@@ -49,6 +49,8 @@ def _lib():
         lib.orc_normal_matrix.restype = i64
         lib.orc_row_scale_l2.argtypes = [i64, vp, vp, vp]
         lib.orc_csc_rmatvec.argtypes = [i64, vp, vp, vp, vp, vp]
+        lib.orc_csr_rmatvec_acc.argtypes = [i64, i64, vp, vp, vp, vp, vp]
+        lib.orc_csr_rmatvec_acc.restype = i64
         lib.orc_scale_rows_reversed.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.orc_stack_standard_form.argtypes = [i64, i64, i64] + [vp] * 9
         lib.orc_sort_rows.argtypes = [i64, vp, vp, vp]
@@ -161,6 +163,17 @@ def rmatvec(a, y):
         _lib().orc_csc_rmatvec(a.shape[1], _p(cptr), _p(crow), _p(cdata), _p(y), _p(out))
         return out
     _lib().orc_csr_rmatvec(a.shape[0], a.shape[1], _p(a.indptr), _p(a.indices), _p(a.data), _p(y), _p(out))
+    return out
+
+
+def rmatvec_acc(a, y, out):
+    """``out += y * a`` continuing the chains of additions in ``out`` (in place; rows of ``a`` sorted by column): the next row
+    chunk of a stacked matrix -- the result over all chunks is ``rmatvec`` of the stacked matrix bit for bit."""
+    y = _f64(y)
+    assert y.size == a.shape[0] and out.size == a.shape[1] and out.dtype == np.float64 and out.flags.c_contiguous
+    bad = _lib().orc_csr_rmatvec_acc(a.shape[0], a.shape[1], _p(a.indptr), _p(a.indices), _p(a.data), _p(y), _p(out))
+    if bad:
+        raise ValueError(f"rmatvec_acc: row {bad - 1} is not sorted by column")
     return out
 
 

@@ -75,6 +75,38 @@ void orc_csr_rmatvec(i64 nrow, i64 ncol, const i64 *indptr, const i32 *indices,
     }
 }
 
+/* out += y * A, CONTINUING the chains of additions `out` already holds: the form a row-chunked matrix needs -- chunk k of the
+ * stacked rows carries on the column sums chunks 0 .. k-1 left, so that out[j] = ((0 + t_1) + t_2) + ... over ALL rows in
+ * order, exactly what orc_csr_rmatvec computes on the stacked matrix (tests/test_oracle_golden.py).  Threads own column
+ * ranges (a column's chain is walked by one thread, rows in order): the rows must be sorted by column, the range of a
+ * thread inside a row is found by binary search.  Returns 0, or 1 + the first unsorted row. */
+i64 orc_csr_rmatvec_acc(i64 nrow, i64 ncol, const i64 *indptr, const i32 *indices, const double *data, const double *y,
+                        double *out)
+{
+    for (i64 i = 0; i < nrow; ++i)
+        for (i64 k = indptr[i] + 1; k < indptr[i + 1]; ++k)
+            if (indices[k - 1] >= indices[k])
+                return 1 + i;
+    const int nt = g_threads < 1 ? 1 : g_threads;
+#pragma omp parallel num_threads(nt) if (nt > 1)
+    {
+        const int t = omp_get_thread_num(), tt = omp_get_num_threads();
+        const i64 c0 = ncol * t / tt, c1 = ncol * (t + 1) / tt;
+        for (i64 i = 0; i < nrow; ++i) {
+            i64 lo = indptr[i], hi = indptr[i + 1];
+            while (lo < hi) {                       /* first entry of the row with column >= c0 */
+                const i64 mid = (lo + hi) >> 1;
+                if ((i64)indices[mid] < c0) lo = mid + 1;
+                else hi = mid;
+            }
+            const double yi = y[i];
+            for (i64 k = lo; k < indptr[i + 1] && (i64)indices[k] < c1; ++k)
+                out[indices[k]] += data[k] * yi;
+        }
+    }
+    return 0;
+}
+
 /* The same `y * A` from the CSC arrays of A as orc_csr_to_csc builds them (stable: rows increasing inside every
  * column, ties in storage order): out[j] = ((0 + t_1) + t_2) + ... over the column's entries -- exactly the chain
  * of additions orc_csr_rmatvec performs on out[j], so the two agree bit for bit (tests/test_oracle_golden.py).

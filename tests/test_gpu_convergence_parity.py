@@ -1,0 +1,29 @@
+"""Long-horizon parity on current code, trimmed (the full run: tools/convergence_parity.py -> profiles/r05_convergence_parity.json):
+200 iterations of Chambolle-Pock and of the matrix-free ADMM on two 2e7-entry LPs of the benchmark generator -- one that runs
+on LDS strips (dictionary, fp64, CSR kernels in turn), one on tall cells (both item forms) -- against the CPU oracle
+(ChambollePockPPD.py:195-343, ADMM.py:143-268): objective within 1e-6 relative (north_star), worst row violation equal to
+1e-6, Chambolle-Pock iterates bit for bit.  -m gpu."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("shape", ["strips", "tall"])
+def test_two_hundred_iterations_against_the_oracle(shape):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import convergence_parity as cpar
+
+    threads = min(64, os.cpu_count() or 1)
+    rec = cpar.run(shape, (50, 200), (50, 200), threads=threads)
+    obj, vio = cpar.verdict({"shapes": {shape: rec}})
+    assert obj <= 1e-6 and vio <= 1e-6, (obj, vio)
+    for name, fmt in rec["formats"].items():
+        for k, r in fmt["chambolle_pock_ppd"].items():
+            if name != "csr":   # (the CSR kernels spread a 100-entry row over 32 lanes: tolerance parity, the bars above)
+                assert r["bit_identical"], (name, k)     # strips and tall cells: every product is the sequential CSR sum
