@@ -45,6 +45,7 @@ static void refresh_composites(slp_matrix *g) {
             f.tall = f.tall && p->tall;
             first = false;
         }
+        f.fused = f.tall && tall_fuse(f);   // one launch per product when every chunk runs on tall cells of one kind
     }
     g->at.nrow = g->a.ncol;
     g->at.ncol = g->a.nrow;
@@ -83,6 +84,18 @@ int slp_matrix_chunked_append(slp_matrix *g, slp_matrix *c) {
         // sub-vectors of y start at the chunk's first row: the strip kernels stage x with 16-byte loads
         SLP_REQUIRE(g->a.nrow % 2 == 0, "slp_matrix_chunked_append: every chunk but the last must have an even number of rows");
         Phase ph("slp_matrix_chunked_append");
+        // K chunks announced (slp_matrix_chunked_expect): the chunks' tall cells will run in ONE grid (tall_fuse), so this chunk
+        // brings 1 / K of a multiple of the CU count of row blocks instead of a whole multiple -- its row blocks stay as tall
+        // as the LDS allows however finely the rows are chunked (config 4 in 16 chunks: 128 blocks of 9766 rows each, 2048 in
+        // the grid; a whole multiple per chunk would halve the blocks' height and double the per-cell work)
+        if (g->expect_chunks > 1 && !c->tried_fa) {
+            const char *e = getenv("SLP_TALL_FUSE");
+            if (!(e && e[0] == '0')) {
+                i64 a = ctx().num_cu, b = g->expect_chunks;
+                while (b) { const i64 t = a % b; a = b; b = t; }
+                c->tall_block_multiple = ctx().num_cu / a;
+            }
+        }
         // both product copies straight from the chunk's CSR
         const StripJds *f0 = fast_format(c, false), *f1 = fast_format(c, true);
         SLP_REQUIRE(f0 && f1, "slp_matrix_chunked_append: the chunk does not qualify for strip copies in both orientations (too small or "
@@ -123,8 +136,8 @@ int64_t slp_matrix_chunks(const slp_matrix *g) { return g ? (int64_t)g->chunks.s
 
 int64_t slp_matrix_product_launches(const slp_matrix *g, int transposed) {
     if (!g) return -1;
-    (void)transposed;
-    return g->chunks.empty() ? 1 : (int64_t)g->chunks.size();
+    if (g->chunks.empty()) return 1;
+    return (transposed ? g->fat : g->fa).fused ? 1 : (int64_t)g->chunks.size();
 }
 
 }  // extern "C"

@@ -221,7 +221,13 @@ struct TallWg {
     const unsigned int *dir;   // packet headers (8 dwords each)
     const unsigned int *pay;   // payload words
     const double *val;         // fp64 entries (NULL with a value dictionary)
+    const double *dict;        // the stream's value table (NULL: the launch's argument)
     i64 npk;                   // packets, including the 2 x depth that are only ever prefetched
+    i64 row0;                  // where the block's sums go: out[row0 + r], r < nrows
+    i64 x0;                    // first element of x the stream multiplies (a column chunk of a composite copy of A^T), else 0
+    i64 ncol;                  // columns of x the stream sees (range check of the x-tile loads)
+    int nrows;                 // rows of the block
+    int D;                     // entries of the value table
 };
 
 // strip-JDS copy of a CSR matrix for the LDS-tiled SpMV (slp_strip.hip)
@@ -257,6 +263,7 @@ struct StripJds {
     std::vector<const StripJds *> parts;
     std::vector<i64> part_off;        // first row of chunk k inside the chunked matrix
     bool parts_cols = false;          // the copy of A^T: the chunks cut its COLUMNS (x is sliced, the sums of a row continue)
+    bool fused = false;               // tall_wg holds ONE descriptor table over all parts: a product is a single launch (tall_fuse)
 };
 constexpr int kTallRmax = 9984;       // most rows of a tall-cell row block (their running sums: 78 KB of LDS)
 // sorted distinct stored values of a matrix, when there are at most kDictMax of them
@@ -278,8 +285,10 @@ void strip_spmv_abs_pow(const StripJds &f, double pw, const double *x, double *o
 // long rows that are sparse inside every LDS-sized window (slp_tall.hip); transposed: the question / the copy for A^T, taken
 // straight from the CSR of A (no transposed CSR is ever formed)
 bool tall_wanted(i64 nrow, i64 ncol, i64 nnz);
-bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict);
+bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict, i64 block_multiple = 0);
 void tall_spmv(const StripJds &f, const double *x, double *out, int accum);
+bool tall_fuse(StripJds &composite);                                          // one descriptor table over all chunks' copies, if they allow it
+void tall_spmv_fused(const StripJds &composite, const double *x, double *out);  // the whole product of a fused composite in ONE launch
 void tall_spmv_pow(const StripJds &f, double pw, const double *x, double *out, int accum);  // fp64 entries: values |v|^pw * 1.0
 size_t strip_format_bytes(const StripJds &f);   // bytes of the copy a product streams (composites: all chunks)
 
@@ -304,6 +313,7 @@ struct slp_matrix {
     std::vector<slp::i64> chunk_row0;      // first row of every chunk
     slp::DevBuf<double> rowsq;             // a chunk: [2 * rows] the two sums of squares behind the ADMM row scaling (tools.py:272-290)
     slp::i64 expect_chunks = 0;            // slp_matrix_chunked_expect: chunks to come in all (0: unknown, nothing is reserved ahead)
+    slp::i64 tall_block_multiple = 0;      // a chunk about to join a chunked matrix of K chunks: row blocks in multiples of CUs / gcd(CUs, K)
     ~slp_matrix();
 };
 

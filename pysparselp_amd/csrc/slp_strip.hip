@@ -1156,6 +1156,7 @@ static void for_parts(const StripJds &f, F call) {
 
 void strip_spmv(const StripJds &f, const double *x, double *out) {
     if (f.parts.empty()) { strip_spmv_one(f, x, out, 0); return; }
+    if (f.fused) { tall_spmv_fused(f, x, out); return; }   // all chunks' tall cells in one launch
     for_parts(f, [&](const StripJds &g, i64 xo, i64 oo, int accum) { strip_spmv_one(g, x + xo, out + oo, accum); });
 }
 

@@ -15,8 +15,8 @@ constexpr int kTallIdBits = 11, kTallColBits = 12, kTallRowBits = 14;
 constexpr int kTallCellShift = kTallIdBits + kTallColBits + kTallRowBits;  // sort key: cell | row | column | id
 static_assert(kTallBuckets * 32 == 3 * kWave, "k_tall_build scans the (count, bank class) buckets three per lane of one wave");
 static_assert(kTallRmax < (1 << kTallRowBits) && kTallC == (1 << kTallColBits) && kTallDictMax == (1 << kTallIdBits), "tall geometry");
-// LDS of the product kernel: sums + value table + two x-tiles
-static_assert(kTallRmax * 8 + kTallDictMax * 8 + 2 * kTallC * 8 <= 160 * 1024, "tall cells: LDS budget");
+// LDS of the product kernel: sums (+ the scratch cell) + value table + two x-tiles
+static_assert((kTallRmax + 1) * 8 + kTallDictMax * 8 + 2 * kTallC * 8 <= 160 * 1024, "tall cells: LDS budget");
 
 constexpr unsigned int kPktNewCell = 0x80000000u;  // first packet of a cell: barrier, then the other x-tile
 constexpr unsigned int kNoTile = 0x7fffffffu;

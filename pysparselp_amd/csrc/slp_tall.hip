@@ -9,8 +9,10 @@
 // workgroup owns R ~ 10^4 rows (their R running sums live in LDS, 78 KB) and walks strips of 4096 columns (the x-tile,
 // double-buffered, 64 KB of LDS), so that a cell holds ~4000 entries although a row has < 1.
 //
-//   item (5 bytes)  = value id (11 bits) | column inside the strip (12 bits) << 11 | local row (14 bits) << 23
-//                     -- self-describing: no per-row metadata, rows without entries in a cell cost nothing
+//   item (5 bytes)  = value id (11 bits) | column inside the strip (12 bits) << 11 | (local row + 1) (14 bits) << 23
+//                     -- self-describing: no per-row metadata, rows without entries in a cell cost nothing; row field 0 is
+//                     the product kernel's scratch cell: a skip item, and the zero word a lane outside a slot loads, need
+//                     no predicate anywhere
 //   cell            = the items of its non-empty rows, every row handed WHOLE to one of the 1024 lanes (rows sorted by
 //                     their entry count, dealt round by round: lane p takes sorted positions p, p + 1024, ...), so a
 //                     lane's list is its rows' entries in storage order and list lengths never increase with p
@@ -408,15 +410,18 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
                 unsigned int hb0 = 0, hb1 = 0, so = 0;
                 for (int j = 0; j < kTallSlots; ++j) {
                     if ((unsigned)p < wd[j]) {
-                        unsigned int item = DICT ? 0u : 0x80000000u, hib = 0x80u;  // skip item: a lane inside the envelope whose list has ended
+                        // skip item (a lane inside the envelope whose list has ended): row field 0 = the kernel's scratch cell, like
+                        // the zero a load past the buffer descriptor returns for a lane outside the slot
+                        unsigned int item = 0u, hib = 0u;
                         double value = 0.0;
                         if (mypos < npos) {
                             const unsigned long long key = keys[c0 + rstart[myrow] + s];
+                            const unsigned int r1 = myrow + 1u;   // the row field holds the local row + 1
                             if (DICT) {
-                                item = ((unsigned int)key & ((1u << (kTallIdBits + kTallColBits)) - 1)) | ((myrow & 0x1ffu) << 23);
-                                hib = myrow >> 9;
+                                item = ((unsigned int)key & ((1u << (kTallIdBits + kTallColBits)) - 1)) | ((r1 & 0x1ffu) << 23);
+                                hib = r1 >> 9;
                             } else {
-                                item = ((unsigned int)(key >> kTallIdBits) & (kTallC - 1)) | (myrow << kTallColBits);
+                                item = ((unsigned int)(key >> kTallIdBits) & (kTallC - 1)) | (r1 << kTallColBits);
                                 value = svals[c0 + rstart[myrow] + s];
                             }
                             if (++s == mycnt) {
@@ -470,8 +475,10 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
 // keeps the running sums free of bank conflicts) only while the rows with TWO OR MORE entries in the cell fit one per lane --
 // R * P(Poisson(per_cell) >= 2) <= ~900.  Denser matrices get shorter row blocks for that (measured on 2.5e6 x 1e7: density
 // 2e-4 at R = 9766 ran at 1.5 TB/s, 17.5 ms, against 4.2 ms for half the entries at 1e-4).
-static void tall_geometry(i64 nrow, i64 T, double per_cell, int *R_out, int *S_out) {
-    const i64 cus = ctx().num_cu;
+// `block_multiple` (0 = the CU count): the row blocks come in multiples of this -- a row chunk that will run in ONE grid with
+// the other chunks of its chunked matrix (tall_fuse) only has to bring its share of a multiple of the CU count.
+static void tall_geometry(i64 nrow, i64 T, double per_cell, i64 block_multiple, int *R_out, int *S_out) {
+    const i64 cus = block_multiple > 0 ? std::min<i64>(block_multiple, ctx().num_cu) : ctx().num_cu;
     const double p2 = 1.0 - exp(-per_cell) * (1.0 + per_cell);
     const i64 rcap = std::max<i64>(1024, std::min<i64>(kTallRmax, p2 > 0.0 ? (i64)(900.0 / p2) : kTallRmax));
     const char *es = getenv("SLP_TALL_SPLIT");
@@ -517,7 +524,7 @@ static void tall_launch_build(bool write, unsigned V, int R, i64 T, int S, i64 n
 
 // The tall-cell copy of `a` (transposed: of a^T) straight from the CSR of `a`.  Keys are drawn and sorted in passes over ranges
 // of the copy's row blocks (a pass's cells all precede the next pass's: the sorted ranges line up into the sorted whole).
-bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict) {
+bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict, i64 block_multiple) {
     Phase ph(transposed ? "tall_build (A^T from the CSR of A)" : "tall_build");
     hipStream_t st = ctx().stream;
     f = StripJds();
@@ -526,7 +533,7 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     if (ncolF * 8 >= ((i64)1 << 31)) return false;  // x is addressed through a buffer descriptor with 32-bit byte offsets
     const i64 T = (ncolF + kTallC - 1) / kTallC;
     int R = 0, S = 1;
-    tall_geometry(nrowF, T, (double)a.nnz / (double)nrowF / (double)T, &R, &S);
+    tall_geometry(nrowF, T, (double)a.nnz / (double)nrowF / (double)T, transposed ? 0 : block_multiple, &R, &S);
     const i64 B = (nrowF + R - 1) / R, ncell = B * T, V = B * S;  // V workgroups: (row block, strip range)
     unsigned int cellbits = 1;
     while (((i64)1 << cellbits) < ncell) ++cellbits;
@@ -637,10 +644,17 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
                                   reinterpret_cast<TallPkt *>(dir.p), pay.p, vals);
     std::vector<TallWg> wg((size_t)V);
     for (i64 v = 0; v < V; ++v) {
+        const i64 b = v / S;
         wg[(size_t)v].dir = dir.p + hpkt[v] * 8;
         wg[(size_t)v].pay = pay.p + hbase[v];
         wg[(size_t)v].val = vals ? vals + hbase[v] : nullptr;
+        wg[(size_t)v].dict = nullptr;   // (the launch's table: strip_spmv_with_dict swaps it; a fused composite names each chunk's)
         wg[(size_t)v].npk = hpkt[v + 1] - hpkt[v];
+        wg[(size_t)v].row0 = (v % S) * nrowF + b * (i64)R;   // S > 1: into the partial-sum array, one slice per strip range
+        wg[(size_t)v].x0 = 0;
+        wg[(size_t)v].ncol = ncolF;
+        wg[(size_t)v].nrows = (int)std::min<i64>(R, nrowF - b * (i64)R);
+        wg[(size_t)v].D = dict ? dict->D : 0;
     }
     f.tall_wg.upload(wg.data(), wg.size());
     SLP_HIP(hipStreamSynchronize(st));

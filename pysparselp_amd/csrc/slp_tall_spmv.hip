@@ -27,25 +27,37 @@ struct TallRegs {
 // DICT: depth 4 (20 KB of payload per packet); fp64 entries: depth 2 (48 KB per packet, 16 more registers per packet)
 // POW (fp64 entries only): every stored value v enters as |v|^pw * 1.0 -- the sums behind the Chambolle-Pock preconditioners
 // (slp_cp.hip, strip_spmv_abs_pow) over a copy without a value table; the same chain of additions as the CSR walk.
+// A workgroup runs `nseg` packet streams one after the other over ONE set of running sums (descriptor of segment s of workgroup v:
+// wgs[s * gridDim.x + v]): nseg = 1 for a row block of an ordinary copy -- and for the row blocks of ALL chunks of a chunked
+// matrix in one grid (A x in one launch); nseg = the chunks for the copy of A^T of a chunked matrix, where the workgroup of a
+// column block walks chunk 0, 1, ... in order and the column sums simply stay in LDS between them (A^T y in one launch: the chain
+// of additions of the unchunked product, as the chunk-by-chunk launches formed it through `out`).
 template <bool DICT, bool ACC, bool POW = false>
-__global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R, int S, const TallWg *__restrict__ wgs,
-                                                      const double *__restrict__ dict, int D, const double *__restrict__ x,
-                                                      double *__restrict__ out, double pw) {
+__global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__restrict__ wgs, const double *__restrict__ dict_arg,
+                                                      const double *__restrict__ x, double *__restrict__ out, double pw) {
     constexpr int kDepth = DICT ? kTallDepth : 2;
-    __shared__ double acc[kTallRmax];
+    // acc[0] is a scratch cell: the row field of an item is its local row + 1, and whatever is not a lane's item -- a slot
+    // beyond its list (the load past the buffer descriptor returns 0), a skip item -- decodes to row 0, value id 0, column 0
+    // and adds into the scratch cell: no predicate on the stores, none on the sums
+    __shared__ double acc[kTallRmax + 1];
     __shared__ double dv[kTallDictMax];
     __shared__ double xt[2][kTallC];
-    __shared__ double dump;   // where the slots that are not a lane's store (never read)
     const int p = threadIdx.x;
     const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
-    const i64 v = blockIdx.x, b = v / S;  // workgroup v walks the strips of range v % S of row block b
-    // ACC (S == 1): the sums continue from what `out` holds -- a row chunk of a chunked matrix carrying on the column sums of
-    // the chunks before it, the chain of additions of the unchunked product (S > 1: taken in k_tall_combine).  A template
-    // parameter: loads under a run-time condition in front of the pipeline made the compiler wait for vmcnt(0) in the loop.
-    for (int r = p; r < R; r += kTallT) acc[r] = (ACC && S == 1 && b * (i64)R + r < nrow) ? out[b * (i64)R + r] : 0.0;
-    if (DICT)
-        for (int q = p; q < D; q += kTallT) dv[q] = dict[q];
-    const TallWg wg = wgs[v];
+    const int v = blockIdx.x;
+    int cur = 0;
+    TallWg wg = wgs[v];
+    // ACC: the sums continue from what `out` holds -- a row chunk of a chunked matrix carrying on the column sums of the chunks
+    // before it, launch by launch (the strip-range split takes it in k_tall_combine instead: its descriptors point into the
+    // partial-sum array).  A template parameter: loads under a run-time condition in front of the pipeline made the compiler
+    // wait for vmcnt(0) in the loop.
+    for (int r = p; r <= wg.nrows; r += kTallT) acc[r] = (ACC && r > 0) ? out[wg.row0 + r - 1] : 0.0;
+  for (int seg = 0; seg < nseg; ++seg) {
+    if (seg > 0) wg = wgs[(i64)seg * gridDim.x + v];
+    if (DICT) {
+        const double *__restrict__ dsrc = dict_arg ? dict_arg : wg.dict;
+        for (int q = p; q < wg.D; q += kTallT) dv[q] = dsrc[q];
+    }
     // this lane's dword of every header -- through a GLOBAL-address-space pointer: a pointer read from a structure in memory is
     // a generic one to the compiler, its loads become flat_load (complete out of order: every wait a vmcnt(0), the pipeline gone)
 #ifdef SLP_TALL_FLAT  // lab: the generic-pointer form (drains the pipeline at every packet group), for re-measurement
@@ -59,10 +71,9 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
     const __amdgpu_buffer_rsrc_t rs_pay =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(wg.pay), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)(ncol * 8), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x + wg.x0), 0, (int)(wg.ncol * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : wg.val), 0, 0x7fffffff, 0x00020000);
-    int cur = 0;
 
     TallRegs<DICT> regs[kDepth];
     unsigned int hw[2 * kDepth];
@@ -74,6 +85,25 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
             c[2 * i] = v & 0xffffu;
             c[2 * i + 1] = v >> 16;
         }
+    };
+
+    // this lane's two 16-byte pieces of an x-tile (doubles 2p, 2p + 1 of each tile half).  A piece that straddles the end of x
+    // (odd width) may fetch the 8 bytes behind it: every device block carries 16 bytes of slack, and no item names that column
+    auto load_tile = [&](TallRegs<DICT> &g, const unsigned int xo) {
+#ifdef SLP_TALL_X64   // lab: four 8-byte loads (rounds 3-4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)(i & 1) + (i >> 1) * (unsigned int)(kTallC * 4), 0, 0);
+            g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo + (unsigned int)i * (unsigned int)(kTallC * 4), 0, 0);
+            g.x[2 * i] = __hiloint2double((int)v[1], (int)v[0]);
+            g.x[2 * i + 1] = __hiloint2double((int)v[3], (int)v[2]);
+        }
+#endif
     };
 
     auto issue = [&](TallRegs<DICT> &g, unsigned int h) {
@@ -107,11 +137,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
         // lane pair collided -- the tile write was the largest single item of the kernel's ablation, 0.9 of 4.1 ms)
         const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
 #endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)(i & 1) + (i >> 1) * (unsigned int)(kTallC * 4), 0, 0);
-            g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
-        }
+        load_tile(g, xo);
     };
 
 #ifndef SLP_TALL_WHOLE_ISSUE   // (lab: SLP_TALL_WHOLE_ISSUE = all loads of a packet behind all of its items, as in rounds 3-4)
@@ -141,19 +167,14 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
         if (part == 1) {
             const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
             const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)(i & 1) + (i >> 1) * (unsigned int)(kTallC * 4), 0, 0);
-                g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
-            }
+            load_tile(g, xo);
         }
     };
 #endif
 
     auto consume = [&](const TallRegs<DICT> &g, unsigned int h, auto &&between) {
         const unsigned int xw = (unsigned int)__builtin_amdgcn_readlane((int)h, 1);
-        unsigned int c[kTallSlots];
-        widths(h, c);
+        const unsigned int c4 = (unsigned int)__builtin_amdgcn_readlane((int)h, 4) & 0xffffu;   // lanes with a fifth item
         if (xw & kPktNewCell) {
             // sums of the previous cell (other lanes owned these rows there) and the x-tile: LDS only, loads stay in flight
 #if !defined(SLP_TALL_ABL) || (SLP_TALL_ABL != 4 && SLP_TALL_ABL != 7)
@@ -192,10 +213,10 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
                 w[k] = g.lo[k0 + k];
                 if (DICT) {
                     hb[k] = (g.hi[DICT ? (k0 >> 2) : 0] >> (8 * k)) & 0xffu;
-                    row[k] = (w[k] >> 23) | ((hb[k] & 0x1fu) << 9);
+                    row[k] = (w[k] >> 23) | (hb[k] << 9);          // local row + 1; 0 = the scratch cell
                 } else {
-                    hb[k] = (w[k] >> 24) & 0x80u;   // bit 31: skip item
-                    row[k] = (w[k] >> kTallColBits) & ((1u << kTallRowBits) - 1);
+                    hb[k] = 0;
+                    row[k] = w[k] >> kTallColBits;
                 }
             }
 #if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)   // lab: no running-sum traffic
@@ -218,33 +239,22 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
 #pragma unroll
             for (int k = 1; k < 4; ++k) t[k] = ((row[k] == row[k - 1]) ? t[k - 1] : ar[k]) + pr[k];
 #if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)
-            if ((unsigned)p < c[k0 + 3] && !(hb[3] & 0x80u)) acc[p] = ((t[0] + t[1]) + t[2]) + t[3];   // one store per group keeps the work alive
+            acc[p] = ((t[0] + t[1]) + t[2]) + t[3];   // one store per group keeps the work alive
 #else
-#ifdef SLP_TALL_BRANCHY_STORES   // lab: the stores of rounds 3-4 -- each under its own exec mask, i.e. eight small basic blocks per packet
+            // Unconditional stores, no predicate at all: what is not this lane's item lands in the scratch cell acc[0] by its own
+            // decoding -- a packet's items stay ONE basic block, which the instruction scheduler may interleave with the loads of
+            // the packets ahead (rounds 3-4: a branch, then a select, per store: 3 vector instructions per item more)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((unsigned)p < c[k0 + k] && !(hb[k] & 0x80u)) acc[row[k]] = t[k];
-#else
-            // Unconditional stores: a slot that is not this lane's stores into a scratch cell instead of being skipped under an exec
-            // mask -- a packet's items stay ONE basic block, which the instruction scheduler may interleave with the loads of the
-            // packets ahead (with a branch around every store it could not move anything past them).
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double *dst = ((unsigned)p < c[k0 + k] && !(hb[k] & 0x80u)) ? &acc[row[k]] : &dump;
-                *dst = t[k];
-            }
-#endif
+            for (int k = 0; k < 4; ++k) acc[row[k]] = t[k];
 #endif
         };
 #ifndef SLP_TALL_WHOLE_ISSUE
         group(0);   // (a wave without items -- nearly never -- reads cell 0 of the arrays and stores into the scratch cell)
         between();
-        if (wbase < c[4]) group(4);
+        if (wbase < c4) group(4);
 #else
-        if (wbase < c[0]) {
-            group(0);
-            if (wbase < c[4]) group(4);
-        }
+        group(0);
+        if (wbase < c4) group(4);
         between();
 #endif
         // The x-tile of the NEXT cell goes into the other buffer AFTER this packet's items (it only has to be there by the next
@@ -274,11 +284,10 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(i64 nrow, i64 ncol, int R,
             hw[u] = hd[(i64)(jj + u + 2 * kDepth) * 8];                     // header of packet jj + u + 2 depth
         }
     }
-    __syncthreads();
-    for (int r = p; r < R; r += kTallT) {
-        const i64 row = b * (i64)R + r;
-        if (row < nrow) out[(v % S) * nrow + row] = acc[r];  // (S > 1: partial sums of this strip range, added up in range order)
-    }
+    __syncthreads();   // (every wave is done with this segment's tiles and value table)
+  }
+    // (S > 1: row0 points into the partial-sum array -- the sums of this strip range, added up in range order by k_tall_combine)
+    for (int r = p; r < wg.nrows; r += kTallT) out[wg.row0 + r] = acc[r + 1];
 }
 
 
@@ -294,9 +303,9 @@ void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
     double *dst = f.S > 1 ? f.part.p : out;
     const unsigned grid = (unsigned)(f.B * f.S);
     const bool acc = accum && f.S == 1;
-#define SLP_TALL_LAUNCH(DICT, ACC)                                                                                                   \
-    hipLaunchKernelGGL((k_tall_spmv<DICT, ACC>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S, f.tall_wg.p, \
-                       DICT ? f.dict : (const double *)nullptr, DICT ? f.D : 0, x, dst, 0.0)
+#define SLP_TALL_LAUNCH(DICT, ACC)                                                                                        \
+    hipLaunchKernelGGL((k_tall_spmv<DICT, ACC>), dim3(grid), dim3(kTallT), 0, ctx().stream, 1, f.tall_wg.p,               \
+                       DICT ? f.dict : (const double *)nullptr, x, dst, 0.0)
     if (f.D > 0) { if (acc) SLP_TALL_LAUNCH(true, true); else SLP_TALL_LAUNCH(true, false); }
     else { if (acc) SLP_TALL_LAUNCH(false, true); else SLP_TALL_LAUNCH(false, false); }
 #undef SLP_TALL_LAUNCH
@@ -305,17 +314,59 @@ void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
     SLP_HIP(hipGetLastError());
 }
 
+// A composite of tall-cell copies (the chunks of a chunked matrix) in ONE launch: the descriptor table tall_fuse() laid out.
+// Rows orientation: a grid over the row blocks of all chunks (2048 workgroups drained by 256 compute units: no launch ends at
+// its slowest workgroup eight times per product).  Columns orientation: one workgroup per column block walks the chunks in
+// order, the column sums stay in LDS (no hand-over of the sums through `out` between launches).
+void tall_spmv_fused(const StripJds &f, const double *x, double *out) {
+    const int nseg = f.parts_cols ? (int)f.parts.size() : 1;
+    const unsigned grid = (unsigned)(f.tall_wg.n / (size_t)nseg);
+    if (f.D > 0)
+        hipLaunchKernelGGL((k_tall_spmv<true, false>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, f.tall_wg.p, (const double *)nullptr, x, out, 0.0);
+    else
+        hipLaunchKernelGGL((k_tall_spmv<false, false>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, f.tall_wg.p, (const double *)nullptr, x, out, 0.0);
+    SLP_HIP(hipGetLastError());
+}
+
+// The fused descriptor table of a composite whose parts are all tall-cell copies of one kind (all with a dictionary or all
+// without, no strip-range split; columns orientation: the same row blocks in every chunk).  False: the composite keeps its
+// chunk-by-chunk launches.
+bool tall_fuse(StripJds &f) {
+    f.tall_wg.release();
+    const char *e = getenv("SLP_TALL_FUSE");
+    if (e && e[0] == '0') return false;
+    if (f.parts.empty()) return false;
+    const StripJds &f0 = *f.parts[0];
+    for (const StripJds *g : f.parts)
+        if (!g->ok || !g->tall || g->S != 1 || (g->D > 0) != (f0.D > 0) || (f.parts_cols && (g->B != f0.B || g->tall_R != f0.tall_R || g->nrow != f0.nrow)))
+            return false;
+    std::vector<TallWg> all;
+    for (size_t k = 0; k < f.parts.size(); ++k) {
+        const StripJds &g = *f.parts[k];
+        std::vector<TallWg> wg((size_t)g.B);
+        SLP_HIP(hipMemcpy(wg.data(), g.tall_wg.p, wg.size() * sizeof(TallWg), hipMemcpyDeviceToHost));
+        for (TallWg &w : wg) {
+            w.dict = g.dict;                                   // every chunk has a value table of its own
+            if (f.parts_cols) w.x0 = f.part_off[k];            // the chunk multiplies its slice of x ...
+            else w.row0 += f.part_off[k];                      // ... or writes its own rows
+            all.push_back(w);
+        }
+    }
+    f.tall_wg.upload(all.data(), all.size());
+    return true;
+}
+
 // out = |A|^pw x over a tall-cell copy with fp64 entries (strip_spmv_abs_pow)
 void tall_spmv_pow(const StripJds &f, double pw, const double *x, double *out, int accum) {
     SLP_REQUIRE(f.ok && f.tall && f.D == 0, "tall_spmv_pow: not a tall-cell copy with fp64 entries");
     double *dst = f.S > 1 ? f.part.p : out;
     const unsigned grid = (unsigned)(f.B * f.S);
     if (accum && f.S == 1)
-        hipLaunchKernelGGL((k_tall_spmv<false, true, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S,
-                           f.tall_wg.p, (const double *)nullptr, 0, x, dst, pw);
+        hipLaunchKernelGGL((k_tall_spmv<false, true, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, 1, f.tall_wg.p,
+                           (const double *)nullptr, x, dst, pw);
     else
-        hipLaunchKernelGGL((k_tall_spmv<false, false, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, f.nrow, f.ncol, f.tall_R, f.S,
-                           f.tall_wg.p, (const double *)nullptr, 0, x, dst, pw);
+        hipLaunchKernelGGL((k_tall_spmv<false, false, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, 1, f.tall_wg.p,
+                           (const double *)nullptr, x, dst, pw);
     if (f.S > 1)
         hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());

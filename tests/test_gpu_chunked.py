@@ -79,6 +79,31 @@ def test_chunked_products_equal_the_unchunked_ones_and_the_oracle_bit_for_bit(ta
 
 
 @pytest.mark.parametrize("chunks", [3, 8])
+def test_one_launch_per_product_equals_the_chunk_by_chunk_launches(tall_reference, chunks, monkeypatch):
+    """Round 5: when every chunk runs on tall cells the product of a chunked matrix is ONE launch -- ``A x``: a grid over the
+    row blocks of all chunks; ``A^T y``: one workgroup per column block walks the chunks in order, the column sums stay in LDS
+    (csrc/slp_tall_spmv.hip ``tall_spmv_fused``).  ``SLP_TALL_FUSE=0`` keeps the round-4 form (a launch per chunk, the sums
+    handed over through the output vector): the same bits either way, and the unchunked product's."""
+    ref = tall_reference
+    lib = ref["a"]._l
+    got = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SLP_TALL_FUSE", fuse)
+        a = _lp(TALL, chunks)[0]
+        try:
+            launches = (int(lib.slp_matrix_product_launches(a._h, 0)), int(lib.slp_matrix_product_launches(a._h, 1)))
+            assert launches == ((1, 1) if fuse == "1" else (chunks, chunks))
+            got[fuse] = (a.matvec(ref["x"]), a.rmatvec(ref["y"]), a.rmatvec(ref["y"]), a.abs_pow_matvec(ref["x"], 2.0),
+                         a.abs_pow_matvec(ref["y"], 1.0, transposed=True))
+        finally:
+            a.close()
+    for u, w in zip(got["1"], got["0"]):
+        assert np.array_equal(u, w)
+    assert np.array_equal(got["1"][0], ref["ax"]) and np.array_equal(got["1"][1], ref["aty"]) and np.array_equal(got["1"][2], ref["aty"])
+    assert int(lib.slp_matrix_product_launches(ref["a"]._h, 0)) == 1
+
+
+@pytest.mark.parametrize("chunks", [3, 8])
 def test_chunked_solvers_equal_the_unchunked_ones_and_the_oracle(tall_reference, chunks):
     from pysparselp_amd.admm_cg import DeviceADMM
     from pysparselp_amd.scale import DeviceCP
