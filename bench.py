@@ -85,7 +85,12 @@ CONFIG_BLOCKS = {"c5": 8}   # row blocks of the whole LP (admm_blocks)
 PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: (("r04_tall_slice_pmc_hbm.json", "r03_tall_slice_pmc_hbm.json"), "slp::k_tall_spmv")},
                       (10_000_000, 20_000_000, 1e-4): {6: (("r05_c4_pmc_hbm.json", "r04_c4_pmc_hbm.json"), "slp::k_tall_spmv")},
                       (50_000_000, 4_000_000, 1e-4): {6: (("r05_c5_pmc_hbm.json", "r04_c5shape_pmc_hbm.json"), "slp::k_tall_spmv")}}
-CHUNK_ENTRIES = 2.6e9   # a chunk's CSR (12 B per entry) + its conversion temporaries must fit beside the copies already built
+# A chunk's CSR (12 B per entry) + its conversion temporaries (sorted keys 8 B, pass scratch) sit beside the copies already built:
+# at 1.3e9 entries per chunk (config 4: 16 chunks on one GPU) the set-up peaks at 252 of the 309 GB instead of 280 with 8 chunks.
+# Since round 5 the chunking no longer shows in the products: all chunks' tall cells run in ONE launch per product (a chunk brings
+# its share of a multiple of the CU count of row blocks, slp_matrix_chunked_expect), measured 9.52-9.54 it/s with 16 chunks
+# against 9.57 with 8 on one box (profiles/r05_c4_chunks_16_vs_8.txt).
+CHUNK_ENTRIES = 1.3e9
 
 
 def parse():
@@ -238,6 +243,18 @@ def cpu_baseline(args, method):
         "sample_setup_seconds": setup_s,
         "host_cores_present": os.cpu_count(),
     }
+    if (args.n, args.m, args.density) == CONFIGS["c4"]:
+        # is the row-sample extrapolation valid at n = 1e7?  tools/cpu_sample_scaling.py: the same measurement on 1 %, 2 %, 5 % of the rows
+        try:
+            rec = json.load(open(os.path.join(REPO, "profiles", "r05_cpu_sample_scaling_c4.json")))
+            key = "admm" if method == "admm" else "chambolle_pock_ppd"
+            out["sample_validation"] = {
+                "source": "profiles/r05_cpu_sample_scaling_c4.json",
+                "what": "the same oracle timing on 1 % / 2 % / 5 % of the rows at n = 1e7 (1 thread): full-size rates extrapolated from each",
+                "extrapolated_full_size_it_per_s": {str(r["fraction"]): r[key]["extrapolated_full_size_it_per_s"] for r in rec["samples"]},
+                "spread": rec[key + "_extrapolations_spread"]}
+        except Exception:  # optional evidence, never a reason to lose the bench line
+            pass
     if (args.n, args.m, args.density) == CONFIGS["c3"]:
         for name in ("r03_cpu_full_c3.json", "r02_cpu_full_c3.json"):  # (r02: Chambolle-Pock only)
             full = os.path.join(REPO, "profiles", name)
