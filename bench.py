@@ -48,7 +48,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # the HIP library first: bench never needs torch on one GPU
 from pysparselp_amd import _lib  # noqa: E402
-from pysparselp_amd.device import ChunkedDeviceMatrix, DeviceMatrix  # noqa: E402
+from pysparselp_amd.device import DeviceMatrix  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a plain copy achieves)
 
@@ -82,9 +82,11 @@ PMC_FILES = {   # newest record first
 CONFIGS = {"c3": (1_000_000, 2_000_000, 1e-3), "c4slice": (10_000_000, 2_500_000, 1e-4), "c4": (10_000_000, 20_000_000, 1e-4),
            "c5": (50_000_000, 4_000_000, 1e-4)}
 CONFIG_BLOCKS = {"c5": 8}   # row blocks of the whole LP (admm_blocks)
-PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: (("r04_tall_slice_pmc_hbm.json", "r03_tall_slice_pmc_hbm.json"), "slp::k_tall_spmv")},
-                      (10_000_000, 20_000_000, 1e-4): {6: (("r05_c4_pmc_hbm.json", "r04_c4_pmc_hbm.json"), "slp::k_tall_spmv")},
-                      (50_000_000, 4_000_000, 1e-4): {6: (("r05_c5_pmc_hbm.json", "r04_c5shape_pmc_hbm.json"), "slp::k_tall_spmv")}}
+# (record, launches of the recorded kernel that make ONE product: round 4 ran a launch per row chunk, round 5 runs one per product)
+PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: ((("r05_tall_slice_pmc_hbm.json", 1), ("r04_tall_slice_pmc_hbm.json", 1), ("r03_tall_slice_pmc_hbm.json", 1)),
+                                                          "slp::k_tall_spmv")},
+                      (10_000_000, 20_000_000, 1e-4): {6: ((("r05_c4_pmc_hbm.json", 1), ("r04_c4_pmc_hbm.json", 8)), "slp::k_tall_spmv")},
+                      (50_000_000, 4_000_000, 1e-4): {6: ((("r05_c5_pmc_hbm.json", 1), ("r04_c5shape_pmc_hbm.json", 1)), "slp::k_tall_spmv")}}
 # A chunk's CSR (12 B per entry) + its conversion temporaries (sorted keys 8 B, pass scratch) sit beside the copies already built:
 # at 1.3e9 entries per chunk (config 4: 16 chunks on one GPU) the set-up peaks at 252 of the 309 GB instead of 280 with 8 chunks.
 # Since round 5 the chunking no longer shows in the products: all chunks' tall cells run in ONE launch per product (a chunk brings
@@ -155,17 +157,18 @@ def spmv_bytes(nnz, rows, cols):
 
 
 def pmc_traffic(kernel_id, shape):
-    """(HBM bytes per launch from the committed rocprofv3 PMC summary of this workload, its path) or (None, None)."""
+    """(HBM bytes per PRODUCT from the committed rocprofv3 PMC summary of this workload, its path) or (None, None)."""
     table = PMC_FILES if shape == (1_000_000, 2_000_000, 1e-3) else PMC_FILES_BY_SHAPE.get(shape, {})
     if kernel_id not in table:
         return None, None
     names, kern = table[kernel_id]
     for name in names:
+        name, launches = name if isinstance(name, tuple) else (name, 1)
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
             for full, k in json.load(open(path))["kernels"].items():
                 if full.startswith(kern):
-                    return k["hbm_bytes_per_launch_corrected"], "profiles/" + name
+                    return k["hbm_bytes_per_launch_corrected"] * launches, "profiles/" + name
     return None, None
 
 
@@ -180,8 +183,6 @@ def spmv_block(lib, a, transposed, shape, reps=5):
     alg = spmv_bytes(a.nnz, rows, cols)
     traffic, src = pmc_traffic(which, shape) if not transposed else (None, None)
     launches = max(1, int(lib.slp_matrix_product_launches(a._h, int(transposed))))
-    if traffic is not None:
-        traffic *= max(1, int(lib.slp_matrix_chunks(a._h)))   # the PMC summary is per chunk-sized launch
     out = {
         "kernel": KERNEL_NAMES.get(which, "?"),
         "achieved": moved / (ms * 1e-3) / 1e9,
@@ -630,19 +631,22 @@ def run_workload(lib, args, rank, world, distributed):
             roofline["general_fp64"] = general_block(lib, args, a, b, c, lb, ub, shape)
         if world == 1 and not args.no_general and args.format == 0 and which == 6 and args.method != "admm_blocks" and chunks > 1:
             # The metric's LP with ARBITRARY coefficients: fp64 entries are 12.4 B per stored entry as tall cells -- both
-            # orientations of all chunks would be 2.4 x the 5.2 B dictionary copies and do not fit one GPU.  What one GPU holds
-            # of it is measured instead: ONE row chunk (the per-rank share of `chunks` GPUs) with the dictionary ruled out.
+            # orientations of the whole LP would be 2.4 x the 5.2 B dictionary copies (509 GB) and do not fit one GPU.  What one
+            # GPU holds of it is measured instead: the first EIGHTH of the rows (the row block of one of 8 ranks = --config
+            # c4slice) with the dictionary ruled out.
             a.close()
             _lib.check(lib.slp_trim())
-            cuts = ChunkedDeviceMatrix.cuts(rows, chunks)
-            a = DeviceMatrix.random(cuts[1] - cuts[0], args.n, args.density, args.seed, r0)
-            share = general_block(lib, args, a, b[:cuts[1] - cuts[0]], c, lb, ub, shape)
-            fp64_bytes = 2.0 * share["spmv"]["matrix_copy_bytes_per_product"] * chunks
-            share.update({"resident_on_one_gpu": False, "share_of_rows": (cuts[1] - cuts[0]) / rows,
+            part = (rows // 8) & ~1
+            a = DeviceMatrix.random(part, args.n, args.density, args.seed, r0)
+            share = general_block(lib, args, a, b[:part], c, lb, ub, shape)
+            fp64_bytes = share["spmv"]["matrix_copy_bytes_per_product"] + share["spmv_transposed"]["matrix_copy_bytes_per_product"]
+            fp64_bytes *= rows / part
+            share.update({"resident_on_one_gpu": False, "share_of_rows": part / rows,
                           "fp64_copies_of_the_whole_lp_gb": fp64_bytes / 1e9,
                           "min_gpus": int(np.ceil(fp64_bytes / (0.9 * mem_total_bytes(lib)))),
-                          "note": f"measured on the first of {chunks} row chunks ({cuts[1] - cuts[0]} rows, the row block of one of {chunks} "
-                                  "ranks); rates of the whole LP on that many GPUs = these per-rank rates (plus the exchange)"})
+                          "note": f"measured on the first eighth of the rows ({part} rows: the row block of one of 8 ranks); the whole LP "
+                                  "with fp64 entries needs min_gpus GPUs, where a rank's rates are these per-share rates scaled by its "
+                                  "share of the rows (plus the exchange)"})
             roofline["general_fp64"] = share
         if world == 1 and not args.no_cpu_baseline:
             a.close()

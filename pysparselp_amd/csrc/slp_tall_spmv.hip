@@ -197,7 +197,17 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
                 *reinterpret_cast<double2 *>(dst + kTallC / 2) = make_double2(g.x[2], g.x[3]);
             }
         };
-#ifdef SLP_TALL_WRITE_FIRST   // lab: the order of rounds 3-4a -- every wave stores its share of the tile right behind the barrier
+        // WHERE the wave stores its share of the NEXT cell's x-tile (it only has to be there by the next cell's barrier; lab:
+        // -DSLP_TALL_STAGE=0..3).  Round 5, with the predicate-free item code: right behind the barrier (0) 3.28-3.29 ms on the
+        // 2.5e6 x 1e7 slice; behind the first four items (1) 3.74-3.77; between the two item groups' loads (2) 3.44-3.46; behind all
+        // of the packet's items (3) 3.44 (profiles/r05_tall_stage_position.log).  Round 4's kernel -- a select and a compare
+        // per store -- had it the other way round (behind the items 3.92 against 3.99 behind the barrier: there every wave's
+        // gathers queued behind 32 KB of stores): with the shorter item code the stores are out of the way before the first
+        // gathers are ready to issue, and they no longer sit between a packet's items and the next packet's.
+#ifndef SLP_TALL_STAGE
+#define SLP_TALL_STAGE 0
+#endif
+#if SLP_TALL_STAGE == 0
         stage_tile();
 #endif
         const double *__restrict__ tile = xt[cur];
@@ -212,8 +222,13 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
             for (int k = 0; k < 4; ++k) {
                 w[k] = g.lo[k0 + k];
                 if (DICT) {
+#if defined(SLP_TALL_ABL) && SLP_TALL_ABL == 9   // lab (wrong results): what a 4-byte item would cost -- no fifth byte
+                    hb[k] = 0;
+                    row[k] = (w[k] >> 23) | ((unsigned)(p & 7) << 9);
+#else
                     hb[k] = (g.hi[DICT ? (k0 >> 2) : 0] >> (8 * k)) & 0xffu;
                     row[k] = (w[k] >> 23) | (hb[k] << 9);          // local row + 1; 0 = the scratch cell
+#endif
                 } else {
                     hb[k] = 0;
                     row[k] = w[k] >> kTallColBits;
@@ -236,8 +251,13 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
                              : (POW ? abs_pow(g.val[DICT ? 0 : k0 + k], pw) * 1.0 : g.val[DICT ? 0 : k0 + k]) * tile[w[k] & (kTallC - 1)];
 #endif
             t[0] = ar[0] + pr[0];
+#if defined(SLP_TALL_ABL) && SLP_TALL_ABL == 8   // lab (wrong results): no carry between a lane's items of one row
+#pragma unroll
+            for (int k = 1; k < 4; ++k) t[k] = ar[k] + pr[k];
+#else
 #pragma unroll
             for (int k = 1; k < 4; ++k) t[k] = ((row[k] == row[k - 1]) ? t[k - 1] : ar[k]) + pr[k];
+#endif
 #if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)
             acc[p] = ((t[0] + t[1]) + t[2]) + t[3];   // one store per group keeps the work alive
 #else
@@ -250,17 +270,20 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
         };
 #ifndef SLP_TALL_WHOLE_ISSUE
         group(0);   // (a wave without items -- nearly never -- reads cell 0 of the arrays and stores into the scratch cell)
+#if SLP_TALL_STAGE == 1
+        stage_tile();
+#endif
         between();
+#if SLP_TALL_STAGE == 2
+        stage_tile();
+#endif
         if (wbase < c4) group(4);
 #else
         group(0);
         if (wbase < c4) group(4);
         between();
 #endif
-        // The x-tile of the NEXT cell goes into the other buffer AFTER this packet's items (it only has to be there by the next
-        // cell's barrier): right behind the barrier all 16 waves would store at once and every wave's gathers would queue behind
-        // 32 KB of stores; behind the items the waves' stores spread over the cell.
-#ifndef SLP_TALL_WRITE_FIRST
+#if SLP_TALL_STAGE == 3
         stage_tile();
 #endif
     };
