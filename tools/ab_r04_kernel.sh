@@ -17,8 +17,8 @@ except Exception as e:
 PY
 }
 for rep in 1 2; do
-    run c3_r4_$rep r4kernel --config c3
-    run c3_new_$rep "" --config c3
+    [ -n "$AB_C3" ] && run c3_r4_$rep r4kernel --config c3
+    [ -n "$AB_C3" ] && run c3_new_$rep "" --config c3
     run c4_r4_k8_$rep r4kernel --chunks 8
     run c4_new_k8_$rep "" --chunks 8
     run c4_new_k16_$rep ""
