@@ -331,7 +331,40 @@ __global__ __launch_bounds__(kStripT) void k_strip_fill(i64 nrow, i64 T, const i
             }
             k[h] += c[h];
         }
+        // Quad variant: the up to three positions that pad a slot to whole quads become PAD ENTRIES (value id D, column C): the
+        // kernel keeps -0.0 at dv[D] and 1.0 at xt[C], so a pad adds -0.0 * 1.0 = -0.0 to a running sum -- v + -0.0 == v bit
+        // for bit for every v -- and the slot body needs no predicate (k_qstrip_spmv).
+        if (RPL == 4 && D > 0 && threadIdx.x < kStripSL) {
+            const unsigned int cnt = start[threadIdx.x], padded = (cnt + 3u) & ~3u;   // rows with more than `slot` entries
+            const unsigned int e24 = (unsigned int)D | ((unsigned int)C << 12);
+            for (unsigned int q = cnt; q < padded; ++q) {
+                unsigned char *o8 = reinterpret_cast<unsigned char *>(oent) + (bs + offs[threadIdx.x] + q) * 3;
+                o8[0] = (unsigned char)e24;
+                o8[1] = (unsigned char)(e24 >> 8);
+                o8[2] = (unsigned char)(e24 >> 16);
+            }
+        }
+        // Pair variant: the one position that pads an odd slot to whole pairs, the same way (k_dstrip_spmv)
+        if (RPL == 2 && D > 0 && !WIDE && threadIdx.x < kStripSL && (start[threadIdx.x] & 1u)) {
+            const i64 o = bs + offs[threadIdx.x] + start[threadIdx.x];
+            oent[(o >> 1) * 4 + (o & 1)] = (unsigned short)D;
+            oent[(o >> 1) * 4 + 2 + (o & 1)] = (unsigned short)C;
+        }
         __syncthreads();
+    }
+    if (RPL == 2 && D > 0 && !WIDE && blockIdx.x == gridDim.x - 1 && threadIdx.x < 2) {   // the all-pad pair behind the last cell
+        const i64 o = ((base[(i64)gridDim.x * T] + 1) & ~(i64)1) + threadIdx.x;
+        oent[(o >> 1) * 4 + (o & 1)] = (unsigned short)D;
+        oent[(o >> 1) * 4 + 2 + (o & 1)] = (unsigned short)C;
+    }
+    // ... and one quad of pad entries right behind the last cell: where a lane whose rows have all ended points its load
+    if (RPL == 4 && D > 0 && blockIdx.x == gridDim.x - 1 && threadIdx.x < 4) {
+        const i64 endq = (base[(i64)gridDim.x * T] + 3) >> 2;   // (every cell is a whole number of quads)
+        const unsigned int e24 = (unsigned int)D | ((unsigned int)C << 12);
+        unsigned char *o8 = reinterpret_cast<unsigned char *>(oent) + (endq * 4 + threadIdx.x) * 3;
+        o8[0] = (unsigned char)e24;
+        o8[1] = (unsigned char)(e24 >> 8);
+        o8[2] = (unsigned char)(e24 >> 16);
     }
 }
 
@@ -548,9 +581,10 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
                                                                          const double *__restrict__ dict, int D,
                                                                          const double *__restrict__ x0, const double *__restrict__ x1,
                                                                          double *__restrict__ out0, double *__restrict__ out1) {
-    __shared__ double xt[NV][kDictC];
+    // (pad entries: value id D, column kDictC -- -0.0 at dv[D], 1.0 at xt[kDictC]: see k_qstrip_spmv)
+    __shared__ double xt[NV][kDictC + 2];
     __shared__ double acc[NV][kStripR];
-    __shared__ double dv[kDictMax];
+    __shared__ double dv[kDictMax + 1];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
     const bool cont = ACC && gridDim.y == 1;  // as in k_strip_spmv
@@ -561,6 +595,12 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
         if (NV == 2) acc[NV - 1][h * kStripT + p] = (cont && row < nrow) ? out1[row] : 0.0;
     }
     for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
+    if (p == 0) {
+        dv[D] = -0.0;
+        xt[0][kDictC] = 1.0;
+        if (NV == 2) xt[NV - 1][kDictC] = 1.0;
+    }
+    const unsigned long long padp_abs = (unsigned long long)((base[(i64)gridDim.x * T] + 1) >> 1);   // the all-pad pair behind the last cell
     const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
     // Software pipeline: the x-tile and the per-strip row metadata of strip t + 1 are loaded into registers
     // while strip t's entries stream, so the tile's L2 / Infinity-Cache latency is off the critical path.
@@ -606,6 +646,8 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
         const ushort2 r = r_next;
         const unsigned int n0 = nn_next.x, n1 = nn_next.y;  // n0 >= n1 (sorted)
         const uint2 *__restrict__ e2 = reinterpret_cast<const uint2 *>(ent) + (base_next >> 1);
+        const unsigned int padp = (unsigned int)(padp_abs - (unsigned long long)(base_next >> 1));
+        (void)padp;
         __syncthreads();
         if (t + 1 < t_end) prefetch(t + 1);
         double a0 = acc[0][r.x], a1 = acc[0][r.y], b0 = 0.0, b1 = 0.0;
@@ -638,11 +680,22 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
             unsigned int of[kDictU];  // s + i <= 255: counts are < 256 and s is a multiple of kDictU
 #pragma unroll
             for (int i = 0; i < kDictU; ++i) of[i] = so[s + i];
+#ifndef SLP_DSTRIP_PADS   // dead terms skipped by branches (a lane whose rows have ended reads the pair at offset p)
 #pragma unroll
             for (int i = 0; i < kDictU; ++i) q[i] = ld_stream<NT>(e2 + ((s + i < n0) ? (of[i] >> 1) + p : p));
 #pragma unroll
             for (int i = 0; i < kDictU; ++i)
                 if (s + i < n0) SLP_DSTRIP_STEP(q[i], s + i < n1)
+#else
+            // lab (round 5, -DSLP_DSTRIP_PADS): no per-lane predicate -- dead terms are pad entries worth -0.0 (the slot's padding
+            // position, or the all-pad pair for a lane whose rows have ended), as in k_qstrip_spmv.  Measured on config 3, same
+            // box: A^T y 2.51-2.53 ms against 2.47-2.50 for the branches (profiles/r05_c3_pairs_predicate_free_ab.log): not taken.
+#pragma unroll
+            for (int i = 0; i < kDictU; ++i) q[i] = ld_stream<NT>(e2 + ((s + i < n0) ? (of[i] >> 1) + p : padp));
+#pragma unroll
+            for (int i = 0; i < kDictU; ++i)
+                if (s + i < n0w) SLP_DSTRIP_STEP(q[i], true)
+#endif
         }
 #undef SLP_DSTRIP_STEP
         acc[0][r.x] = a0;
@@ -682,9 +735,14 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstri
                                                                          const double *__restrict__ dict, int D,
                                                                          const double *__restrict__ x0, const double *__restrict__ x1,
                                                                          double *__restrict__ out0, double *__restrict__ out1) {
-    __shared__ double xt[NV][kQuadC];
+    // Round 5: NO predicate in the slot body.  A position that pads a slot to whole quads is a PAD ENTRY (value id D, column
+    // kQuadC; k_strip_fill), and a lane whose rows have all ended loads the all-pad quad behind the last cell: with -0.0 at dv[D]
+    // and 1.0 at xt[kQuadC] such an entry adds -0.0 * 1.0 = -0.0 -- and v + -0.0 == v bit for bit for every v, signed zeros
+    // included -- so every sum is still the sequential storage-order sum, without the compare and the two selects per term that
+    // kept the dead terms out (rounds 2-4).
+    __shared__ double xt[NV][kQuadC + 2];
     __shared__ double acc[NV][kQuadR];
-    __shared__ double dv[kDictMax];
+    __shared__ double dv[kDictMax + 1];
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
     const bool cont = ACC && gridDim.y == 1;  // as in k_strip_spmv
@@ -695,6 +753,12 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstri
         if (NV == 2) acc[NV - 1][p + h * kStripT] = (cont && row < nrow) ? out1[row] : 0.0;
     }
     for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
+    if (p == 0) {
+        dv[D] = -0.0;   // (whatever table the launch brought -- strip_spmv_with_dict swaps it -- the pad value is the kernel's own)
+        xt[0][kQuadC] = 1.0;
+        if (NV == 2) xt[NV - 1][kQuadC] = 1.0;
+    }
+    const unsigned long long padq_abs = (unsigned long long)((base[(i64)gridDim.x * T] + 3) >> 2);   // the all-pad quad behind the last cell
     const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
     constexpr int kTileQ = (kQuadC / 2 + kStripT - 1) / kStripT;
     double2 tv[NV][kTileQ];
@@ -736,8 +800,9 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstri
             }
         }
         const ushort4 r = r_next;
-        const unsigned int n0 = nn_next.x, n1 = nn_next.y, n2 = nn_next.z, n3 = nn_next.w;  // n0 >= n1 >= n2 >= n3
+        const unsigned int n0 = nn_next.x;  // the longest of the lane's four rows (sorted: n0 >= n1 >= n2 >= n3)
         const Quad12 *__restrict__ e4 = reinterpret_cast<const Quad12 *>(ent) + (base_next >> 2);
+        const unsigned int padq = (unsigned int)(padq_abs - (unsigned long long)(base_next >> 2));   // (relative to this cell: < 2^32 quads per copy)
         // NT: the cell's entries through a wave-uniform buffer descriptor, 12-byte loads with the non-temporal policy
         const unsigned long long e4u = (unsigned long long)e4;
         const void *e4s = (const void *)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(e4u >> 32)) << 32) |
@@ -758,26 +823,28 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstri
             for (int i = 0; i < kU; ++i) of[i] = so[(s + i) & (kStripSL - 1)];
 #pragma unroll
             for (int i = 0; i < kU; ++i) {
-                const unsigned int qi = (s + i < n0) ? (of[i] >> 2) + p : p;
+                const unsigned int qi = (s + i < n0) ? (of[i] >> 2) + p : padq;
                 if (ABL == 3) {
                     q[i].x = qi * 2654435761u; q[i].y = q[i].x ^ (qi << 7); q[i].z = q[i].y + 0x9e3779b9u;
                     q[i].x &= 0xff7ff7ffu; q[i].y &= 0xf7ff7ff7u; q[i].z &= 0x7ff7ff7fu;  // ids < 2048, columns < 3968
                 } else if (NT) {
+                    // (lab, SLP_NT_QUADS=1: 12-byte loads with the non-temporal policy through a wave-uniform descriptor; a lane
+                    // whose rows have ended addresses the all-pad quad through the same descriptor: 32-bit byte offsets, so only
+                    // for copies below 2 GB (the descriptor's range) -- strip_spmv_one checks)
                     const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, qi * 12u, 0, 2);
                     q[i].x = v.x; q[i].y = v.y; q[i].z = v.z;
                 } else {
                     q[i] = e4[qi];
                 }
             }
-            // Branch-free slot body: all eight LDS gathers of a slot (value table and x-tile for the lane's four rows) are
-            // issued back to back -- every address is valid, pad entries are (id 0, column 0) -- and only the accumulation is
-            // predicated (a select).  With a branch per term the compiler waits for each term's two gathers before it issues
-            // the next pair (s_waitcnt lgkmcnt(0) after every term): the LDS latency was paid once per entry.
+            // Branch-free, predicate-free slot body: all eight LDS gathers of a slot (value table and x-tile for the lane's four
+            // rows) are issued back to back -- every address is valid -- and every term is simply added: dead terms are pad
+            // entries worth -0.0.  (With a branch per term the compiler waits for each term's two gathers before it issues the
+            // next pair, s_waitcnt lgkmcnt(0) after every term; rounds 2-4 predicated the accumulation with a select instead.)
 #pragma unroll
             for (int i = 0; i < kU; ++i) {
                 if (s + i < n0w) {  // wave-uniform: slots beyond the wave's longest row are skipped as a whole
                     const unsigned int e[4] = {q[i].x, (q[i].x >> 24) | (q[i].y << 8), (q[i].y >> 16) | (q[i].z << 16), q[i].z >> 8};
-                    const bool live[4] = {s + i < n0, s + i < n1, s + i < n2, s + i < n3};
                     // two rows at a time: four gathers in flight (eight spill registers at the 64-VGPR budget)
 #pragma unroll
                     for (int g = 0; g < 4; g += kQuadG) {
@@ -791,12 +858,8 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? SLP_QUAD_WAVES : 4) void k_qstri
                         }
 #pragma unroll
                         for (int h = 0; h < kQuadG; ++h) {
-                            const double t0 = a[0][g + h] + w[h] * xv[0][h];
-                            a[0][g + h] = live[g + h] ? t0 : a[0][g + h];
-                            if (NV == 2) {
-                                const double t1 = a[NV - 1][g + h] + w[h] * xv[NV - 1][h];
-                                a[NV - 1][g + h] = live[g + h] ? t1 : a[NV - 1][g + h];
-                            }
+                            a[0][g + h] = a[0][g + h] + w[h] * xv[0][h];
+                            if (NV == 2) a[NV - 1][g + h] = a[NV - 1][g + h] + w[h] * xv[NV - 1][h];
                         }
                     }
                 }
@@ -1116,7 +1179,7 @@ static void strip_spmv_one(const StripJds &f, const double *x, double *out, int 
             else SLP_QLAUNCH(false, 3);
         } else
 #endif
-        if (f.rpl == 4 && nt_quads()) SLP_WITH_ACC(accum, SLP_QLAUNCH(true, 0));
+        if (f.rpl == 4 && nt_quads() && f.ent.n * sizeof(unsigned short) < ((size_t)1 << 31)) SLP_WITH_ACC(accum, SLP_QLAUNCH(true, 0));
         else if (f.rpl == 4) SLP_WITH_ACC(accum, SLP_QLAUNCH(false, 0));
         else if (nt_level() == 1) SLP_WITH_ACC(accum, SLP_DLAUNCH(true));  // 8-byte non-temporal loads measured SLOWER than plain ones (2.33 vs 2.23 ms): explicit only
         else SLP_WITH_ACC(accum, SLP_DLAUNCH(false));
