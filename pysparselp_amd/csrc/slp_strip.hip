@@ -581,10 +581,15 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
                                                                          const double *__restrict__ dict, int D,
                                                                          const double *__restrict__ x0, const double *__restrict__ x1,
                                                                          double *__restrict__ out0, double *__restrict__ out1) {
-    // (pad entries: value id D, column kDictC -- -0.0 at dv[D], 1.0 at xt[kDictC]: see k_qstrip_spmv)
+#ifdef SLP_DSTRIP_PADS   // lab: pad entries (value id D, column kDictC: -0.0 at dv[D], 1.0 at xt[kDictC]) as in k_qstrip_spmv
     __shared__ double xt[NV][kDictC + 2];
     __shared__ double acc[NV][kStripR];
     __shared__ double dv[kDictMax + 1];
+#else
+    __shared__ double xt[NV][kDictC];
+    __shared__ double acc[NV][kStripR];
+    __shared__ double dv[kDictMax];
+#endif
     const i64 b = blockIdx.x;
     const int p = threadIdx.x;
     const bool cont = ACC && gridDim.y == 1;  // as in k_strip_spmv
@@ -595,12 +600,14 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
         if (NV == 2) acc[NV - 1][h * kStripT + p] = (cont && row < nrow) ? out1[row] : 0.0;
     }
     for (int q = p; q < D; q += kStripT) dv[q] = dict[q];
+#ifdef SLP_DSTRIP_PADS
     if (p == 0) {
         dv[D] = -0.0;
         xt[0][kDictC] = 1.0;
         if (NV == 2) xt[NV - 1][kDictC] = 1.0;
     }
     const unsigned long long padp_abs = (unsigned long long)((base[(i64)gridDim.x * T] + 1) >> 1);   // the all-pad pair behind the last cell
+#endif
     const i64 t_begin = (T * (i64)blockIdx.y) / gridDim.y, t_end = (T * (i64)(blockIdx.y + 1)) / gridDim.y;
     // Software pipeline: the x-tile and the per-strip row metadata of strip t + 1 are loaded into registers
     // while strip t's entries stream, so the tile's L2 / Infinity-Cache latency is off the critical path.
@@ -646,8 +653,9 @@ __global__ __launch_bounds__(kStripT, NV == 1 ? 8 : 4) void k_dstrip_spmv(i64 nr
         const ushort2 r = r_next;
         const unsigned int n0 = nn_next.x, n1 = nn_next.y;  // n0 >= n1 (sorted)
         const uint2 *__restrict__ e2 = reinterpret_cast<const uint2 *>(ent) + (base_next >> 1);
+#ifdef SLP_DSTRIP_PADS
         const unsigned int padp = (unsigned int)(padp_abs - (unsigned long long)(base_next >> 1));
-        (void)padp;
+#endif
         __syncthreads();
         if (t + 1 < t_end) prefetch(t + 1);
         double a0 = acc[0][r.x], a1 = acc[0][r.y], b0 = 0.0, b1 = 0.0;

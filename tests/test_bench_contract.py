@@ -178,6 +178,22 @@ def test_bench_under_the_launcher_two_ranks_with_chunked_row_blocks():
 
 
 @pytest.mark.gpu
+def test_bench_block_groups_under_the_launcher_two_ranks_on_one_gpu():
+    """What `--config c5 --gpus 2` does, in small: block-splitting ADMM with TWO row blocks on each of two ranks, every block
+    generated from its own row range (no resident matrix), a block's consensus all-reduce issued beside the next block's
+    projection: 2 collectives per iteration, all timed, the overlapped part reported; same objective as one rank with four blocks."""
+    more = ("--method", "admm_blocks", "--blocks-per-rank", "2")
+    two = _launch(2, {"SLP_DEVICE": "0", "SLP_COMM_TRANSPORT": "host", "SLP_STRIP_MIN_NNZ": "1"}, 29711, more=more)
+    check_line(two, need_cpu_baseline=False)
+    cfg, e = two["config"], two["exchange"]
+    assert two["n_gpus"] == 2 and cfg["blocks_per_rank"] == 2 and cfg["blocks_total"] == 4 and cfg["collectives_per_iteration"] == 2.0
+    assert "no resident matrix" in cfg["workload"] and e["ms_overlapped_per_iteration"] > 0 and cfg["cg_steps_per_block_update"] > 0
+    one = _launch(1, {"SLP_STRIP_MIN_NNZ": "1"}, 29721, more=("--method", "admm_blocks", "--blocks-per-rank", "4"))
+    assert one["config"]["blocks_total"] == 4 and one["config"]["nnz"] == two["config"]["nnz"]
+    assert abs(two["objective_after_run"] - one["objective_after_run"]) <= 1e-8 * (1 + abs(one["objective_after_run"]))
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(1200)
 def test_bench_under_the_launcher_eight_ranks_on_one_gpu():
     """The driver's 8-GPU launch line (`torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`) with all eight ranks on
