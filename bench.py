@@ -93,6 +93,7 @@ PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: ((("r05_tall_slice_pmc_
 # its share of a multiple of the CU count of row blocks, slp_matrix_chunked_expect), measured 9.52-9.54 it/s with 16 chunks
 # against 9.57 with 8 on one box (profiles/r05_c4_chunks_16_vs_8.txt).
 CHUNK_ENTRIES = 1.3e9
+UNCHUNKED_ENTRIES = 2.6e9   # a row block up to this size is an ordinary DeviceMatrix (config 3, the 1/8 slice = one of 8 ranks of config 4)
 
 
 def parse():
@@ -468,7 +469,8 @@ def run_workload(lib, args, rank, world, distributed):
 
     shape = (args.n, args.m, args.density)
     r0, rows = row_block(args.m, world, rank)
-    chunks = args.chunks or max(1, int(np.ceil(rows * args.n * args.density / CHUNK_ENTRIES)))
+    entries = rows * args.n * args.density
+    chunks = args.chunks or (1 if entries <= UNCHUNKED_ENTRIES else int(np.ceil(entries / CHUNK_ENTRIES)))
     alloc = np.zeros(5)
     _lib.check(lib.slp_alloc_stats(None, 1))
     t_gen = time.perf_counter()
