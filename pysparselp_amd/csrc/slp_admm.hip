@@ -10,6 +10,12 @@
 // thread in storage order, so x is bit-identical to the sequential sweep.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
 
 #include "slp_common.h"
 #include "slp_kernels.h"
@@ -637,6 +643,65 @@ struct GsPlan {
     mutable DevBuf<int> prog;         // levels stored, per band of the run being swept
 };
 
+// wave-slot headers of one workgroup: a level's wave slots dealt to the waves in turn; a wave without one in a level
+// repeats the level's first wave slot (see k_gs_sweep_windowed); a wave's last header of a level carries the barrier.
+// As many waves as the widest level has wave slots (at most max_waves): a wave with nothing of its own in a level repeats
+// another's wave slot, and those repeats take issue cycles from the waves on its SIMD.  with_stored: header k also says
+// how many levels are complete with the wave's wave slot k - 6 (bands).  `info(q0, &rounds, &far)`: chain rounds and far mask
+// of the wave slot that starts at lane slot q0.  Appends to hd / hoffs; returns the group's first index into hoffs.
+template <class Info>
+static int gs_emit_headers(std::vector<GsStepW> &hd, std::vector<int> &hoffs, const std::vector<std::pair<i64, i64>> &lv, int max_waves,
+                           bool with_stored, bool bands_safe, int *waves_out, Info info) {
+    i64 widest = 1;
+    for (const auto &r : lv) widest = std::max(widest, (r.second - r.first) / 64);
+    const int waves = (int)std::min<i64>(max_waves, widest);
+    *waves_out = waves;
+    std::vector<std::vector<GsStepW>> per((size_t)waves);
+    std::vector<std::vector<int>> done((size_t)waves);  // levels complete once the header's wave slot is stored
+    for (size_t l = 0; l < lv.size(); ++l) {
+        const i64 nw = (lv[l].second - lv[l].first) / 64;
+        for (i64 q = 0; q < nw; ++q) {
+            const size_t q0 = (size_t)(lv[l].first + 64 * q);
+            unsigned rounds = 1, far = 0;
+            info(q0, &rounds, &far);
+            GsStepW h;
+            h.first = (int)q0;
+            h.meta = 1u | (rounds << 1) | (far ? 128u : 0u);
+            per[(size_t)(q % waves)].push_back(h);
+            done[(size_t)(q % waves)].push_back((int)l);
+        }
+        for (int wv = 0; wv < waves; ++wv) {
+            if ((i64)wv >= nw) {  // nothing left for this wave: it repeats wave 0's
+                per[(size_t)wv].push_back(per[0].back());
+                done[(size_t)wv].push_back((int)l);
+            }
+            per[(size_t)wv].back().meta |= 64u;
+            done[(size_t)wv].back() = (int)l + 1;
+        }
+    }
+    const int off = (int)hoffs.size();
+    for (int wv = 0; wv < waves; ++wv) {
+        // the kernel's loop is unrolled by 6 without a remainder: pad with repeats of the wave's last wave slot
+        // (after the last barrier; same inputs, same results), without the barrier flag
+        while (per[(size_t)wv].size() % 6) {
+            GsStepW h = per[(size_t)wv].back();
+            h.meta &= ~64u;
+            per[(size_t)wv].push_back(h);
+            done[(size_t)wv].push_back((int)lv.size());
+        }
+        if (with_stored) {
+            const char *el = getenv("SLP_GS_BANDS_LAG");  // lab only
+            const size_t lag = bands_safe ? 0 : (el ? (size_t)atoi(el) : 6);
+            for (size_t k = 0; k < per[(size_t)wv].size(); ++k)
+                per[(size_t)wv][k].meta = (per[(size_t)wv][k].meta & 0xffu) | ((unsigned)(k >= lag ? done[(size_t)wv][k - lag] : 0) << 8);
+        }
+        hoffs.push_back((int)hd.size());
+        hd.insert(hd.end(), per[(size_t)wv].begin(), per[(size_t)wv].end());
+    }
+    hoffs.push_back((int)hd.size());
+    return off;
+}
+
 static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, const double *data) {
     SLP_REQUIRE(n >= 0 && indptr, "gauss-seidel: bad arguments");
     SLP_REQUIRE(n < (i64)1 << 31, "gauss-seidel: dimension must fit int32");
@@ -973,58 +1038,16 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
         std::vector<GsStepW> hd;
         std::vector<int> hoffs;
         auto emit_headers = [&](const std::vector<std::pair<i64, i64>> &lv, int max_waves, bool with_stored, int *waves_out) {
-            i64 widest = 1;
-            for (const auto &r : lv) widest = std::max(widest, (r.second - r.first) / 64);
-            const int waves = (int)std::min<i64>(max_waves, widest);
-            *waves_out = waves;
-            std::vector<std::vector<GsStepW>> per((size_t)waves);
-            std::vector<std::vector<int>> done((size_t)waves);  // levels complete once the header's wave slot is stored
-            for (size_t l = 0; l < lv.size(); ++l) {
-                const i64 nw = (lv[l].second - lv[l].first) / 64;
-                for (i64 q = 0; q < nw; ++q) {
-                    const size_t q0 = (size_t)(lv[l].first + 64 * q);
-                    unsigned rounds = 1, far = 0;
-                    for (size_t k = q0; k < q0 + 64; ++k) {
-                        rounds = std::max(rounds, (unsigned)(lanes[k].info & 15) + 1u);
-                        far |= (unsigned)(lanes[k].info >> 8);
-                    }
-                    GsStepW h;
-                    h.first = (int)q0;
-                    h.meta = 1u | (rounds << 1) | (far ? 128u : 0u);
-                    if (far) g.has_far = true;
-                    per[(size_t)(q % waves)].push_back(h);
-                    done[(size_t)(q % waves)].push_back((int)l);
+            return gs_emit_headers(hd, hoffs, lv, max_waves, with_stored, g.bands_safe, waves_out, [&](size_t q0, unsigned *rounds, unsigned *far) {
+                unsigned r = 1, f = 0;
+                for (size_t k = q0; k < q0 + 64; ++k) {
+                    r = std::max(r, (unsigned)(lanes[k].info & 15) + 1u);
+                    f |= (unsigned)(lanes[k].info >> 8);
                 }
-                for (int wv = 0; wv < waves; ++wv) {
-                    if ((i64)wv >= nw) {  // nothing left for this wave: it repeats wave 0's
-                        per[(size_t)wv].push_back(per[0].back());
-                        done[(size_t)wv].push_back((int)l);
-                    }
-                    per[(size_t)wv].back().meta |= 64u;
-                    done[(size_t)wv].back() = (int)l + 1;
-                }
-            }
-            const int off = (int)hoffs.size();
-            for (int wv = 0; wv < waves; ++wv) {
-                // the kernel's loop is unrolled by 6 without a remainder: pad with repeats of the wave's last wave slot
-                // (after the last barrier; same inputs, same results), without the barrier flag
-                while (per[(size_t)wv].size() % 6) {
-                    GsStepW h = per[(size_t)wv].back();
-                    h.meta &= ~64u;
-                    per[(size_t)wv].push_back(h);
-                    done[(size_t)wv].push_back((int)lv.size());
-                }
-                if (with_stored) {
-                    const char *el = getenv("SLP_GS_BANDS_LAG");  // lab only
-                    const size_t lag = g.bands_safe ? 0 : (el ? (size_t)atoi(el) : 6);
-                    for (size_t k = 0; k < per[(size_t)wv].size(); ++k)
-                        per[(size_t)wv][k].meta = (per[(size_t)wv][k].meta & 0xffu) | ((unsigned)(k >= lag ? done[(size_t)wv][k - lag] : 0) << 8);
-                }
-                hoffs.push_back((int)hd.size());
-                hd.insert(hd.end(), per[(size_t)wv].begin(), per[(size_t)wv].end());
-            }
-            hoffs.push_back((int)hd.size());
-            return off;
+                *rounds = r;
+                *far = f;
+                if (f) g.has_far = true;
+            });
         };
         // one lane of a row: entries [j E, (j + 1) E) of row position t; cls(row, e, lane record, entry record) sets the entry's class
         auto push_row = [&](i64 t, int ldsw, auto &&cls) {
@@ -1248,6 +1271,106 @@ static void gs_plan(GsPlan &g, i64 n, const i64 *indptr, const i32 *indices, con
     if (getenv("SLP_GS_VERBOSE"))
         fprintf(stderr, "gauss-seidel plan: n %lld, %lld entries, %lld levels: levels %.1f ms, bands %.1f ms, permute + upload %.1f ms, lane records %.1f ms, all %.1f ms (host)\n",
                 (long long)n, (long long)g.nnz, (long long)g.nlevels, ms_levels, ms_bands, ms_permute, ms_pack, plan_ms());
+}
+
+}  // namespace slp
+#include "slp_gs_plan_device.h"
+namespace slp {
+
+// SLP_GS_PLAN: "device" (default) -- the plan is built on the device from the matrix where it lies (gs_plan_device; the host plan only
+// where that declines); "host" -- gs_plan from a host copy of the matrix (rounds 1-4); "check" -- both, and every array of the
+// device plan must equal the host plan's (tests).
+constexpr i64 kGsSmallPlan = 200000;   // stored entries up to which the host plan is the quicker one
+static int gs_plan_mode() {
+    const char *e = getenv("SLP_GS_PLAN");
+    if (e && !strcmp(e, "host")) return 0;
+    if (e && !strcmp(e, "check")) return 2;
+    return 1;
+}
+
+template <class T>
+static void gs_plan_same(const char *what, const DevBuf<T> &a, const DevBuf<T> &b, size_t count) {
+    if (count == 0) return;
+    SLP_REQUIRE(a.p && b.p && a.n >= count && b.n >= count, std::string("gs plan check: ") + what + ": missing or short array");
+    std::vector<T> ha(count), hb(count);
+    a.download(ha.data(), count);
+    b.download(hb.data(), count);
+    if (memcmp(ha.data(), hb.data(), count * sizeof(T)) != 0) {
+        size_t k = 0;
+        while (k < count && memcmp(&ha[k], &hb[k], sizeof(T)) == 0) ++k;
+        throw Error(std::string("gs plan check: ") + what + " differs at element " + std::to_string(k) + " of " + std::to_string(count));
+    }
+}
+
+// every array the sweep reads: device plan `d` against host plan `h`
+static void gs_plan_compare(const GsPlan &d, const GsPlan &h) {
+    auto same = [&](bool ok, const char *what) { SLP_REQUIRE(ok, std::string("gs plan check: ") + what + " differs"); };
+    same(d.n == h.n && d.nnz == h.nnz && d.nlevels == h.nlevels && d.max_width == h.max_width, "sizes / levels");
+    same(d.lptr == h.lptr, "level pointer");
+    same(d.one_block == h.one_block && d.pipelined == h.pipelined && d.windowed == h.windowed && d.has_far == h.has_far && d.nbands == h.nbands,
+         "plan kind (one_block / pipelined / windowed / has_far / bands)");
+    const size_t n = (size_t)d.n;
+    gs_plan_same("rows", d.rows, h.rows, n);
+    gs_plan_same("ptr", d.ptr, h.ptr, n + 1);
+    gs_plan_same("idx", d.idx, h.idx, (size_t)d.nnz + kGsEntries);
+    gs_plan_same("val", d.val, h.val, (size_t)d.nnz + kGsEntries);
+    gs_plan_same("invd", d.invd, h.invd, n);
+    gs_plan_same("diag", d.diag, h.diag, n);
+    gs_plan_same("lptr_dev", d.lptr_dev, h.lptr_dev, (size_t)d.nlevels + 1);
+    same(d.segments.size() == h.segments.size(), "segment count");
+    for (size_t k = 0; k < d.segments.size(); ++k) {
+        const GsPlan::Segment &a = d.segments[k], &b = h.segments[k];
+        same(a.launch == b.launch && a.level_first == b.level_first && a.level_count == b.level_count && a.bands == b.bands && a.waves == b.waves &&
+                 (a.launch || (a.slot_first == b.slot_first && a.slot_count == b.slot_count && (a.bands || a.hoff == b.hoff) && a.band_first == b.band_first)) &&
+                 (!a.launch || a.first == b.first),
+             "a segment");
+    }
+    if (d.pipelined) {
+        same(d.lanes.n == h.lanes.n && d.ents.n == h.ents.n && d.stepsw.n == h.stepsw.n && d.hoffs.n == h.hoffs.n, "lane slot / header counts");
+        gs_plan_same("ents", d.ents, h.ents, d.ents.n);
+        gs_plan_same("lanes", d.lanes, h.lanes, d.lanes.n);
+        gs_plan_same("lane_row", d.lane_row, h.lane_row, d.lane_row.n);
+        gs_plan_same("stepsw", d.stepsw, h.stepsw, d.stepsw.n);
+        gs_plan_same("hoffs", d.hoffs, h.hoffs, d.hoffs.n);
+        same(d.scratch.n == h.scratch.n && d.dyn.n == h.dyn.n, "scratch / term buffers");
+        if (d.nbands) {
+            same(d.fsrc.n == h.fsrc.n && d.freq.n == h.freq.n, "band table sizes");
+            gs_plan_same("bands", d.bands, h.bands, (size_t)d.nbands);
+            gs_plan_same("fsrc", d.fsrc, h.fsrc, d.fsrc.n);
+            gs_plan_same("freq", d.freq, h.freq, d.freq.n);
+        }
+    }
+}
+
+// the plan for a matrix that lies on the device (dptr / didx / dval); host copies are made only where the host plan is needed
+static void gs_plan_any(GsPlan &g, i64 n, i64 nnz, const i64 *dptr, const i32 *didx, const double *dval) {
+    const int mode = gs_plan_mode();
+    auto host_plan = [&](GsPlan &out) {
+        std::vector<i64> mp((size_t)n + 1);
+        std::vector<i32> mj((size_t)nnz);
+        std::vector<double> mx((size_t)nnz);
+        hipStream_t st = ctx().stream;
+        SLP_HIP(hipMemcpyAsync(mp.data(), dptr, mp.size() * sizeof(i64), hipMemcpyDeviceToHost, st));
+        if (nnz) SLP_HIP(hipMemcpyAsync(mj.data(), didx, mj.size() * sizeof(i32), hipMemcpyDeviceToHost, st));
+        if (nnz) SLP_HIP(hipMemcpyAsync(mx.data(), dval, mx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SLP_HIP(hipStreamSynchronize(st));
+        Phase ph("gs_plan (host level schedule)");
+        gs_plan(out, n, mp.data(), mj.data(), mx.data());
+    };
+    // (small systems -- the single-workgroup regime -- keep the host plan: a 2 MB download and microseconds of host work against
+    // ~30 launches and a dozen synchronisations)
+    if (mode == 0 || (mode == 1 && nnz <= kGsSmallPlan)) { host_plan(g); return; }
+    bool ok;
+    {
+        Phase ph("gs_plan_device");
+        ok = gs_plan_device(g, n, nnz, dptr, didx, dval);
+    }
+    if (!ok) { g = GsPlan(); host_plan(g); return; }
+    if (mode == 2) {
+        GsPlan h;
+        host_plan(h);
+        gs_plan_compare(g, h);
+    }
 }
 
 // bounded = false: plain SOR sweep (no bounds); the kernels then read the diagonal through the `lo` argument
@@ -1557,7 +1680,20 @@ slp_gs *slp_gs_create(int64_t n, const int64_t *indptr, const int32_t *indices, 
         ctx();
         auto *g = new slp_gs();
         try {
-            gs_plan(g->plan, n, indptr, indices, data);
+            SLP_REQUIRE(n >= 0 && indptr, "gauss-seidel: bad arguments");
+            SLP_REQUIRE(n < (i64)1 << 31, "gauss-seidel: dimension must fit int32");
+            if (gs_plan_mode() == 0 || n == 0 || (gs_plan_mode() == 1 && indptr[n] <= kGsSmallPlan)) {
+                gs_plan(g->plan, n, indptr, indices, data);
+            } else {
+                const i64 nnz = indptr[n];
+                DevBuf<i64> dp;
+                DevBuf<i32> dj;
+                DevBuf<double> dx;
+                dp.upload(indptr, (size_t)n + 1);
+                dj.upload(indices, (size_t)nnz);
+                dx.upload(data, (size_t)nnz);
+                gs_plan_any(g->plan, n, nnz, dp.p, dj.p, dx.p);
+            }
             g->b.alloc((size_t)n); g->lo.alloc((size_t)n); g->hi.alloc((size_t)n); g->x.alloc((size_t)n);
             SLP_HIP(hipStreamSynchronize(ctx().stream));
         } catch (...) { delete g; throw; }
@@ -1593,23 +1729,25 @@ static void admm_finish_create(slp_admm *s, const int64_t *m_indptr, const int32
     build_transpose(s->a);
     s->lanes_rows = lanes_for(s->a->a, s->order);
     s->lanes_cols = lanes_for(s->a->at, s->order);
-    if (m_indptr) {
+    if (m_indptr && (gs_plan_mode() == 0 || N == 0 || (gs_plan_mode() == 1 && m_indptr[N] <= kGsSmallPlan))) {
         Phase ph("gs_plan (host level schedule)");
         gs_plan(s->plan, N, m_indptr, m_indices, m_data);
+    } else if (m_indptr) {
+        const i64 nnz = m_indptr[N];
+        DevBuf<i64> dp;
+        DevBuf<i32> dj;
+        DevBuf<double> dx;
+        dp.upload(m_indptr, (size_t)N + 1);
+        dj.upload(m_indices, (size_t)nnz);
+        dx.upload(m_data, (size_t)nnz);
+        gs_plan_any(s->plan, N, nnz, dp.p, dj.p, dx.p);
     } else {
-        // M = gamma_eq A^T A + gamma_ineq I formed on the device (slp_spgemm.hip, SMMP accumulation order); the
-        // level schedule of the sweep is still planned on the host from one download of M
+        // M = gamma_eq A^T A + gamma_ineq I formed on the device (slp_spgemm.hip, SMMP accumulation order) and planned where it
+        // lies (gs_plan_device: levels, level order, lane records on the device; SLP_GS_PLAN=host: from one download of M)
         slp_matrix *mm = slp_matrix_normal(s->a, s->gamma_eq, s->gamma_ineq);
         if (!mm) throw Error(slp_last_error());
         try {
-            std::vector<i64> mp((size_t)N + 1);
-            std::vector<i32> mj((size_t)mm->a.nnz);
-            std::vector<double> mx((size_t)mm->a.nnz);
-            mm->a.ptr.download(mp.data(), mp.size());
-            mm->a.idx.download(mj.data(), mj.size());
-            mm->a.val.download(mx.data(), mx.size());
-            Phase ph("gs_plan (host level schedule)");
-            gs_plan(s->plan, N, mp.data(), mj.data(), mx.data());
+            gs_plan_any(s->plan, N, mm->a.nnz, mm->a.ptr.p, mm->a.idx.p, mm->a.val.p);
         } catch (...) { delete mm; throw; }
         delete mm;
     }
