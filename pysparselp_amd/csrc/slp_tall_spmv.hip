@@ -164,15 +164,25 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
             else so += c[0] * 4u;
             g.hi[DICT ? part : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4 * part] ? mine : kOob, so, 2);
         }
-        if (part == 1) {
+#ifndef SLP_TALL_XLOAD
+#define SLP_TALL_XLOAD 0   // lab: where the tile loads of the packet `depth` ahead are issued: 0 behind all items, 1 between the groups, 2 behind the tile store
+#endif
+        if (part == (SLP_TALL_XLOAD == 1 ? 0 : 1) && SLP_TALL_XLOAD != 2) {
             const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
             const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
             load_tile(g, xo);
         }
     };
+#if SLP_TALL_XLOAD == 2
+    auto issue_tile = [&](TallRegs<DICT> &g, unsigned int h) {
+        const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
+        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
+        load_tile(g, xo);
+    };
+#endif
 #endif
 
-    auto consume = [&](const TallRegs<DICT> &g, unsigned int h, auto &&between) {
+    auto consume = [&](TallRegs<DICT> &g, unsigned int h, unsigned int hnext, auto &&between) {
         const unsigned int xw = (unsigned int)__builtin_amdgcn_readlane((int)h, 1);
         const unsigned int c4 = (unsigned int)__builtin_amdgcn_readlane((int)h, 4) & 0xffffu;   // lanes with a fifth item
         if (xw & kPktNewCell) {
@@ -209,6 +219,9 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
 #endif
 #if SLP_TALL_STAGE == 0
         stage_tile();
+#endif
+#if !defined(SLP_TALL_WHOLE_ISSUE) && SLP_TALL_XLOAD == 2
+        issue_tile(g, hnext);   // (the tile's registers are free again)
 #endif
         const double *__restrict__ tile = xt[cur];
         // Four slots at a time: all twelve LDS reads (running sums, values, x) are issued together, the products do not
@@ -298,10 +311,10 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
 #pragma unroll
         for (int u = 0; u < 2 * kDepth; ++u) {
 #ifndef SLP_TALL_WHOLE_ISSUE
-            consume(regs[u % kDepth], hw[u], [&]() { issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 0); });   // packet jj + u
+            consume(regs[u % kDepth], hw[u], hw[(u + kDepth) % (2 * kDepth)], [&]() { issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 0); });   // packet jj + u
             issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 1);                                               // (payload of packet jj + u + depth)
 #else
-            consume(regs[u % kDepth], hw[u], []() {});                      // packet jj + u
+            consume(regs[u % kDepth], hw[u], 0u, []() {});                  // packet jj + u
             issue(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)]);       // payload of packet jj + u + depth
 #endif
             hw[u] = hd[(i64)(jj + u + 2 * kDepth) * 8];                     // header of packet jj + u + 2 depth
