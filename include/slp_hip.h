@@ -383,7 +383,10 @@ slp_matrix *slp_matrix_random(int64_t nrow, int64_t ncol, double density,
 /* The vectors of the same LP, keyed by (seed, global index):
  * feasible_x, c, lb, ub of length n (:33,51-55) and, for the local rows of
  * `a`, b_upper = ceil((A feasible_x + |rand_sparse|) * 1000) / 1000 (:43-46).
- * Host output buffers; any may be NULL. */
+ * Host output buffers; any may be NULL.  `a` may be a chunked matrix (or one
+ * whose CSR was released): A feasible_x is then formed by its product copies,
+ * for all rows at once after the last append; row_offset = the global index
+ * of its first row. */
 int slp_random_lp_vectors(slp_matrix *a, double density, uint64_t seed, int64_t row_offset,
                           double *feasible_x, double *c, double *lb, double *ub,
                           double *b_upper);

@@ -209,7 +209,6 @@ int slp_random_lp_vectors(slp_matrix *m, double density, uint64_t seed, int64_t 
                           double *lb, double *ub, double *b_upper) {
     SLP_API_INT({
         SLP_REQUIRE(m, "slp_random_lp_vectors: NULL matrix");
-        if (m->a.nrow && b_upper) require_csr(m, "slp_random_lp_vectors (b_upper = ceil(A x_f + ...): take it chunk by chunk, before the append)");
         Phase ph("slp_random_lp_vectors");
         hipStream_t st = ctx().stream;
         const i64 n = m->a.ncol, rows = m->a.nrow;
@@ -217,7 +216,14 @@ int slp_random_lp_vectors(slp_matrix *m, double density, uint64_t seed, int64_t 
         hipLaunchKernelGGL(k_random_cols, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, n, seed, xf.p, dc.p, dl.p, du.p);
         SLP_HIP(hipGetLastError());
         if (rows && b_upper) {
-            launch_spmv(m->a, xf.p, ax.p, SLP_ORDER_AUTO);
+            // A x_f as the matrix's own product forms it: through the product copies where the matrix has (or qualifies for) them --
+            // every row one chain of additions in storage order, scipy's csr_matvec of randomLP.py:43 -- else the CSR kernel in the
+            // same order.  A chunked matrix is asked once, after the last append (all rows in one launch of the fused product).  The
+            // order matters: x_f and the coefficients are multiples of 0.01, so A x_f * 1000 lies within rounding of a whole number in
+            // a tenth of the rows and the ceiling below turns on the last bit there -- one order everywhere, and every chunking
+            // of an LP draws the same b_upper.  (Round 1-4 took it chunk by chunk from the CSR with the rows spread over 64 lanes:
+            // every x gathered from L2, 11 x the CSR's bytes in HBM traffic at 1e7 columns, 45 ms per 2.5e9 entries against 3.)
+            matrix_spmv(m, false, xf.p, ax.p, SLP_ORDER_SEQUENTIAL);
             hipLaunchKernelGGL(k_random_bupper, dim3(grid_for(rows, kBlock)), dim3(kBlock), 0, st, rows, seed, row_offset, density,
                                ax.p, db.p);
             SLP_HIP(hipGetLastError());

@@ -161,15 +161,63 @@ __device__ __forceinline__ unsigned long long tall_block_scan(unsigned long long
     return base + inc - v;
 }
 
-// One workgroup per row block walks its cells in strip order.  WRITE = false: sizes only (payload words, packets);
-// WRITE = true: headers and payload at the offsets the host derived from the sizes.
+// ONE pass over the cells, any cell by any workgroup.  Where a cell's packets go depends on the sizes of all cells before it, and
+// a cell's size is only known once its rows have been dealt -- most of the work.  Round 1-4 ran the kernel twice (sizes, host
+// scan, fill), one workgroup per ROW BLOCK (a chunk's copy of A has 128 of them: half the chip).  Now the cells are handed out
+// by a ticket counter in cell order, a workgroup deals its cell, PUBLISHES the cell's sizes and sums the sizes of the cells
+// before it by a decoupled look-back (as a single-pass device scan does: every cell publishes first its own sizes, then the
+// sums up to and including itself; a later cell adds own sizes backwards until it meets such sums -- tickets are taken in order
+// by running workgroups, so whatever a cell waits for is being worked on), and writes its packets behind them: the payload comes
+// out compact in cell order = stream order, into a buffer sized by an estimate (`cap_w` words, `cap_p` packets; a cell that would
+// not fit writes nothing and the host repeats the pass with the exact totals).  Packet headers are written with offsets relative
+// to the cell; k_tall_dir moves them into the streams' directories.
+// The scan's state is two 64-bit words per cell, each stamped with its own level in bits 62-63 (0 nothing yet, 1 the cell's own
+// sizes, 2 the sums up to and including the cell) and written / polled by relaxed agent-scope atomics: nothing else has to be
+// ordered against them, so no release / acquire -- on this chip those are write-backs and invalidations of a whole L2, twice
+// per cell and once per poll (measured: 132 ms per 2.5e9 entries with them).  The writer stamps `w` first, then `p`; a reader takes `w`,
+// then `p`, and retries until both carry the same level.
+#ifdef SLP_TALL_BUILD_PROF   // lab: where a cell's time goes -- 100 MHz ticks between marks, summed over all cells by thread 0 of every workgroup
+__device__ unsigned long long g_tb_prof[16];
+#define SLP_TB_PROF(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_tb_prof[k], now_ - tb_last_); tb_last_ = now_; } } while (0)
+#else
+#define SLP_TB_PROF(k) do {} while (0)
+#endif
+struct TallScan {
+    unsigned long long *w;       // level << 62 | payload words (own, or up to and including the cell)
+    unsigned long long *p;       // level << 62 | packets
+    unsigned long long *before_w, *before_p;  // (plain, read after the pass) payload words / packets of the cells before this one
+    unsigned long long *ticket;  // next cell to hand out
+};
+constexpr unsigned long long kScanMask = (1ull << 62) - 1;
+__device__ __forceinline__ void tall_scan_put(const TallScan &sc, i64 c, unsigned long long level, unsigned long long w, unsigned long long k) {
+    __hip_atomic_store(&sc.w[c], (level << 62) | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sc.p[c], (level << 62) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int tall_scan_get(const TallScan &sc, i64 c, unsigned long long *w, unsigned long long *k) {
+    for (;;) {
+        const unsigned long long a = __hip_atomic_load(&sc.w[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(a >> 62)) continue;
+        const unsigned long long b = __hip_atomic_load(&sc.p[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((a >> 62) != (b >> 62)) continue;
+        *w = a & kScanMask;
+        *k = b & kScanMask;
+        return (unsigned int)(a >> 62);
+    }
+}
+
+__device__ __forceinline__ i64 tall_range_of(i64 t, i64 T, int S) {  // the strip range (of S) that holds strip t: T s / S <= t < T (s + 1) / S
+    i64 s = t * S / T;
+    while (T * (s + 1) / S <= t) ++s;
+    while (T * s / S > t) --s;
+    return s;
+}
+
 // DICT: 5-byte items (value id inside); !DICT: 4-byte items (column | row << 12) + the fp64 value in a parallel array at the same offsets.
-template <bool WRITE, bool DICT>
-__global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 ncol, const unsigned long long *__restrict__ keys,
-                                                       const double *__restrict__ svals, const i64 *__restrict__ cellptr,
-                                                       i64 *__restrict__ sizes, const i64 *__restrict__ blk_base,
-                                                       const i64 *__restrict__ pkt_ptr, TallPkt *__restrict__ dir,
-                                                       unsigned int *__restrict__ payload, double *__restrict__ pvals) {
+template <bool DICT>
+__global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 ncell, const unsigned long long *__restrict__ keys,
+                                                       const double *__restrict__ svals, const i64 *__restrict__ cellptr, TallScan sc,
+                                                       i64 cap_w, i64 cap_p, TallPkt *__restrict__ sdir,
+                                                       unsigned int *__restrict__ spay, double *__restrict__ spayv) {
     __shared__ unsigned int cnt[kTallRmax];       // entries of the row inside the cell
     __shared__ unsigned int rstart[kTallRmax];    // position of the row's first entry inside the cell
     __shared__ unsigned short posrow[kTallRmax];  // sorted position -> local row
@@ -180,39 +228,39 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
     __shared__ unsigned long long cbuf[kTallT];  // scans over the 32 threads of a bank class
     __shared__ unsigned int ccls[kTallT];   // demands of the 32 lanes of every bank class
     __shared__ unsigned int spare1[32];     // one-entry rows of a bank class that no lane of the class takes
+    __shared__ i64 s_cell;
+    __shared__ unsigned long long s_before_w, s_before_p;
     const int p = threadIdx.x;
-    // workgroup v = (row block b, strip range sr of S): its own packet stream (S > 1: few, tall row blocks whose strips are
-    // shared by S workgroups -- see tall_geometry)
-    const i64 v = blockIdx.x, b = v / S;
-    const i64 t_begin = T * (v % S) / S, t_end = T * (v % S + 1) / S;
-    unsigned int *pay = WRITE ? payload + blk_base[v] : nullptr;
-    double *payv = (WRITE && !DICT) ? pvals + blk_base[v] : nullptr;
-    TallPkt *pk = WRITE ? dir + pkt_ptr[v] : nullptr;
-    i64 woff = 0, npk = 0;  // running payload offset / packet count of the row block (uniform)
-
-    auto empty_packet = [&](unsigned int xsrc) {
-        if (WRITE && p == 0) {
-            TallPkt h;
-            h.off = (unsigned int)woff; h.xsrc = xsrc; h.c[0] = h.c[1] = h.c[2] = h.c[3] = 0; h.strip = 0; h.pad = 0;
-            pk[npk] = h;
-        }
-        ++npk;
-    };
+#ifdef SLP_TALL_BUILD_PROF
+    unsigned long long tb_last_ = wall_clock64();
+#endif
     auto tile_of = [&](i64 t) -> unsigned int { return t >= 0 ? (unsigned int)(t * (i64)kTallC) : kNoTile; };
-    auto next_cell = [&](i64 t) -> i64 {  // first strip > t of this workgroup's range with entries in the row block, or -1
+    for (;;) {
+        if (p == 0) {
+            i64 c;
+            for (;;) {  // the next cell with entries; a cell without takes part in the scan with sizes of zero
+                c = (i64)atomicAdd(sc.ticket, 1ull);
+                if (c >= ncell || cellptr[c + 1] > cellptr[c]) break;
+                tall_scan_put(sc, c, 1ull, 0ull, 0ull);
+            }
+            s_cell = c;
+        }
+        __syncthreads();
+        SLP_TB_PROF(0);
+        const i64 cell = s_cell;
+        if (cell >= ncell) break;
+        // cell = (row block b, strip t); the packet stream it belongs to: strip range sr of S (S > 1: few, tall row blocks whose
+        // strips are shared by S workgroups of the product kernel -- see tall_geometry)
+        const i64 b = cell / T, t = cell % T;
+        const i64 t_end = S > 1 ? T * (tall_range_of(t, T, S) + 1) / S : T;
+        i64 tn = -1;  // next strip of the stream with entries in the row block: its x-tile rides on this cell's first packet
         for (i64 u = t + 1; u < t_end; ++u)
-            if (cellptr[b * T + u + 1] > cellptr[b * T + u]) return u;
-        return -1;
-    };
-
-    i64 t = next_cell(t_begin - 1);
-    empty_packet(tile_of(t));  // the x-tile of the first cell rides on a leading packet without items
-    while (t >= 0) {
-        const i64 tn = next_cell(t);
-        const i64 c0 = cellptr[b * T + t];
-        const int n = (int)(cellptr[b * T + t + 1] - c0);
+            if (cellptr[b * T + u + 1] > cellptr[b * T + u]) { tn = u; break; }
+        const i64 c0 = cellptr[cell];
+        const int n = (int)(cellptr[cell + 1] - c0);
         for (int r = p; r < R; r += kTallT) cnt[r] = 0;
         __syncthreads();
+        SLP_TB_PROF(1);
         for (int i = p; i < n; i += kTallT) {
             const unsigned int r = (unsigned int)(keys[c0 + i] >> (kTallIdBits + kTallColBits)) & ((1u << kTallRowBits) - 1);
             const unsigned int rp = i > 0 ? (unsigned int)(keys[c0 + i - 1] >> (kTallIdBits + kTallColBits)) & ((1u << kTallRowBits) - 1) : ~0u;
@@ -220,6 +268,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
             atomicAdd(&cnt[r], 1u);
         }
         __syncthreads();
+        SLP_TB_PROF(2);
         // Sorted positions: rows with entries, by min(count, 6) descending and, inside a count, by their BANK CLASS
         // rho = row % 32 (the LDS bank pair of the row's running sum in the product kernel): 192 buckets.
         // Thread (i, rho) = p walks the rows rho + 32 m of its bank class for a range of m; an exclusive scan over the 32
@@ -256,6 +305,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
             for (int cl = kTallBuckets; cl >= 1; --cl)
                 bcnt[(kTallBuckets - cl) * 32 + p] = (unsigned int)(((cl > 3 ? ta : tb) >> (21 * ((cl > 3 ? kTallBuckets : 3) - cl))) & 0x1fffffu);
         __syncthreads();
+        SLP_TB_PROF(3);
         if (p < kWave) {   // exclusive scan of the 192 bucket counts by one wave: three per lane (one thread walking them was
             const unsigned int c0 = bcnt[3 * p], c1 = bcnt[3 * p + 1], c2 = bcnt[3 * p + 2];  // 8 of the ~30 us a cell takes)
             unsigned int inc = c0 + c1 + c2;
@@ -271,6 +321,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
             if (p == kWave - 1) bstart[kTallBuckets * 32] = inc;
         }
         __syncthreads();
+        SLP_TB_PROF(4);
         for (int m = m0; m < m1; ++m) {
             const unsigned int r = (unsigned int)((p & 31) + 32 * m), c = cnt[r];
             if (c) {
@@ -282,6 +333,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
             }
         }
         __syncthreads();
+        SLP_TB_PROF(5);
         const unsigned int npos = bstart[kTallBuckets * 32];
         const unsigned int n2 = bstart[(kTallBuckets - 1) * 32];  // rows with two or more entries come first
         // Dealing rows to lanes.  Sparse cells (all rows with two or more entries fit the 1024 lanes -- the regime this
@@ -310,7 +362,9 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
                     pos0 = bs[rho] + i;  // a row of the lane's own bank class
                 } else {                 // the u-th lane without one takes the u-th row without a lane
                     unsigned int u = i - nr;
+                    #pragma nounroll
                     for (unsigned int r = 0; r < rho; ++r) { const unsigned int nl = lanes_of(r), rr = bs[r + 1] - bs[r]; u += nl > rr ? nl - rr : 0u; }
+                    #pragma nounroll
                     for (unsigned int r = 0; r < 32u; ++r) {
                         const unsigned int nl = lanes_of(r), rr = bs[r + 1] - bs[r], spare = rr > nl ? rr - nl : 0u;
                         if (u < spare) { pos0 = bs[r] + nl + u; break; }
@@ -338,6 +392,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
             nown = before >= n1 ? 0u : (want < n1 - before ? want : n1 - before);
             if (p < 32) spare1[p] = n1 > all ? n1 - all : 0u;  // rows of the class nobody of the class takes
             __syncthreads();
+            SLP_TB_PROF(6);
             // ... then, for what is still missing, the rows left over in other classes: in lane order
             unsigned long long total;
             left0 = (unsigned int)tall_block_scan(want - nown, wtot, &total);
@@ -356,6 +411,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
             if (q >= nleft) return npos;
             const unsigned int *b1 = bstart + (kTallBuckets - 1) * 32;
             unsigned int u = left0 + q;
+            #pragma nounroll
             for (unsigned int r = 0; r < 32u; ++r) {
                 if (u < spare1[r]) return b1[r + 1] - spare1[r] + u;
                 u -= spare1[r];
@@ -384,7 +440,24 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
         }
         nlane[p] = cover;
         __syncthreads();
+        SLP_TB_PROF(7);
         const unsigned int longest = nlane[0];
+        // The cell's sizes from the envelope alone: slot k is as wide as the lanes whose envelope exceeds k, so the slots of all
+        // packets hold sum_p cover[p] words; the fifth bytes take a word per lane of slot 8 g and of slot 8 g + 4 of every packet g.
+        // A cell's payload is rounded up to 16 bytes (every stream then starts 16-byte aligned).
+        unsigned long long cw;
+        {
+            unsigned long long w = cover;
+            if (DICT) w += (cover + 7u) / 8u + (cover > 4u ? (cover - 4u + 7u) / 8u : 0u);
+            (void)tall_block_scan(w, wtot, &cw);
+        }
+        const unsigned long long cell_w = (cw + 3ull) & ~3ull, cell_p = longest ? (longest + kTallSlots - 1) / kTallSlots : 1u;
+        if (p == 0) tall_scan_put(sc, cell, 1ull, cell_w, cell_p);  // the cell's sizes stand: later cells need not wait for more
+        bool fits = true;
+        unsigned int *pay = nullptr;
+        double *payv = nullptr;
+        TallPkt *pk = nullptr;
+        unsigned int woff = 0, npk = 0;  // payload offset inside the cell / packets of the cell so far (uniform)
         // the lane's cursor over its own list: its q-th row (sorted position mypos), entry s of that row
         unsigned int q = 0, s = 0, mypos = rowpos(0);
         unsigned int myrow = mypos < npos ? posrow[mypos] : 0u, mycnt = mypos < npos ? cnt[myrow] : 0u;
@@ -401,38 +474,90 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
                 width[p] = (unsigned int)lo;
             }
             __syncthreads();
+            SLP_TB_PROF(8);
             unsigned int wd[kTallSlots], words = 0;
             for (int j = 0; j < kTallSlots; ++j) { wd[j] = width[j]; words += wd[j]; }
             const unsigned int hi0 = words, hi1 = words + wd[0];
             if (DICT) words += wd[0] + wd[4];
-            if (WRITE) {
+            // The lane's items of this packet in three steps, so that their keys are fetched TOGETHER (one after the other, each
+            // waited for before the cursor moved on, they were 5-8 dependent L2 round trips per cell): where the keys lie (the
+            // cursor's walk: LDS only), the loads, the items.  A lane inside a slot whose list has ended stores a skip item: row
+            // field 0 = the product kernel's scratch cell, like the zero a load past the buffer descriptor returns for a lane
+            // outside the slot.
+            unsigned int kofs[kTallSlots], have = 0;
+#pragma unroll
+            for (int j = 0; j < kTallSlots; ++j) {
+                kofs[j] = 0;
+                if ((unsigned)p < wd[j] && mypos < npos) {
+                    kofs[j] = rstart[myrow] + s;
+                    have |= 1u << j;
+                    if (++s == mycnt) {
+                        ++q; s = 0;
+                        mypos = rowpos(q);
+                        myrow = mypos < npos ? posrow[mypos] : 0u;
+                        mycnt = mypos < npos ? cnt[myrow] : 0u;
+                    }
+                }
+            }
+            unsigned long long key[kTallSlots];
+            double value[kTallSlots];
+#pragma unroll
+            for (int j = 0; j < kTallSlots; ++j) {
+                key[j] = (have >> j & 1u) ? keys[c0 + kofs[j]] : 0ull;
+                value[j] = (!DICT && (have >> j & 1u)) ? svals[c0 + kofs[j]] : 0.0;
+            }
+            if (g == 0) {
+                // Where the cell's packets go: the sizes of all cells before it, summed backwards by one wave from the cells' own
+                // sizes until a cell with its sums is met (behind the loads above: their latency and the look-back's overlap).
+                if (p < kWave) {
+                    unsigned long long bw = 0, bp = 0;
+                    for (i64 j = cell - 1; j >= 0; j -= kWave) {
+                        const i64 qc = j - p;   // lane p looks at the p-th cell back
+                        unsigned int st = 2u;   // (before the first cell: sums of zero)
+                        unsigned long long w = 0, k = 0;
+                        if (qc >= 0) st = tall_scan_get(sc, qc, &w, &k);
+                        const unsigned long long summed = __ballot(st == 2u);
+                        const int f = summed ? __ffsll((long long)summed) - 1 : kWave;  // the nearest cell that has its sums
+                        if (p > f) { w = 0; k = 0; }
+#pragma unroll
+                        for (int off = kWave / 2; off; off >>= 1) { w += __shfl_xor(w, off, kWave); k += __shfl_xor(k, off, kWave); }
+                        bw += w; bp += k;
+                        if (summed) break;
+                    }
+                    if (p == 0) {
+                        tall_scan_put(sc, cell, 2ull, bw + cell_w, bp + cell_p);
+                        sc.before_w[cell] = bw;
+                        sc.before_p[cell] = bp;
+                        s_before_w = bw;
+                        s_before_p = bp;
+                    }
+                }
+                __syncthreads();
+                SLP_TB_PROF(9);
+                fits = (i64)(s_before_w + cell_w) <= cap_w && (i64)(s_before_p + cell_p) <= cap_p;  // uniform
+                pay = spay + s_before_w;
+                payv = DICT ? nullptr : spayv + s_before_w;
+                pk = sdir + s_before_p;
+            }
+            if (!fits) break;   // (the host repeats the pass with the exact sizes; the scan itself is complete)
+            {
                 unsigned int *base = pay + woff;
                 unsigned int hb0 = 0, hb1 = 0, so = 0;
+#pragma unroll
                 for (int j = 0; j < kTallSlots; ++j) {
                     if ((unsigned)p < wd[j]) {
-                        // skip item (a lane inside the envelope whose list has ended): row field 0 = the kernel's scratch cell, like
-                        // the zero a load past the buffer descriptor returns for a lane outside the slot
                         unsigned int item = 0u, hib = 0u;
-                        double value = 0.0;
-                        if (mypos < npos) {
-                            const unsigned long long key = keys[c0 + rstart[myrow] + s];
-                            const unsigned int r1 = myrow + 1u;   // the row field holds the local row + 1
+                        if (have >> j & 1u) {
+                            const unsigned int r1 = ((unsigned int)(key[j] >> (kTallIdBits + kTallColBits)) & ((1u << kTallRowBits) - 1)) + 1u;  // local row + 1
                             if (DICT) {
-                                item = ((unsigned int)key & ((1u << (kTallIdBits + kTallColBits)) - 1)) | ((r1 & 0x1ffu) << 23);
+                                item = ((unsigned int)key[j] & ((1u << (kTallIdBits + kTallColBits)) - 1)) | ((r1 & 0x1ffu) << 23);
                                 hib = r1 >> 9;
                             } else {
-                                item = ((unsigned int)(key >> kTallIdBits) & (kTallC - 1)) | (r1 << kTallColBits);
-                                value = svals[c0 + rstart[myrow] + s];
-                            }
-                            if (++s == mycnt) {
-                                ++q; s = 0;
-                                mypos = rowpos(q);
-                                myrow = mypos < npos ? posrow[mypos] : 0u;
-                                mycnt = mypos < npos ? cnt[myrow] : 0u;
+                                item = ((unsigned int)(key[j] >> kTallIdBits) & (kTallC - 1)) | (r1 << kTallColBits);
                             }
                         }
                         base[so + p] = item;
-                        if (!DICT) payv[woff + so + p] = value;
+                        if (!DICT) payv[woff + so + p] = value[j];
                         if (j < 4) hb0 |= hib << (8 * j);
                         else hb1 |= hib << (8 * (j - 4));
                     }
@@ -442,7 +567,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
                 if (DICT && (unsigned)p < wd[4]) base[hi1 + p] = hb1;
                 if (p == 0) {
                     TallPkt h;
-                    h.off = (unsigned int)woff;
+                    h.off = woff;   // (inside the cell: k_tall_dir adds where the cell lies in its stream)
                     h.xsrc = (g == 0) ? (kPktNewCell | tile_of(tn)) : kNoTile;
                     for (int i = 0; i < 4; ++i) h.c[i] = wd[2 * i] | (wd[2 * i + 1] << 16);
                     h.strip = (unsigned int)t;
@@ -453,14 +578,82 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
             woff += words;
             ++npk;
             __syncthreads();  // width[] is rewritten by the next packet
+            SLP_TB_PROF(10);
         }
-        t = tn;
     }
-    // whole groups of 2 x depth packets, then 2 x depth more that are only ever prefetched (the deeper pipeline's count
-    // serves both kernels)
-    while (npk % (2 * kTallDepth)) empty_packet(kNoTile);
-    for (int i = 0; i < 2 * kTallDepth; ++i) empty_packet(kNoTile);
-    if (!WRITE && p == 0) { sizes[2 * v] = woff; sizes[2 * v + 1] = npk; }
+}
+
+// What the single pass is given room for: per cell of n entries, min(n, 1024) lists of ceil(n / 1024) items (what the dealing
+// aims at; rows longer than that and the envelope's skip items come out of the margin the host adds).
+template <bool DICT>
+__global__ __launch_bounds__(kBlock) void k_tall_estimate(i64 ncell, const i64 *__restrict__ cellptr, unsigned long long *__restrict__ est) {
+    unsigned long long w = 0, k = 0;
+    for (i64 c = (i64)blockIdx.x * kBlock + threadIdx.x; c < ncell; c += (i64)gridDim.x * kBlock) {
+        const unsigned long long n = (unsigned long long)(cellptr[c + 1] - cellptr[c]);
+        if (!n) continue;
+        const unsigned long long L = n < (unsigned)kTallT ? n : (unsigned)kTallT, tau = (n + kTallT - 1) / kTallT;
+        unsigned long long cw = L * tau;
+        if (DICT) cw += L * ((tau + 7) / 8 + (tau > 4 ? (tau - 4 + 7) / 8 : 0));
+        w += (cw + 3ull) & ~3ull;
+        k += (tau + kTallSlots - 1) / kTallSlots;
+    }
+#pragma unroll
+    for (int off = kWave / 2; off; off >>= 1) { w += __shfl_xor(w, off, kWave); k += __shfl_xor(k, off, kWave); }
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicAdd(&est[0], w); atomicAdd(&est[1], k); }
+}
+
+// The streams' extents from the scan: stream v = (row block, strip range) = the cells [cs, ce): payload words before it
+// (its base: the payload is compact in cell order), its words, packets before it, its packets.  Only cells with entries carry
+// sums: the sums in front of a cell are those of the nearest such cell before it (all streams together walk every cell at most
+// twice).
+__global__ void k_tall_streams(i64 V, i64 T, int S, const i64 *__restrict__ cellptr, TallScan sc, i64 *__restrict__ ext) {
+    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (i64)gridDim.x * blockDim.x) {
+        const i64 b = v / S, cs = b * T + T * (v % S) / S, ce = b * T + T * (v % S + 1) / S;
+        auto before = [&](i64 c, i64 *w, i64 *k) {  // payload words / packets of the cells [0, c)
+            for (--c; c >= 0 && cellptr[c + 1] == cellptr[c];) --c;
+            *w = c >= 0 ? (i64)(sc.w[c] & kScanMask) : 0;
+            *k = c >= 0 ? (i64)(sc.p[c] & kScanMask) : 0;
+        };
+        i64 w0, p0, w1, p1;
+        before(cs, &w0, &p0);
+        before(ce, &w1, &p1);
+        ext[4 * v] = w0;
+        ext[4 * v + 1] = w1 - w0;
+        ext[4 * v + 2] = p0;
+        ext[4 * v + 3] = p1 - p0;
+    }
+}
+
+// The streams' packet directories: [leading packet without items: the x-tile of the stream's first cell] [the cells' packets,
+// payload offsets now relative to the stream] [packets without items up to a whole group of 2 x depth, then 2 x depth more that are
+// only ever prefetched].  A thread per cell, then a thread per stream for its ends.
+__global__ void k_tall_dir(i64 ncell, i64 V, i64 T, int S, const i64 *__restrict__ cellptr, TallScan sc, const i64 *__restrict__ ext,
+                           const i64 *__restrict__ pkt_ptr, const TallPkt *__restrict__ sdir, TallPkt *__restrict__ dir) {
+    const i64 i0 = (i64)blockIdx.x * blockDim.x + threadIdx.x, step = (i64)gridDim.x * blockDim.x;
+    for (i64 c = i0; c < ncell; c += step) {
+        if (cellptr[c + 1] == cellptr[c]) continue;
+        const i64 pk0 = (i64)sc.before_p[c], np = (i64)(sc.p[c] & kScanMask) - pk0, w0 = (i64)sc.before_w[c];
+        const i64 b = c / T, t = c % T, v = b * S + (S > 1 ? tall_range_of(t, T, S) : 0);
+        TallPkt *out = dir + pkt_ptr[v] + 1 + (pk0 - ext[4 * v + 2]);
+        for (i64 j = 0; j < np; ++j) {
+            TallPkt h = sdir[pk0 + j];
+            h.off += (unsigned int)(w0 - ext[4 * v]);
+            out[j] = h;
+        }
+    }
+    for (i64 v = i0; v < V; v += step) {
+        const i64 b = v / S, t_begin = T * (v % S) / S, t_end = T * (v % S + 1) / S;
+        i64 first = -1;
+        for (i64 u = t_begin; u < t_end; ++u)
+            if (cellptr[b * T + u + 1] > cellptr[b * T + u]) { first = u; break; }
+        TallPkt h;
+        h.off = 0; h.xsrc = first >= 0 ? (unsigned int)(first * (i64)kTallC) : kNoTile;
+        h.c[0] = h.c[1] = h.c[2] = h.c[3] = 0; h.strip = 0; h.pad = 0;
+        dir[pkt_ptr[v]] = h;
+        h.off = (unsigned int)ext[4 * v + 1];
+        h.xsrc = kNoTile;
+        for (i64 k = pkt_ptr[v] + 1 + ext[4 * v + 3]; k < pkt_ptr[v + 1]; ++k) dir[k] = h;
+    }
 }
 // ---- host side ---------------------------------------------------------------------------------------------------------
 // Rows per block: as tall as the LDS allows, and such that the blocks are (nearly) a multiple of the CU count -- every
@@ -507,19 +700,6 @@ static i64 tall_pass_nnz() {
     const char *e = getenv("SLP_TALL_PASS_NNZ");
     const i64 v = e ? atoll(e) : 500000000ll;
     return v > 0 ? v : 500000000ll;
-}
-
-template <bool DICT>
-static void tall_launch_build(bool write, unsigned V, int R, i64 T, int S, i64 ncol, const unsigned long long *sorted, const double *svals,
-                              const i64 *cellptr, i64 *sizes, const i64 *base, const i64 *pkt, TallPkt *dir, unsigned int *pay, double *vals) {
-    hipStream_t st = ctx().stream;
-    if (write)
-        hipLaunchKernelGGL((k_tall_build<true, DICT>), dim3(V), dim3(kTallT), 0, st, R, T, S, ncol, sorted, svals, cellptr, sizes, base, pkt, dir,
-                           pay, vals);
-    else
-        hipLaunchKernelGGL((k_tall_build<false, DICT>), dim3(V), dim3(kTallT), 0, st, R, T, S, ncol, sorted, svals, cellptr, sizes, base, pkt, dir,
-                           pay, vals);
-    SLP_HIP(hipGetLastError());
 }
 
 // The tall-cell copy of `a` (transposed: of a^T) straight from the CSR of `a`.  Keys are drawn and sorted in passes over ranges
@@ -617,31 +797,78 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     DevBuf<i64> cellptr((size_t)ncell + 1);
     hipLaunchKernelGGL(k_tall_cellptr, dim3(grid_for(a.nnz, kBlock)), dim3(kBlock), 0, st, a.nnz, ncell, sorted.p, cellptr.p);
     SLP_HIP(hipGetLastError());
-    Phase p2("  tall: packets (sizes + fill)");
-    DevBuf<i64> sizes(2 * (size_t)V);
-    if (dict) tall_launch_build<true>(false, (unsigned)V, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, sizes.p, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else tall_launch_build<false>(false, (unsigned)V, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, sizes.p, nullptr, nullptr, nullptr, nullptr, nullptr);
-    std::vector<i64> hs(2 * (size_t)V), hbase((size_t)V + 1), hpkt((size_t)V + 1);
-    sizes.download(hs.data(), hs.size());
-    const i64 limit = dict ? ((i64)1 << 28) : ((i64)1 << 27);  // payload words of one workgroup (32-bit byte offsets; fp64: 2 x)
-    hbase[0] = hpkt[0] = 0;
-    for (i64 v = 0; v < V; ++v) {
-        if (hs[2 * v] >= limit) return false;  // a workgroup's payload outgrows its 32-bit byte offsets: another format serves
-        hbase[v + 1] = hbase[v] + ((hs[2 * v] + 3) & ~(i64)3);  // 16-byte aligned streams
-        hpkt[v + 1] = hpkt[v] + hs[2 * v + 1];
+    Phase p2("  tall: packets (one pass)");
+    DevBuf<unsigned long long> scan(4 * (size_t)ncell + 1), est(2);
+    TallScan sc;
+    sc.w = scan.p; sc.p = scan.p + ncell; sc.ticket = scan.p + 2 * ncell; sc.before_w = sc.ticket + 1; sc.before_p = sc.before_w + ncell;
+    est.zero();
+    if (dict) hipLaunchKernelGGL((k_tall_estimate<true>), dim3(grid_for(ncell, kBlock)), dim3(kBlock), 0, st, ncell, cellptr.p, est.p);
+    else hipLaunchKernelGGL((k_tall_estimate<false>), dim3(grid_for(ncell, kBlock)), dim3(kBlock), 0, st, ncell, cellptr.p, est.p);
+    SLP_HIP(hipGetLastError());
+    unsigned long long hest[2];
+    est.download(hest, 2);
+    // room for the pass: the estimate + 6 % (measured need on the benchmark's LPs: + 0.3 ... 2 %); the directory is 32 bytes per ~20 KB cell
+    i64 cap_w = (i64)hest[0] + (i64)hest[0] / 16 + 65536, cap_p = 2 * (i64)hest[1] + 4096;
+    if (const char *e = getenv("SLP_TALL_BUILD_ROOM")) cap_w = std::max<i64>(4, (i64)((double)hest[0] * atof(e)));  // (tests: force the second attempt)
+    i64 tot_w = 0, tot_p = 0;
+    DevBuf<i64> ext(4 * (size_t)V);
+    std::vector<i64> hext(4 * (size_t)V);
+    DevBuf<unsigned int> spay, sdir;
+    DevBuf<double> spayv;
+    for (int attempt = 0;; ++attempt) {
+        spay.alloc((size_t)cap_w + 64);
+        sdir.alloc((size_t)cap_p * 8);
+        if (!dict) spayv.alloc((size_t)cap_w + 64);
+        SLP_HIP(hipMemsetAsync(scan.p, 0, (2 * (size_t)ncell + 1) * sizeof(unsigned long long), st));  // levels and the ticket
+        // as many workgroups as the chip holds at once (the kernel's LDS: one per compute unit); each takes cells until none is left
+        const unsigned grid = (unsigned)std::min<i64>(ncell, (i64)ctx().num_cu);
+        if (dict) hipLaunchKernelGGL((k_tall_build<true>), dim3(grid), dim3(kTallT), 0, st, R, T, S, ncell, sorted.p, (const double *)nullptr, cellptr.p, sc,
+                                     cap_w, cap_p, reinterpret_cast<TallPkt *>(sdir.p), spay.p, (double *)nullptr);
+        else hipLaunchKernelGGL((k_tall_build<false>), dim3(grid), dim3(kTallT), 0, st, R, T, S, ncell, sorted.p, svals.p, cellptr.p, sc,
+                                cap_w, cap_p, reinterpret_cast<TallPkt *>(sdir.p), spay.p, spayv.p);
+        hipLaunchKernelGGL(k_tall_streams, dim3(grid_for(V, kBlock)), dim3(kBlock), 0, st, V, T, S, cellptr.p, sc, ext.p);
+        SLP_HIP(hipGetLastError());
+        ext.download(hext.data(), hext.size());
+#ifdef SLP_TALL_BUILD_PROF
+        {
+            unsigned long long hp[16], zero[16] = {0};
+            SLP_HIP(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_tb_prof), sizeof hp));
+            SLP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tb_prof), zero, sizeof zero));
+            fprintf(stderr, "[tall build prof] cells %lld, us per cell and mark:", (long long)ncell);
+            for (int i = 0; i < 11; ++i) fprintf(stderr, " %d:%.2f", i, (double)hp[i] / 100.0 / (double)ncell);
+            fprintf(stderr, "\n");
+        }
+#endif
+        tot_w = hext[4 * (V - 1)] + hext[4 * (V - 1) + 1];
+        tot_p = hext[4 * (V - 1) + 2] + hext[4 * (V - 1) + 3];
+        if (tot_w <= cap_w && tot_p <= cap_p) break;
+        SLP_REQUIRE(attempt == 0, "tall_build: the pass with the exact sizes did not fit");
+        cap_w = tot_w; cap_p = tot_p;   // some cell did not fit and wrote nothing: once more, with the sizes the pass has found
     }
-    DevBuf<i64> dbase, dpkt;
-    dbase.upload(hbase.data(), hbase.size());
+    sorted.release();  // (the keys are spent: their memory serves the copy itself)
+    svals.release();
+    std::vector<i64> hbase((size_t)V + 1), hpkt((size_t)V + 1);
+    const i64 limit = dict ? ((i64)1 << 28) : ((i64)1 << 27);  // payload words of one workgroup (32-bit byte offsets; fp64: 2 x)
+    hpkt[0] = 0;
+    for (i64 v = 0; v < V; ++v) {
+        if (hext[4 * v + 1] >= limit) return false;  // a workgroup's payload outgrows its 32-bit byte offsets: another format serves
+        hbase[v] = hext[4 * v];
+        const i64 np = 1 + hext[4 * v + 3];  // whole groups of 2 x depth packets, then 2 x depth more that are only ever prefetched
+        hpkt[v + 1] = hpkt[v] + (np + 2 * kTallDepth - 1) / (2 * kTallDepth) * (2 * kTallDepth) + 2 * kTallDepth;
+    }
+    hbase[V] = tot_w;
+    DevBuf<i64> dpkt;
     dpkt.upload(hpkt.data(), hpkt.size());
     f.tall_dir.emplace_back((size_t)hpkt[V] * 8);
-    f.tall_pay.emplace_back((size_t)hbase[V] + 64);
+    f.tall_pay.emplace_back((size_t)tot_w + 64);
     DevBuf<unsigned int> &dir = f.tall_dir.back(), &pay = f.tall_pay.back();
     double *vals = nullptr;
-    if (!dict) { f.tall_val.emplace_back((size_t)hbase[V] + 64); vals = f.tall_val.back().p; }
-    if (dict) tall_launch_build<true>(true, (unsigned)V, R, T, S, ncolF, sorted.p, nullptr, cellptr.p, nullptr, dbase.p, dpkt.p,
-                                      reinterpret_cast<TallPkt *>(dir.p), pay.p, nullptr);
-    else tall_launch_build<false>(true, (unsigned)V, R, T, S, ncolF, sorted.p, svals.p, cellptr.p, nullptr, dbase.p, dpkt.p,
-                                  reinterpret_cast<TallPkt *>(dir.p), pay.p, vals);
+    if (!dict) { f.tall_val.emplace_back((size_t)tot_w + 64); vals = f.tall_val.back().p; }
+    SLP_HIP(hipMemcpyAsync(pay.p, spay.p, (size_t)tot_w * sizeof(unsigned int), hipMemcpyDeviceToDevice, st));
+    if (vals) SLP_HIP(hipMemcpyAsync(vals, spayv.p, (size_t)tot_w * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_tall_dir, dim3(grid_for(std::max<i64>(ncell, V), kBlock)), dim3(kBlock), 0, st, ncell, V, T, S, cellptr.p, sc, ext.p, dpkt.p,
+                       reinterpret_cast<const TallPkt *>(sdir.p), reinterpret_cast<TallPkt *>(dir.p));
+    SLP_HIP(hipGetLastError());
     std::vector<TallWg> wg((size_t)V);
     for (i64 v = 0; v < V; ++v) {
         const i64 b = v / S;

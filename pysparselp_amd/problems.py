@@ -85,7 +85,7 @@ def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1
 
     ``chunks > 1``: the same LP as a ``ChunkedDeviceMatrix`` -- the rows are generated, converted and released ``chunks``
     row ranges at a time, so the CSR of the whole matrix never exists (the generator is keyed by the global row: every
-    chunking draws the same matrix, and ``b_upper`` is taken from each chunk's CSR exactly as from the whole one).
+    chunking draws the same matrix; ``b_upper`` is taken once all chunks stand, from the chunked matrix's own product).
     ``chunked=True``: a ``ChunkedDeviceMatrix`` even for one chunk -- the rows are converted into their product copies and the
     CSR is released at once (a row block of the block-splitting ADMM at BASELINE config 5: only ever multiplied).
     ``columns=False``: only ``b_upper`` is formed (``feasible_x, c, lb, ub`` are ``None``): the column vectors do not depend on
@@ -99,15 +99,10 @@ def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1
         return a, xf, c, lb, ub, b
     cuts = ChunkedDeviceMatrix.cuts(rows, max(1, chunks))
     a = ChunkedDeviceMatrix(n, expect_chunks=len(cuts) - 1)
-    b = np.empty(rows)
-    xf = c = lb = ub = None
-    for k, (r0, r1) in enumerate(zip(cuts, cuts[1:])):
-        chunk = DeviceMatrix.random(r1 - r0, n, density, seed, row_offset + r0)
-        got = chunk.random_lp_vectors(density, seed, row_offset + r0, columns=(k == 0 and columns))
-        if k == 0:
-            xf, c, lb, ub = got[:4]
-        b[r0:r1] = got[4]
-        a.append(chunk)
+    for r0, r1 in zip(cuts, cuts[1:]):
+        a.append(DeviceMatrix.random(r1 - r0, n, density, seed, row_offset + r0))
+    # b_upper = ceil((A x_f + ...) 1000) / 1000 of all rows at once, through the product copies (one launch of the fused product)
+    xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset, columns=columns)
     return a, xf, c, lb, ub, b
 
 

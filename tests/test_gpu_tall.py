@@ -195,3 +195,61 @@ def test_strip_range_split_for_short_very_wide_blocks():
     for split in ("2", "-1"):
         assert np.max(np.abs(got[split][0] - ref) / (1e-300 + mag)) < 1e-13
     assert not np.array_equal(got["2"][0], ref) or not np.array_equal(got["-1"][0], ref)  # (the split really happened)
+
+
+def test_single_pass_build_repeats_with_the_exact_sizes_when_its_room_was_short(monkeypatch):
+    """The copy is written in ONE pass over the cells (ticket order, decoupled look-back over the cells' sizes) into room sized
+    by an estimate; a cell that would not fit writes nothing and the pass is repeated with the sizes it has found.  Forced here
+    by halving the room (SLP_TALL_BUILD_ROOM): same copy -- byte count, products against the oracle bit for bit -- as the
+    build whose first attempt fits, with both item forms, for a single and for many row blocks, and with the strip-range split."""
+    from pysparselp_amd import _lib
+    from pysparselp_amd.device import DeviceMatrix
+
+    a_host = _random(40_000, 300_000, 2e-4, seed=21)
+    rng = np.random.RandomState(4)
+    x, y = rng.randn(a_host.shape[1]), rng.randn(a_host.shape[0])
+    ax, aty = oracle.matvec(oracle.as_csr(a_host), x), oracle.rmatvec(oracle.as_csr(a_host), y)
+    for r in (None, 1024):
+        if r:
+            monkeypatch.setenv("SLP_TALL_R", str(r))
+        sizes = []
+        for room in (None, "0.5", "0.01"):
+            if room:
+                monkeypatch.setenv("SLP_TALL_BUILD_ROOM", room)
+            else:
+                monkeypatch.delenv("SLP_TALL_BUILD_ROOM", raising=False)
+            a = DeviceMatrix.from_csr(a_host)
+            try:
+                for policy, want in ((0, 6), (1, 7)):
+                    a.set_format(policy)
+                    assert a.spmv_kernel(False) == want and a.spmv_kernel(True) == want
+                    assert np.array_equal(a.matvec(x), ax) and np.array_equal(a.rmatvec(y), aty), (r, room, policy)
+                    sizes.append((int(_lib.lib().slp_matrix_format_bytes(a._h, 0)), int(_lib.lib().slp_matrix_format_bytes(a._h, 1))))
+            finally:
+                a.close()
+        assert sizes[0:2] == sizes[2:4] == sizes[4:6], sizes
+    monkeypatch.delenv("SLP_TALL_BUILD_ROOM", raising=False)
+
+
+def test_b_upper_of_the_generated_lp_through_the_product_copies():
+    """``random_lp_on_device(chunks=...)`` takes ``b_upper = ceil((A x_f + ...) 1000) / 1000`` from the chunked matrix's own
+    product once all chunks stand (the CSR kernel it used per chunk gathered every x from L2: 11 x the CSR's bytes in HBM traffic at
+    1e7 columns): the same vector as from the CSR of the unchunked matrix, and x_f is feasible for it."""
+    from pysparselp_amd.problems import random_lp_on_device
+
+    n, m, dens, seed = 200_000, 60_000, 5e-4, 6
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, dens, seed=seed)
+    ch, xf2, c2, lb2, ub2, b2 = random_lp_on_device(n, m, dens, seed=seed, chunks=3)
+    try:
+        assert ch.chunks == 3 and ch.spmv_kernel(False) == 6
+        assert np.array_equal(xf, xf2) and np.array_equal(c, c2) and np.array_equal(lb, lb2) and np.array_equal(ub, ub2)
+        assert np.array_equal(b, b2)
+        # (the ceiling is taken of (A x_f) * 1000 as rounded: b_upper may lie an ulp below A x_f, as in the reference)
+        assert np.all(ch.matvec(xf) <= b2 + 1e-12) and np.all(lb <= xf) and np.all(xf <= ub)
+        ax = oracle.matvec(oracle.as_csr(a.download()), xf)
+        assert np.all(ax <= b2 + 1e-12) and np.all(b2 - ax < 1e-3 + 12.0)   # (|rand_sparse| adds to a few rows)
+        assert np.array_equal(ch.matvec(xf), ax)
+    finally:
+        a.close()
+        ch.close()
+

@@ -20,4 +20,12 @@ for t, name in ((False, "Ax"), (True, "ATy")):
     out[name + "_kernel"] = a.spmv_kernel(t)
     out[name + "_ms"] = a.bench_spmv(t, reps=reps)
     out[name + "_copy_bytes"] = int(lib.slp_matrix_format_bytes(a._h, int(t)))
+if os.environ.get("TALL_ONLY_HASH"):   # the products themselves, for comparing two builds of the copy on one box
+    import hashlib
+
+    import numpy as np
+    rng = np.random.RandomState(1)
+    x, y = rng.randn(cols), rng.randn(rows)
+    out["Ax_sha"] = hashlib.sha256(a.matvec(x).tobytes()).hexdigest()[:16]
+    out["ATy_sha"] = hashlib.sha256(a.rmatvec(y).tobytes()).hexdigest()[:16]
 print(json.dumps(out))
