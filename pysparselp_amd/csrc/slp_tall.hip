@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_tall_sorted(i64 nnz, const i32 *__re
 }
 
 template <bool TR>
-__global__ __launch_bounds__(kBlock) void k_tall_keys(i64 r0, i64 nrow, int R, i64 T, i64 b0, int D, const unsigned long long *__restrict__ dkeys,
+__global__ __launch_bounds__(kBlock) void k_tall_keys(i64 r0, i64 nrow, int R, i64 T, int cshift, i64 b0, int D, const unsigned long long *__restrict__ dkeys,
                                                       const i64 *__restrict__ ptr, const i32 *__restrict__ idx,
                                                       const double *__restrict__ val, const i64 *__restrict__ lo,
                                                       const i64 *__restrict__ opos, i64 obase, unsigned long long *__restrict__ keys,
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_tall_keys(i64 r0, i64 nrow, int R, i
             }
             const i64 trow = TR ? (i64)j : r, tcol = TR ? r : (i64)j;  // row / column of the copy
             const unsigned long long b = (unsigned long long)(trow / R - b0), rl = (unsigned long long)(trow % R);
-            const unsigned long long t = (unsigned long long)(tcol / kTallC), cl = (unsigned long long)(tcol % kTallC);
+            const unsigned long long t = (unsigned long long)(tcol >> cshift), cl = (unsigned long long)(tcol & (((i64)1 << cshift) - 1));
             keys[o + (k - s)] = ((b * (unsigned long long)T + t) << kTallCellShift) | (rl << (kTallIdBits + kTallColBits)) | (cl << kTallIdBits) |
                                 (unsigned long long)id;
             if (kvals) kvals[o + (k - s)] = val[k];
@@ -214,7 +214,7 @@ __device__ __forceinline__ i64 tall_range_of(i64 t, i64 T, int S) {  // the stri
 
 // DICT: 5-byte items (value id inside); !DICT: 4-byte items (column | row << 12) + the fp64 value in a parallel array at the same offsets.
 template <bool DICT>
-__global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 ncell, const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int cshift, i64 ncell, const unsigned long long *__restrict__ keys,
                                                        const double *__restrict__ svals, const i64 *__restrict__ cellptr, TallScan sc,
                                                        i64 cap_w, i64 cap_p, TallPkt *__restrict__ sdir,
                                                        unsigned int *__restrict__ spay, double *__restrict__ spayv) {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, i64 
 #ifdef SLP_TALL_BUILD_PROF
     unsigned long long tb_last_ = wall_clock64();
 #endif
-    auto tile_of = [&](i64 t) -> unsigned int { return t >= 0 ? (unsigned int)(t * (i64)kTallC) : kNoTile; };
+    auto tile_of = [&](i64 t) -> unsigned int { return t >= 0 ? (unsigned int)(t << cshift) : kNoTile; };
     for (;;) {
         if (p == 0) {
             i64 c;
@@ -627,7 +627,7 @@ __global__ void k_tall_streams(i64 V, i64 T, int S, const i64 *__restrict__ cell
 // The streams' packet directories: [leading packet without items: the x-tile of the stream's first cell] [the cells' packets,
 // payload offsets now relative to the stream] [packets without items up to a whole group of 2 x depth, then 2 x depth more that are
 // only ever prefetched].  A thread per cell, then a thread per stream for its ends.
-__global__ void k_tall_dir(i64 ncell, i64 V, i64 T, int S, const i64 *__restrict__ cellptr, TallScan sc, const i64 *__restrict__ ext,
+__global__ void k_tall_dir(i64 ncell, i64 V, i64 T, int S, int cshift, const i64 *__restrict__ cellptr, TallScan sc, const i64 *__restrict__ ext,
                            const i64 *__restrict__ pkt_ptr, const TallPkt *__restrict__ sdir, TallPkt *__restrict__ dir) {
     const i64 i0 = (i64)blockIdx.x * blockDim.x + threadIdx.x, step = (i64)gridDim.x * blockDim.x;
     for (i64 c = i0; c < ncell; c += step) {
@@ -647,7 +647,7 @@ __global__ void k_tall_dir(i64 ncell, i64 V, i64 T, int S, const i64 *__restrict
         for (i64 u = t_begin; u < t_end; ++u)
             if (cellptr[b * T + u + 1] > cellptr[b * T + u]) { first = u; break; }
         TallPkt h;
-        h.off = 0; h.xsrc = first >= 0 ? (unsigned int)(first * (i64)kTallC) : kNoTile;
+        h.off = 0; h.xsrc = first >= 0 ? (unsigned int)(first << cshift) : kNoTile;
         h.c[0] = h.c[1] = h.c[2] = h.c[3] = 0; h.strip = 0; h.pad = 0;
         dir[pkt_ptr[v]] = h;
         h.off = (unsigned int)ext[4 * v + 1];
@@ -711,7 +711,33 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     if ((dict && (dict->D <= 0 || dict->D > kTallDictMax)) || a.nrow == 0 || a.ncol == 0 || a.nnz == 0) return false;
     const i64 nrowF = transposed ? a.ncol : a.nrow, ncolF = transposed ? a.nrow : a.ncol;
     if (ncolF * 8 >= ((i64)1 << 31)) return false;  // x is addressed through a buffer descriptor with 32-bit byte offsets
-    const i64 T = (ncolF + kTallC - 1) / kTallC;
+    // Strip width (4096, 2048 or 1024 columns; items keep their 12-bit column field): the width whose cells the product kernel is
+    // predicted to walk fastest.  Per stored entry the kernel pays for the bytes of its item (4 + the fifth bytes' words: one per
+    // lane and four list positions) and for its share of the cell: a fixed part (barrier, pipeline, list ends) and the x-tile
+    // (8 C bytes) -- fitted on the 2.5e6-row slices of tools/tall_density_sweep.sh (ms per 2.49e9 entries: 0.393 per byte,
+    // 0.95 + 0.34 C / 4096 per cell of 4000 entries; predictions within 3 % of 10 of the 12 measured cases, 10 % low where a cell's lists
+    // are five items long).  What decides is the cell's size n = R x (entries per row and strip): R is what tall_geometry
+    // leaves of the LDS's 9984 rows once the row blocks are a multiple of the CU count and the rows with two or more entries fit one
+    // per lane, so a denser matrix keeps tall blocks only on narrower strips (density 2e-4 on the slice: 4096 columns -> R = 3256,
+    // 4.25 / 3.76 ms; 2048 -> R = 9766, 3.09 / 3.07 ms), while the metric's density stays on 4096 (0.41 entries per row and strip,
+    // n = 4000; 2048 would halve n: predicted 4.6 ms against 3.26).  SLP_TALL_C forces a width.
+    int cshift = kTallColBits;
+    {
+        double best = 0.0;
+        for (int cs = kTallColBits; cs >= kTallColBits - 2; --cs) {
+            const i64 Tc = (ncolF + ((i64)1 << cs) - 1) >> cs;
+            const double pc = (double)a.nnz / (double)nrowF / (double)Tc;
+            int Rc = 0, Sc = 1;
+            tall_geometry(nrowF, Tc, pc, transposed ? 0 : block_multiple, &Rc, &Sc);
+            const double n = std::max(1.0, (double)std::min<i64>(Rc, nrowF) * pc), tau = std::ceil(n / kTallT);
+            const double bytes = dict ? 4.0 + 4.0 * std::min(n, (double)kTallT) * std::ceil(tau / 4.0) / n : 12.0;
+            const double cost = 0.393 * bytes + (0.95 + 0.34 * (double)((i64)1 << cs) / kTallC) * 4000.0 / n;
+            if (cs == kTallColBits || cost < best) { best = cost; cshift = cs; }
+        }
+        if (const char *e = getenv("SLP_TALL_C")) { const int c = atoi(e); if (c == 4096 || c == 2048 || c == 1024) cshift = c == 4096 ? 12 : (c == 2048 ? 11 : 10); }
+    }
+    const i64 Cw = (i64)1 << cshift;
+    const i64 T = (ncolF + Cw - 1) / Cw;
     int R = 0, S = 1;
     tall_geometry(nrowF, T, (double)a.nnz / (double)nrowF / (double)T, transposed ? 0 : block_multiple, &R, &S);
     const i64 B = (nrowF + R - 1) / R, ncell = B * T, V = B * S;  // V workgroups: (row block, strip range)
@@ -769,10 +795,10 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
             if (!dict && transposed) kvals.alloc((size_t)n_p);
             const i64 scan_rows = transposed ? a.nrow : f1 - f0, r0 = transposed ? 0 : f0;
             if (transposed)
-                hipLaunchKernelGGL((k_tall_keys<true>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, (i64)0, D, dk,
+                hipLaunchKernelGGL((k_tall_keys<true>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, cshift, (i64)0, D, dk,
                                    a.ptr.p, a.idx.p, a.val.p, lo.p, opos.p, obase, keys.p, kvals.p, bad.p);
             else
-                hipLaunchKernelGGL((k_tall_keys<false>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, (i64)0, D, dk,
+                hipLaunchKernelGGL((k_tall_keys<false>), dim3(grid_for(scan_rows * kWave, kBlock)), dim3(kBlock), 0, st, r0, scan_rows, R, T, cshift, (i64)0, D, dk,
                                    a.ptr.p, a.idx.p, a.val.p, (const i64 *)nullptr, (const i64 *)nullptr, obase, keys.p, (double *)nullptr, bad.p);
             SLP_HIP(hipGetLastError());
             size_t bytes = 0;
@@ -822,9 +848,9 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
         SLP_HIP(hipMemsetAsync(scan.p, 0, (2 * (size_t)ncell + 1) * sizeof(unsigned long long), st));  // levels and the ticket
         // as many workgroups as the chip holds at once (the kernel's LDS: one per compute unit); each takes cells until none is left
         const unsigned grid = (unsigned)std::min<i64>(ncell, (i64)ctx().num_cu);
-        if (dict) hipLaunchKernelGGL((k_tall_build<true>), dim3(grid), dim3(kTallT), 0, st, R, T, S, ncell, sorted.p, (const double *)nullptr, cellptr.p, sc,
+        if (dict) hipLaunchKernelGGL((k_tall_build<true>), dim3(grid), dim3(kTallT), 0, st, R, T, S, cshift, ncell, sorted.p, (const double *)nullptr, cellptr.p, sc,
                                      cap_w, cap_p, reinterpret_cast<TallPkt *>(sdir.p), spay.p, (double *)nullptr);
-        else hipLaunchKernelGGL((k_tall_build<false>), dim3(grid), dim3(kTallT), 0, st, R, T, S, ncell, sorted.p, svals.p, cellptr.p, sc,
+        else hipLaunchKernelGGL((k_tall_build<false>), dim3(grid), dim3(kTallT), 0, st, R, T, S, cshift, ncell, sorted.p, svals.p, cellptr.p, sc,
                                 cap_w, cap_p, reinterpret_cast<TallPkt *>(sdir.p), spay.p, spayv.p);
         hipLaunchKernelGGL(k_tall_streams, dim3(grid_for(V, kBlock)), dim3(kBlock), 0, st, V, T, S, cellptr.p, sc, ext.p);
         SLP_HIP(hipGetLastError());
@@ -866,7 +892,7 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     if (!dict) { f.tall_val.emplace_back((size_t)tot_w + 64); vals = f.tall_val.back().p; }
     SLP_HIP(hipMemcpyAsync(pay.p, spay.p, (size_t)tot_w * sizeof(unsigned int), hipMemcpyDeviceToDevice, st));
     if (vals) SLP_HIP(hipMemcpyAsync(vals, spayv.p, (size_t)tot_w * sizeof(double), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_tall_dir, dim3(grid_for(std::max<i64>(ncell, V), kBlock)), dim3(kBlock), 0, st, ncell, V, T, S, cellptr.p, sc, ext.p, dpkt.p,
+    hipLaunchKernelGGL(k_tall_dir, dim3(grid_for(std::max<i64>(ncell, V), kBlock)), dim3(kBlock), 0, st, ncell, V, T, S, cshift, cellptr.p, sc, ext.p, dpkt.p,
                        reinterpret_cast<const TallPkt *>(sdir.p), reinterpret_cast<TallPkt *>(dir.p));
     SLP_HIP(hipGetLastError());
     std::vector<TallWg> wg((size_t)V);
@@ -887,7 +913,7 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     SLP_HIP(hipStreamSynchronize(st));
     f.tall_bytes = (dir.n + pay.n) * sizeof(unsigned int) + (vals ? pay.n * sizeof(double) : 0) + wg.size() * sizeof(TallWg) +
                    (dict ? (size_t)dict->D * sizeof(double) : 0);
-    f.nrow = nrowF; f.ncol = ncolF; f.nnz = a.nnz; f.T = T; f.B = B; f.C = kTallC; f.rpl = 1;
+    f.nrow = nrowF; f.ncol = ncolF; f.nnz = a.nnz; f.T = T; f.B = B; f.C = (int)Cw; f.rpl = 1;
     f.D = dict ? dict->D : 0;
     f.dict = dict ? dict->values.p : nullptr;
     f.tall = true;

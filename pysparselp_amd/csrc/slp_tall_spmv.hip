@@ -32,7 +32,10 @@ struct TallRegs {
 // matrix in one grid (A x in one launch); nseg = the chunks for the copy of A^T of a chunked matrix, where the workgroup of a
 // column block walks chunk 0, 1, ... in order and the column sums simply stay in LDS between them (A^T y in one launch: the chain
 // of additions of the unchunked product, as the chunk-by-chunk launches formed it through `out`).
-template <bool DICT, bool ACC, bool POW = false>
+// C: columns per strip = doubles of an x-tile (4096, 2048 or 1024: the build halves the strips of denser matrices until a cell
+// holds ~0.3-0.6 entries per row -- the regime the dealing of a cell's rows to the lanes is made for; items keep their 12-bit
+// column field).
+template <bool DICT, bool ACC, bool POW = false, int C = kTallC>
 __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__restrict__ wgs, const double *__restrict__ dict_arg,
                                                       const double *__restrict__ x, double *__restrict__ out, double pw) {
     constexpr int kDepth = DICT ? kTallDepth : 2;
@@ -41,8 +44,11 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
     // and adds into the scratch cell: no predicate on the stores, none on the sums
     __shared__ double acc[kTallRmax + 1];
     __shared__ double dv[kTallDictMax];
-    __shared__ double xt[2][kTallC];
+    static_assert(C == 4096 || C == 2048 || C == 1024, "tall cells: strip width");
+    __shared__ double xt[2][C];
+    constexpr int kPieces = C / 2048 ? C / 2048 : 1;     // 16-byte pieces of a tile per lane
     const int p = threadIdx.x;
+    const bool tile_lane = C >= 2048 || p < C / 2;       // (1024 columns: the first 512 lanes carry the tile)
     const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
     const int v = blockIdx.x;
     int cur = 0;
@@ -93,13 +99,14 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
 #ifdef SLP_TALL_X64   // lab: four 8-byte loads (rounds 3-4)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            static_assert(C == kTallC, "SLP_TALL_X64: 4096-column strips only");
             const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)(i & 1) + (i >> 1) * (unsigned int)(kTallC * 4), 0, 0);
             g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
         }
 #else
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo + (unsigned int)i * (unsigned int)(kTallC * 4), 0, 0);
+        for (int i = 0; i < kPieces; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo + (unsigned int)i * (unsigned int)(C * 4), 0, 0);
             g.x[2 * i] = __hiloint2double((int)v[1], (int)v[0]);
             g.x[2 * i + 1] = __hiloint2double((int)v[3], (int)v[2]);
         }
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
         // lane p carries doubles 2p, 2p + 1 of the tile's first half and of its second half: consecutive lanes then write
         // consecutive 16-byte pieces of the LDS tile (no bank conflicts; with 4p .. 4p + 3 per lane the two 16-byte writes of a
         // lane pair collided -- the tile write was the largest single item of the kernel's ablation, 0.9 of 4.1 ms)
-        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
+        const unsigned int xo = (xs == kNoTile || !tile_lane) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
 #endif
         load_tile(g, xo);
     };
@@ -169,14 +176,14 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
 #endif
         if (part == (SLP_TALL_XLOAD == 1 ? 0 : 1) && SLP_TALL_XLOAD != 2) {
             const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
-            const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
+            const unsigned int xo = (xs == kNoTile || !tile_lane) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
             load_tile(g, xo);
         }
     };
 #if SLP_TALL_XLOAD == 2
     auto issue_tile = [&](TallRegs<DICT> &g, unsigned int h) {
         const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
-        const unsigned int xo = (xs == kNoTile) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
+        const unsigned int xo = (xs == kNoTile || !tile_lane) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
         load_tile(g, xo);
     };
 #endif
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
                 // have landed by the next one, 1.6 us later; the register path issues the loads four cells ahead.  A third buffer
                 // does not fit beside 78 KB of running sums.)
                 double *dst = &xt[cur ^ 1][2 * p];
-                *reinterpret_cast<double2 *>(dst) = make_double2(g.x[0], g.x[1]);
-                *reinterpret_cast<double2 *>(dst + kTallC / 2) = make_double2(g.x[2], g.x[3]);
+                if (tile_lane) *reinterpret_cast<double2 *>(dst) = make_double2(g.x[0], g.x[1]);
+                if (kPieces == 2) *reinterpret_cast<double2 *>(dst + C / 2) = make_double2(g.x[2], g.x[3]);
             }
         };
         // WHERE the wave stores its share of the NEXT cell's x-tile (it only has to be there by the next cell's barrier; lab:
@@ -335,16 +342,24 @@ __global__ void k_tall_combine(i64 nrow, int S, const double *__restrict__ part,
     }
 }
 
+// the instantiation for the copy's strip width
+template <bool DICT, bool ACC, bool POW>
+static void tall_launch(int C, unsigned grid, int nseg, const TallWg *wgs, const double *dict, const double *x, double *out, double pw) {
+    switch (C) {
+    case 4096: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 4096>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
+    case 2048: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 2048>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
+    case 1024: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 1024>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
+    default: SLP_REQUIRE(false, "tall cells: strip width");
+    }
+}
+
 void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
     double *dst = f.S > 1 ? f.part.p : out;
     const unsigned grid = (unsigned)(f.B * f.S);
     const bool acc = accum && f.S == 1;
-#define SLP_TALL_LAUNCH(DICT, ACC)                                                                                        \
-    hipLaunchKernelGGL((k_tall_spmv<DICT, ACC>), dim3(grid), dim3(kTallT), 0, ctx().stream, 1, f.tall_wg.p,               \
-                       DICT ? f.dict : (const double *)nullptr, x, dst, 0.0)
-    if (f.D > 0) { if (acc) SLP_TALL_LAUNCH(true, true); else SLP_TALL_LAUNCH(true, false); }
-    else { if (acc) SLP_TALL_LAUNCH(false, true); else SLP_TALL_LAUNCH(false, false); }
-#undef SLP_TALL_LAUNCH
+    const double *none = nullptr;
+    if (f.D > 0) { if (acc) tall_launch<true, true, false>((int)f.C, grid, 1, f.tall_wg.p, f.dict, x, dst, 0.0); else tall_launch<true, false, false>((int)f.C, grid, 1, f.tall_wg.p, f.dict, x, dst, 0.0); }
+    else { if (acc) tall_launch<false, true, false>((int)f.C, grid, 1, f.tall_wg.p, none, x, dst, 0.0); else tall_launch<false, false, false>((int)f.C, grid, 1, f.tall_wg.p, none, x, dst, 0.0); }
     if (f.S > 1)
         hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());
@@ -357,10 +372,8 @@ void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
 void tall_spmv_fused(const StripJds &f, const double *x, double *out) {
     const int nseg = f.parts_cols ? (int)f.parts.size() : 1;
     const unsigned grid = (unsigned)(f.tall_wg.n / (size_t)nseg);
-    if (f.D > 0)
-        hipLaunchKernelGGL((k_tall_spmv<true, false>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, f.tall_wg.p, (const double *)nullptr, x, out, 0.0);
-    else
-        hipLaunchKernelGGL((k_tall_spmv<false, false>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, f.tall_wg.p, (const double *)nullptr, x, out, 0.0);
+    if (f.D > 0) tall_launch<true, false, false>((int)f.C, grid, nseg, f.tall_wg.p, nullptr, x, out, 0.0);
+    else tall_launch<false, false, false>((int)f.C, grid, nseg, f.tall_wg.p, nullptr, x, out, 0.0);
     SLP_HIP(hipGetLastError());
 }
 
@@ -374,7 +387,7 @@ bool tall_fuse(StripJds &f) {
     if (f.parts.empty()) return false;
     const StripJds &f0 = *f.parts[0];
     for (const StripJds *g : f.parts)
-        if (!g->ok || !g->tall || g->S != 1 || (g->D > 0) != (f0.D > 0) || (f.parts_cols && (g->B != f0.B || g->tall_R != f0.tall_R || g->nrow != f0.nrow)))
+        if (!g->ok || !g->tall || g->S != 1 || g->C != f0.C || (g->D > 0) != (f0.D > 0) || (f.parts_cols && (g->B != f0.B || g->tall_R != f0.tall_R || g->nrow != f0.nrow)))
             return false;
     std::vector<TallWg> all;
     for (size_t k = 0; k < f.parts.size(); ++k) {
@@ -389,6 +402,7 @@ bool tall_fuse(StripJds &f) {
         }
     }
     f.tall_wg.upload(all.data(), all.size());
+    f.C = f0.C;
     return true;
 }
 
@@ -397,12 +411,8 @@ void tall_spmv_pow(const StripJds &f, double pw, const double *x, double *out, i
     SLP_REQUIRE(f.ok && f.tall && f.D == 0, "tall_spmv_pow: not a tall-cell copy with fp64 entries");
     double *dst = f.S > 1 ? f.part.p : out;
     const unsigned grid = (unsigned)(f.B * f.S);
-    if (accum && f.S == 1)
-        hipLaunchKernelGGL((k_tall_spmv<false, true, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, 1, f.tall_wg.p,
-                           (const double *)nullptr, x, dst, pw);
-    else
-        hipLaunchKernelGGL((k_tall_spmv<false, false, true>), dim3(grid), dim3(kTallT), 0, ctx().stream, 1, f.tall_wg.p,
-                           (const double *)nullptr, x, dst, pw);
+    if (accum && f.S == 1) tall_launch<false, true, true>((int)f.C, grid, 1, f.tall_wg.p, nullptr, x, dst, pw);
+    else tall_launch<false, false, true>((int)f.C, grid, 1, f.tall_wg.p, nullptr, x, dst, pw);
     if (f.S > 1)
         hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());

@@ -25,7 +25,7 @@ def _small_matrices_take_the_tall_format():
     os.environ.pop("SLP_TALL_R", None)
 
 
-def _check(a_host, rows_per_block=None, transposed_too=True):
+def _check(a_host, rows_per_block=None, transposed_too=True, policies=((0, 6), (1, 7))):
     from pysparselp_amd.device import DeviceMatrix
 
     if rows_per_block:
@@ -38,7 +38,7 @@ def _check(a_host, rows_per_block=None, transposed_too=True):
         x, y = rng.randn(a_host.shape[1]), rng.randn(a_host.shape[0])
         ax, aty = oracle.matvec(oracle.as_csr(a_host), x), oracle.rmatvec(oracle.as_csr(a_host), y)
         kern = None
-        for policy, want in ((0, 6), (1, 7)):   # value-dictionary items (5 bytes) / fp64 entries (4 + 8 bytes)
+        for policy, want in policies:   # value-dictionary items (5 bytes) / fp64 entries (4 + 8 bytes)
             a.set_format(policy)
             assert a.spmv_kernel(False) == want, (policy, a.spmv_kernel(False))
             assert np.array_equal(a.matvec(x), ax), policy
@@ -252,4 +252,24 @@ def test_b_upper_of_the_generated_lp_through_the_product_copies():
     finally:
         a.close()
         ch.close()
+
+
+@pytest.mark.parametrize("width", [2048, 1024])
+def test_narrower_strips_for_denser_matrices(width, monkeypatch):
+    """The build halves the strips (4096 -> 2048 -> 1024 columns, the x-tile with them) until a cell holds ~0.3-0.6 entries per
+    row; items keep their 12-bit column field.  Forced widths on the shapes of the tests above (ragged last strip, odd width,
+    continuation packets, empty cells, a transposed copy), then densities at which the build picks them itself: bit for bit."""
+    monkeypatch.setenv("SLP_TALL_C", str(width))
+    a = _random(20000, 50001, 1e-4, 1)
+    _check(a, None)
+    _check(a, 1500)
+    assert _check(_random(60000, 9000, 3e-4, 2), 2048) == 6
+    b = _random(5000, 70000, 5e-5, 6).tocoo()
+    drop = ((b.row >= 100) & (b.row < 400)) | ((b.col >= width * 2) & (b.col < width * 5)) | ((b.row >= 1024) & (b.row < 2048) & (b.col >= width * 7))
+    b = scipy.sparse.coo_matrix((b.data[~drop], (b.row[~drop], b.col[~drop])), shape=b.shape).tocsr()
+    b.sort_indices()
+    _check(b, 1024)
+    monkeypatch.delenv("SLP_TALL_C")
+    dens = {2048: 2e-4, 1024: 4.5e-4}[width]      # 0.82 / 1.84 entries per row and 4096 columns
+    _check(_random(30000, 120001, dens, 9), None, policies=((0, 6),))    # (fp64 entries go to the LDS strips at these densities)
 
