@@ -583,8 +583,9 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
     }
 }
 
-// What the single pass is given room for: per cell of n entries, min(n, 1024) lists of ceil(n / 1024) items (what the dealing
-// aims at; rows longer than that and the envelope's skip items come out of the margin the host adds).
+// What the single pass is given room for: per cell of n entries its n items and the fifth bytes' words of min(n, 1024) lists of
+// ceil(n / 1024) items (what the dealing aims at; rows longer than that and the envelope's skip items -- 2-3 % on the benchmark's
+// LPs -- come out of the margin the host adds).
 template <bool DICT>
 __global__ __launch_bounds__(kBlock) void k_tall_estimate(i64 ncell, const i64 *__restrict__ cellptr, unsigned long long *__restrict__ est) {
     unsigned long long w = 0, k = 0;
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_tall_estimate(i64 ncell, const i64 *
         const unsigned long long n = (unsigned long long)(cellptr[c + 1] - cellptr[c]);
         if (!n) continue;
         const unsigned long long L = n < (unsigned)kTallT ? n : (unsigned)kTallT, tau = (n + kTallT - 1) / kTallT;
-        unsigned long long cw = L * tau;
+        unsigned long long cw = n;
         if (DICT) cw += L * ((tau + 7) / 8 + (tau > 4 ? (tau - 4 + 7) / 8 : 0));
         w += (cw + 3ull) & ~3ull;
         k += (tau + kTallSlots - 1) / kTallSlots;
@@ -833,8 +834,16 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     SLP_HIP(hipGetLastError());
     unsigned long long hest[2];
     est.download(hest, 2);
-    // room for the pass: the estimate + 6 % (measured need on the benchmark's LPs: + 0.3 ... 2 %); the directory is 32 bytes per ~20 KB cell
-    i64 cap_w = (i64)hest[0] + (i64)hest[0] / 16 + 65536, cap_p = 2 * (i64)hest[1] + 4096;
+    // Room for the pass.  It writes straight into the copy's own buffer (a pass into scratch + a copy into an exact-size buffer
+    // held both at once: config 5's peak 276 -> 293 of 309 GB), so the room has to be right: the estimate times what the LAST copy
+    // built by this process needed of its estimate (the chunks and both orientations of one LP are statistically alike: 1.03 on the
+    // benchmark's LPs; kept per orientation and item form) + 0.3 %; the first copy gets + 10 %.  A pass that did not fit is repeated into buffers of the exact size; a buffer
+    // more than 1 % too large (the first copy; an LP unlike the last) is exchanged for one of the exact size.  The directory is 32 bytes
+    // per ~20 KB cell.
+    static double last_needs[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // by orientation and item form: the two copies of a chunk differ by ~1 %
+    double &last_need = last_needs[transposed ? 1 : 0][dict ? 1 : 0];
+    const double room = (last_need > 0.5 && last_need < 2.0) ? last_need * 1.003 : 1.10;
+    i64 cap_w = (i64)((double)hest[0] * room) + 65536, cap_p = 2 * (i64)hest[1] + 4096;
     if (const char *e = getenv("SLP_TALL_BUILD_ROOM")) cap_w = std::max<i64>(4, (i64)((double)hest[0] * atof(e)));  // (tests: force the second attempt)
     i64 tot_w = 0, tot_p = 0;
     DevBuf<i64> ext(4 * (size_t)V);
@@ -842,6 +851,8 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     DevBuf<unsigned int> spay, sdir;
     DevBuf<double> spayv;
     for (int attempt = 0;; ++attempt) {
+        spay.release();   // (a second attempt: the first one's buffers go back before the exact ones are taken)
+        spayv.release();
         spay.alloc((size_t)cap_w + 64);
         sdir.alloc((size_t)cap_p * 8);
         if (!dict) spayv.alloc((size_t)cap_w + 64);
@@ -885,13 +896,24 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     hbase[V] = tot_w;
     DevBuf<i64> dpkt;
     dpkt.upload(hpkt.data(), hpkt.size());
+    if (hest[0]) last_need = (double)tot_w / (double)hest[0];
+    if (cap_w > tot_w + tot_w / 100 + 65536) {   // too much room: the copy moves into buffers of its size
+        DevBuf<unsigned int> exact((size_t)tot_w + 64);
+        SLP_HIP(hipMemcpyAsync(exact.p, spay.p, (size_t)tot_w * sizeof(unsigned int), hipMemcpyDeviceToDevice, st));
+        DevBuf<double> exactv;
+        if (!dict) {
+            exactv.alloc((size_t)tot_w + 64);
+            SLP_HIP(hipMemcpyAsync(exactv.p, spayv.p, (size_t)tot_w * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        SLP_HIP(hipStreamSynchronize(st));
+        spay = std::move(exact);
+        spayv = std::move(exactv);
+    }
     f.tall_dir.emplace_back((size_t)hpkt[V] * 8);
-    f.tall_pay.emplace_back((size_t)tot_w + 64);
+    f.tall_pay.emplace_back(std::move(spay));
     DevBuf<unsigned int> &dir = f.tall_dir.back(), &pay = f.tall_pay.back();
     double *vals = nullptr;
-    if (!dict) { f.tall_val.emplace_back((size_t)tot_w + 64); vals = f.tall_val.back().p; }
-    SLP_HIP(hipMemcpyAsync(pay.p, spay.p, (size_t)tot_w * sizeof(unsigned int), hipMemcpyDeviceToDevice, st));
-    if (vals) SLP_HIP(hipMemcpyAsync(vals, spayv.p, (size_t)tot_w * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (!dict) { f.tall_val.emplace_back(std::move(spayv)); vals = f.tall_val.back().p; }
     hipLaunchKernelGGL(k_tall_dir, dim3(grid_for(std::max<i64>(ncell, V), kBlock)), dim3(kBlock), 0, st, ncell, V, T, S, cshift, cellptr.p, sc, ext.p, dpkt.p,
                        reinterpret_cast<const TallPkt *>(sdir.p), reinterpret_cast<TallPkt *>(dir.p));
     SLP_HIP(hipGetLastError());
@@ -911,7 +933,8 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     }
     f.tall_wg.upload(wg.data(), wg.size());
     SLP_HIP(hipStreamSynchronize(st));
-    f.tall_bytes = (dir.n + pay.n) * sizeof(unsigned int) + (vals ? pay.n * sizeof(double) : 0) + wg.size() * sizeof(TallWg) +
+    // (what a product streams: the words written, not the buffer's margin)
+    f.tall_bytes = (dir.n + (size_t)tot_w) * sizeof(unsigned int) + (vals ? (size_t)tot_w * sizeof(double) : 0) + wg.size() * sizeof(TallWg) +
                    (dict ? (size_t)dict->D * sizeof(double) : 0);
     f.nrow = nrowF; f.ncol = ncolF; f.nnz = a.nnz; f.T = T; f.B = B; f.C = (int)Cw; f.rpl = 1;
     f.D = dict ? dict->D : 0;
