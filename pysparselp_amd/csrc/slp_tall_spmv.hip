@@ -157,6 +157,16 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
         const unsigned int mine = (unsigned int)p * 4u;
         unsigned int so = off * 4u;
         if (part == 1) so += (c[0] + c[1] + c[2] + c[3]) * 4u;
+        // A packet without a fifth item (lists of <= 4 items: the metric's density, where a cell is one such packet) issues no
+        // loads for slots 4-7 and their fifth bytes -- a uniform branch; consume() takes the second group under the same test.  The
+        // compiler then counts the loads in flight by the path without them (vmcnt(24-26) instead of 36-41): exact for those
+        // packets, a shorter prefetch distance behind a packet that has the second group.  3.30 / 3.30 -> 3.25 / 3.22 ms on the
+        // slice, unchanged where lists are five long (-DSLP_TALL_FULL_ISSUE = rounds 3-5a, profiles/r05_tall_half_packets.log).
+#ifndef SLP_TALL_FULL_ISSUE
+        if (part == 0 || wbase < c[4]) {   // (per wave: the waves past the fifth items' lanes skip them too)
+#else
+        {
+#endif
 #pragma unroll
         for (int k = 4 * part; k < 4 * part + 4; ++k) {
             g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);
@@ -170,6 +180,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
             if (part == 0) so += (c[4] + c[5] + c[6] + c[7]) * 4u;   // the fifth bytes follow the eight slots: slots 0-3, then slots 4-7
             else so += c[0] * 4u;
             g.hi[DICT ? part : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4 * part] ? mine : kOob, so, 2);
+        }
         }
 #ifndef SLP_TALL_XLOAD
 #define SLP_TALL_XLOAD 0   // lab: where the tile loads of the packet `depth` ahead are issued: 0 behind all items, 1 between the groups, 2 behind the tile store
