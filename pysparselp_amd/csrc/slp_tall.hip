@@ -31,6 +31,7 @@
 // address past the end of the buffer descriptor: no memory request), so the compiler counts what is in flight
 // (s_waitcnt vmcnt(N), never 0), and the x-tile of the NEXT cell rides on the first packet of the current one.
 // One barrier per cell.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -338,8 +339,8 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
         const unsigned int n2 = bstart[(kTallBuckets - 1) * 32];  // rows with two or more entries come first
         // Dealing rows to lanes.  Sparse cells (all rows with two or more entries fit the 1024 lanes -- the regime this
         // format is for): lane p < n2 takes one of those rows, then every lane takes as many one-entry rows as bring its
-        // list to the mean length tau = ceil(items / 1024): all lists are tau long except those of the few rows longer than
-        // tau, so the 16 waves of the workgroup reach the cell's barrier together.  WHICH row of a count a lane takes is
+        // list to its target length (items / 1024, one more for the first items % 1024 lanes): all lists are that long except those
+        // of the few rows longer than it, so the 16 waves of the workgroup reach the cell's barrier together.  WHICH row of a count a lane takes is
         // free: lanes take rows of their own bank class (p % 32 == row % 32) as far as those last -- the 32 lanes of a
         // half-wave then read and write the running sums without bank conflicts -- and the rest in order.
         // Otherwise (dense cells) round by round: lane p takes positions p, p + 1024, ...
@@ -381,7 +382,17 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
         {
             // one-entry rows (fill mode): first those of the lane's own bank class, in lane order inside the class ...
             const unsigned int *b1 = bstart + (kTallBuckets - 1) * 32;
+            // The lane's target length: items / 1024, one more for the first items % 1024 lanes -- the targets add up to the
+            // cell's items, so the one-entry rows go round (up to the rows longer than their lane's target).  With ceil(items /
+            // 1024) for every lane (rounds 3-5a, -DSLP_TALL_DEAL_CEIL) the demand exceeded the supply by 1024 - items % 1024: the bank
+            // classes ran dry at different lanes, the lists of the last ~150 lanes came out between 0 and the target at random, and
+            // the non-increasing envelope over them was paid in skip items: 2 % of the words at the metric's density (lists of 4
+            // from 3983 items), 20 % where lists are 5 long.
+#ifdef SLP_TALL_DEAL_CEIL
             const unsigned int tau = ((unsigned)n + kTallT - 1) / kTallT;
+#else
+            const unsigned int tau = (unsigned)n / kTallT + ((unsigned)p < (unsigned)n % kTallT ? 1u : 0u);
+#endif
             const unsigned int want = (fill && c0p < tau) ? tau - c0p : 0u;
             ccls[(p >> 5) * 32 + rho] = want;
             __syncthreads();
@@ -840,8 +851,9 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     // benchmark's LPs; kept per orientation and item form) + 0.3 %; the first copy gets + 10 %.  A pass that did not fit is repeated into buffers of the exact size; a buffer
     // more than 1 % too large (the first copy; an LP unlike the last) is exchanged for one of the exact size.  The directory is 32 bytes
     // per ~20 KB cell.
-    static double last_needs[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // by orientation and item form: the two copies of a chunk differ by ~1 %
-    double &last_need = last_needs[transposed ? 1 : 0][dict ? 1 : 0];
+    static std::atomic<double> last_needs[2][2];   // by orientation and item form: the two copies of a chunk differ by ~1 % (zero: none yet)
+    std::atomic<double> &last_need_slot = last_needs[transposed ? 1 : 0][dict ? 1 : 0];
+    const double last_need = last_need_slot.load();
     const double room = (last_need > 0.5 && last_need < 2.0) ? last_need * 1.003 : 1.10;
     i64 cap_w = (i64)((double)hest[0] * room) + 65536, cap_p = 2 * (i64)hest[1] + 4096;
     if (const char *e = getenv("SLP_TALL_BUILD_ROOM")) cap_w = std::max<i64>(4, (i64)((double)hest[0] * atof(e)));  // (tests: force the second attempt)
@@ -896,7 +908,7 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     hbase[V] = tot_w;
     DevBuf<i64> dpkt;
     dpkt.upload(hpkt.data(), hpkt.size());
-    if (hest[0]) last_need = (double)tot_w / (double)hest[0];
+    if (hest[0]) last_need_slot.store((double)tot_w / (double)hest[0]);
     if (cap_w > tot_w + tot_w / 100 + 65536) {   // too much room: the copy moves into buffers of its size
         DevBuf<unsigned int> exact((size_t)tot_w + 64);
         SLP_HIP(hipMemcpyAsync(exact.p, spay.p, (size_t)tot_w * sizeof(unsigned int), hipMemcpyDeviceToDevice, st));
