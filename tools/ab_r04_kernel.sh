@@ -1,6 +1,9 @@
 #!/bin/bash
 # Same-box A/B of the round-4 tall-cell kernel (libslp_hip_r4kernel.so: `make variant NAME=r4kernel` at the round's first commit)
 # against the current library: boxes differ by ~6 % among themselves, only back-to-back runs on ONE box compare kernels.
+# (Since the generator takes b_upper from the chunked matrix's own product -- late in round 5 -- the round-4 library can no longer run
+# bench.py's chunked workloads: its lines come out FAILED.  tools/tall_only.py still runs under SLP_LIB_VARIANT=r4kernel: the slice-level
+# A/B of profiles/r05_tall_half_packets.log.)
 O=gpurun_out/ab_r04
 mkdir -p $O
 run() {  # run <tag> <variant or ""> <bench args...>
