@@ -275,6 +275,12 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
 #if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 1 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)   // lab: no value / x gathers
 #pragma unroll
             for (int k = 0; k < 4; ++k) pr[k] = (double)(w[k] & 0x7fffffu) * tile[p];
+#elif defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 10 || SLP_TALL_ABL == 11 || SLP_TALL_ABL == 12)   // lab (wrong results): gathers without bank conflicts -- the index's low five bits are the lane's (10 both, 11 values only, 12 x only)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned int iv = w[k] & ((1u << kTallIdBits) - 1), ix = (w[k] >> kTallIdBits) & (kTallC - 1);
+                pr[k] = dv[SLP_TALL_ABL != 12 ? ((iv & ~31u) | ((unsigned)p & 31u)) : iv] * tile[SLP_TALL_ABL != 11 ? ((ix & ~31u) | ((unsigned)p & 31u)) : ix];
+            }
 #else
 #pragma unroll
             for (int k = 0; k < 4; ++k)
