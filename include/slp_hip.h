@@ -153,6 +153,10 @@ int64_t slp_matrix_chunks(const slp_matrix *a);
 /* Product-kernel launches one y = A x (transposed: A^T y) takes: 1 for an ordinary matrix, up to one per row chunk for a
  * chunked one (bench.py: "per product" vs "per launch" figures). */
 int64_t slp_matrix_product_launches(const slp_matrix *a, int transposed);
+/* Columns per strip of the orientation's product copy (builds it if need be): 4096 / 2048 / 1024 for tall cells -- the width the
+ * build's cost model chose (slp_tall.hip, tall_build) --, the strip formats' widths otherwise; 0 without a copy (CSR kernels), -1 for
+ * NULL.  A chunked matrix reports its first chunk's.  Diagnostics: what a density sweep or a test asserts. */
+int64_t slp_matrix_strip_width(slp_matrix *a, int transposed);
 
 /* ---- Chambolle-Pock: replaces chambolle_pock_ppd's loop ----------------- *
  * ChambollePockPPD.py:122-179 (preconditioners T, Sigma) and :195-343 (loop).

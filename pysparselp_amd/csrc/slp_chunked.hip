@@ -134,6 +134,19 @@ int slp_matrix_chunked_expect(slp_matrix *g, int64_t chunks) {
 
 int64_t slp_matrix_chunks(const slp_matrix *g) { return g ? (int64_t)g->chunks.size() : -1; }
 
+int64_t slp_matrix_strip_width(slp_matrix *m, int transposed) {
+    if (!m) return -1;
+    int64_t c = 0;
+    const int rc = [&]() -> int {
+        SLP_API_INT({
+            const StripJds *f = fast_format(m, transposed != 0);
+            if (f && !m->chunks.empty() && !f->parts.empty()) f = f->parts[0];
+            c = (f && f->ok) ? (int64_t)f->C : 0;
+        })
+    }();
+    return rc == 0 ? c : -1;
+}
+
 int64_t slp_matrix_product_launches(const slp_matrix *g, int transposed) {
     if (!g) return -1;
     if (g->chunks.empty()) return 1;

@@ -273,3 +273,27 @@ def test_narrower_strips_for_denser_matrices(width, monkeypatch):
     dens = {2048: 2e-4, 1024: 4.5e-4}[width]      # 0.82 / 1.84 entries per row and 4096 columns
     _check(_random(30000, 120001, dens, 9), None, policies=((0, 6),))    # (fp64 entries go to the LDS strips at these densities)
 
+
+def test_strip_width_follows_the_cost_model():
+    """``slp_matrix_strip_width``: the width ``tall_build`` chose per copy.  The metric's density (0.41 entries per row and 4096
+    columns) stays on 4096-column strips; twice the density takes 2048 (the row blocks keep their height), 4.5 times takes 1024;
+    ``SLP_TALL_C`` overrides (profiles/r05_tall_density_sweep.log: the chosen width was the fastest of the three in all cases)."""
+    from pysparselp_amd import _lib
+    from pysparselp_amd.device import DeviceMatrix
+
+    lib = _lib.lib()
+    for dens, cols, want in ((1e-4, 400_000, 4096), (2e-4, 200_000, 2048), (4.5e-4, 100_000, 1024)):
+        a = DeviceMatrix.random(2_500_000, cols, dens, 3, 0)    # 1e8 entries; row blocks of 9766 rows where the width allows
+        try:
+            assert a.spmv_kernel(False) == 6
+            assert int(lib.slp_matrix_strip_width(a._h, 0)) == want, (dens, int(lib.slp_matrix_strip_width(a._h, 0)))
+        finally:
+            a.close()
+    os.environ["SLP_TALL_C"] = "1024"
+    try:
+        a = DeviceMatrix.random(2_500_000, 400_000, 1e-4, 3, 0)
+        assert int(lib.slp_matrix_strip_width(a._h, 0)) == 1024
+        a.close()
+    finally:
+        del os.environ["SLP_TALL_C"]
+
