@@ -11,9 +11,11 @@ variables x 2e7 inequality rows (config 4) at the density that fits one node,
 8 x 288 GB) -- resident on ONE GPU because every rank's row block is generated,
 converted and released in row chunks (ChunkedDeviceMatrix: the CSR of the whole
 block never exists).  N > 1 row-partitions the SAME problem over the N GPUs
-(strong scaling, one RCCL all-reduce of the n partial column sums per SpMV^T);
-launched by the driver as ``python -m torch.distributed.run --nproc-per-node N
-... bench.py --gpus N``.  ``--config c3`` runs BASELINE config 3 (1e6 x 2e6 at
+(strong scaling, one RCCL all-reduce of the n partial column sums per SpMV^T):
+``python bench.py --gpus N`` starts its own N ranks (``self_launch``: plain child
+processes + a TCP id exchange, no torch anywhere); the driver's ``python -m
+torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` works too (bench.py
+only reads the RANK / WORLD_SIZE / MASTER_* it sets).  ``--config c3`` runs BASELINE config 3 (1e6 x 2e6 at
 1e-3, the headline of rounds 1-3); at N = 1 the default run appends it as
 ``secondary.c3`` (same code path, a few seconds).
 
@@ -399,13 +401,76 @@ def general_block(lib, args, a, b, c, lb, ub, shape):
     return out
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher's environment: this process becomes the launcher.  It starts N
+    fresh copies of this script -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / SLP_JOB_TOKEN
+    set, the id exchange on MASTER_PORT + 1 (pysparselp_amd/parallel.py: plain TCP, no torch) -- forwards rank 0's stdout (the
+    ONE JSON line) and exits non-zero if any rank does.  Nothing here has touched HIP: the ranks are children of a process
+    that never initialised a GPU, and nothing is ever re-executed.  ``python -m torch.distributed.run ... bench.py --gpus N``
+    (the driver's line) keeps working: it sets WORLD_SIZE and this function is not reached."""
+    import secrets
+    import socket
+    import subprocess
+
+    def port_block_free(base):   # MASTER_PORT (a launcher's store would sit there), + 1 .. + 8 the id exchange, + 9 the host transport
+        socks = []
+        try:
+            for p in range(base, base + 10):
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                socks.append(s)
+                s.bind(("127.0.0.1", p))
+            return True
+        except OSError:
+            return False
+        finally:
+            for s in socks:
+                s.close()
+
+    base = int(os.environ["MASTER_PORT"]) if "MASTER_PORT" in os.environ else 0
+    if not base:
+        for _ in range(64):
+            base = 20000 + secrets.randbelow(30000)
+            if port_block_free(base):
+                break
+        else:
+            raise SystemExit("bench.py: no free block of 10 ports on 127.0.0.1 for the ranks' rendezvous")
+    token = os.environ.get("SLP_JOB_TOKEN") or secrets.token_hex(8)
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(base), SLP_JOB_TOKEN=token,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+                                      stdout=None if r == 0 else sys.stderr))   # rank 0 prints the line; the others print nothing
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+    if failed is not None:   # a rank died: the others sit in a collective (or its initialisation) for ever -- end them, by PID
+        time.sleep(2.0)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"bench.py: rank {procs.index(failed)} exited with code {failed.returncode}; job ended", file=sys.stderr, flush=True)
+        raise SystemExit(failed.returncode if failed.returncode and failed.returncode > 0 else 1)
+    raise SystemExit(0)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)   # (never returns)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("SLP_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # SLP_DEVICE: several ranks on one GPU (tests)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (bench.py launches "
+                         f"its own ranks) or under a launcher with --nproc-per-node {args.gpus}")
     if args.method == "admm_blocks":
         # short, very wide row blocks: tall row blocks whose strips are shared by several workgroups (partial row sums added
         # in a fixed order; the block ADMM's conjugate gradients have a tolerance bar, slp_tall.hip)
@@ -489,19 +554,19 @@ def run_workload(lib, args, rank, world, distributed):
         nnz_local = solver.nnz
         t_generate = solver.seconds_generating
     else:
-        a, xf, c, lb, ub, b = random_lp_on_device(args.n, args.m, args.density, seed=args.seed, row_offset=r0, rows=rows, chunks=chunks)
+        m_eq_local = 0
+        if args.eq_frac > 0:  # the first eq_frac * m GLOBAL rows are equalities b_eq = A_e x_feasible (randomLP.py:62-68); this rank
+            #                   holds its share; a chunked block is cut at the boundary between the two kinds of rows
+            m_eq_global = int(round(args.eq_frac * args.m)) & ~1
+            m_eq_local = max(0, min(rows, m_eq_global - r0))
+        a, xf, c, lb, ub, b = random_lp_on_device(args.n, args.m, args.density, seed=args.seed, row_offset=r0, rows=rows, chunks=chunks,
+                                                  m_eq=m_eq_local)
         owns_a = True
         nnz_local = a.nnz
         _lib.check(lib.slp_synchronize())
         t_generate = time.perf_counter() - t_gen  # the synthetic LP itself (randomLP.py's part); the rest of setup_seconds is the solver's
         if args.format:
             _lib.check(lib.slp_matrix_set_format(a._h, args.format))
-        m_eq_local = 0
-        if args.eq_frac > 0:  # the first eq_frac * m GLOBAL rows are equalities b_eq = A x_feasible; this rank holds its share
-            m_eq_global = int(round(args.eq_frac * args.m))
-            m_eq_local = max(0, min(rows, m_eq_global - r0))
-            if m_eq_local:
-                b[:m_eq_local] = a.matvec(xf)[:m_eq_local]
         solver = make_solver(args.method, a, b, c, lb, ub, m_eq=m_eq_local, jacobi=args.jacobi)
     _lib.check(lib.slp_synchronize())
     t_gen = time.perf_counter() - t_gen
@@ -592,7 +657,9 @@ def run_workload(lib, args, rank, world, distributed):
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"randomLP synthetic: {args.n} vars, {args.m} inequality rows, density {args.density}, "
+                "workload": f"randomLP synthetic: {args.n} vars, {args.m} "
+                            + (f"rows (the first {int(round(args.eq_frac * args.m)) & ~1} equalities, the others inequalities)" if args.eq_frac > 0
+                               else "inequality rows") + f", density {args.density}, "
                             f"{nnz_total} stored entries, method {args.method} ({solver.describe()}), "
                             f"rows partitioned over {world} GPU(s)"
                             + (f", {args.blocks_per_rank} row block(s) of the block-splitting ADMM per rank, each generated from its own "
@@ -602,6 +669,7 @@ def run_workload(lib, args, rank, world, distributed):
                                "workgroups, partial sums added in range order)" if os.environ.get("SLP_TALL_SPLIT") else ""),
                 "chunks_per_rank": chunks,
                 "n": args.n, "m": args.m, "density": args.density, "seed": args.seed, "nnz": nnz_total, "eq_frac": args.eq_frac,
+                "equality_rows": (int(round(args.eq_frac * args.m)) & ~1) if args.eq_frac > 0 else 0,
                 "method": args.method, "matrix_passes_per_iteration": passes,
                 "collectives_per_iteration": (coll / args.steps) if distributed else 0,
                 **({"cg_steps_per_iteration": (solver.cg_steps() - cg0) / args.steps, "jacobi": bool(args.jacobi),

@@ -179,6 +179,14 @@ int slp_cp_iterate(slp_cp *s, int64_t k);
  * :333-342): primal_step, then slp_cp_report, then dual_step. */
 int slp_cp_primal_step(slp_cp *s);
 int slp_cp_dual_step(slp_cp *s);
+/* How d = (c + y_eq * a_eq) + y_ineq * a_ineq (:206,216) is formed when the LP has
+ * both kinds of rows and runs on strip copies: 1 -- two products over copies of
+ * A_e^T and A_i^T (the chunks of a chunked matrix cut at m_eq, or copies of the
+ * two row ranges built for this solver); 2 -- two products over the copy of the
+ * whole K^T with the other kind of rows masked out of y; 0 -- one kind of rows,
+ * or the CSR / ELL walk that forms both sums in one pass.  Bit for bit the
+ * reference's order in every form. */
+int slp_cp_split_form(const slp_cp *s);
 /* out[0] energy1 (:248,267,271)  out[1] energy2 (:260-272)
  * out[2] max |A_eq z - b_eq| (:269; 0 without equalities)
  * out[3] max (A_ineq x - b_ineq) (:283; -inf without inequalities)
@@ -394,6 +402,13 @@ slp_matrix *slp_matrix_random(int64_t nrow, int64_t ncol, double density,
 int slp_random_lp_vectors(slp_matrix *a, double density, uint64_t seed, int64_t row_offset,
                           double *feasible_x, double *c, double *lb, double *ub,
                           double *b_upper);
+/* The 10 %-equality variant of the same LP (randomLP.py:62-68): the first m_eq
+ * local rows of `a` are equalities a_i x = b_i with b_eq = A_e feasible_x
+ * (:63, no ceiling); the others as above.  The right-hand sides land in
+ * b_upper[0 .. m_eq).  m_eq = 0: slp_random_lp_vectors. */
+int slp_random_lp_vectors_eq(slp_matrix *a, double density, uint64_t seed, int64_t row_offset,
+                             int64_t m_eq, double *feasible_x, double *c, double *lb,
+                             double *ub, double *b_upper);
 /* Chambolle-Pock state over a device-resident matrix (no host copy of A):
  * all rows are inequalities; takes ownership of nothing (a must outlive it). */
 slp_cp *slp_cp_create_on(slp_matrix *a, int64_t m_eq, const double *b, const double *c,

@@ -127,6 +127,74 @@ class ProductsOnly:
         return ProductsOnly(self.shape, lambda x: self._abs_pow_matvec(x, p), lambda y: self._abs_pow_rmatvec(y, p))
 
 
+class StreamedCsr(ProductsOnly):
+    """A matrix this oracle holds ONE ROW CHUNK AT A TIME: ``chunk_source(k)`` hands over rows ``cuts[k] .. cuts[k + 1]`` as a
+    CSR (scipy or ``Csr``; rows sorted by column) whenever a product needs them, and the chunk is dropped again -- BASELINE
+    config 4's 2e10 entries (240 GB of CSR) never sit in host memory at once, yet every product is this file's own:
+      ``a * x``   ``matvec`` of every chunk on its rows (csr_matvec: one chain per row);
+      ``y * a``   ``rmatvec_acc`` chunk after chunk: every column's chain of additions continues in row order -- bit for bit
+                  ``rmatvec`` of the stacked matrix (csc_matvec order; tests/test_oracle_golden.py);
+      ``|a| ** p``  the same with the chunk's values mapped (``powered``: the sums behind ChambollePockPPD.py:134,144,161,172).
+    ``rows=(r0, r1)`` restricts the operator to a row range that starts and ends at cuts (the equality / the inequality rows of
+    an LP whose chunks were cut at m_eq).  ``cache_bytes`` > 0: chunks are kept, up to that many bytes, instead of asked for again.
+    It IS a ``ProductsOnly`` to the solvers below (they consume nothing but the four products) -- with the difference that no
+    product comes from the device."""
+
+    def __init__(self, ncol, cuts, chunk_source, power=None, rows=None, cache_bytes=0, _cache=None):
+        cuts = [int(c) for c in cuts]
+        r0, r1 = (cuts[0], cuts[-1]) if rows is None else (int(rows[0]), int(rows[1]))
+        assert r0 in cuts and r1 in cuts and r0 <= r1
+        self._all_cuts, self._source, self._power, self._ncol = cuts, chunk_source, power, int(ncol)
+        self._ks = [k for k in range(len(cuts) - 1) if cuts[k] >= r0 and cuts[k + 1] <= r1]
+        self._r0 = r0
+        self._cache_bytes, self._cache = int(cache_bytes), ({} if _cache is None else _cache)
+        self.products = 0     # products formed so far (each one streams every chunk once)
+        ProductsOnly.__init__(self, (r1 - r0, ncol), self._mv, self._rmv, lambda x, p: self.powered(p)._mv(x), lambda y, p: self.powered(p)._rmv(y))
+
+    def powered(self, p):
+        return StreamedCsr(self._ncol, self._all_cuts, self._source, power=p, rows=(self._r0, self._r0 + self.shape[0]),
+                           cache_bytes=self._cache_bytes, _cache=self._cache)
+
+    def row_range(self, r0, r1):
+        return StreamedCsr(self._ncol, self._all_cuts, self._source, power=self._power, rows=(r0, r1), cache_bytes=self._cache_bytes,
+                           _cache=self._cache)
+
+    def _chunks(self):
+        for k in self._ks:
+            c = self._cache.get(k)
+            if c is None:
+                c = as_csr(self._source(k))
+                assert c.shape == (self._all_cuts[k + 1] - self._all_cuts[k], self._ncol)
+                held = sum(v.data.nbytes + v.indices.nbytes + v.indptr.nbytes for v in self._cache.values())
+                if held + c.data.nbytes + c.indices.nbytes + c.indptr.nbytes <= self._cache_bytes:
+                    self._cache[k] = c
+            if self._power is not None:
+                c = Csr(c.indptr, c.indices, np.abs(c.data) ** self._power, c.shape)
+            yield self._all_cuts[k] - self._r0, self._all_cuts[k + 1] - self._r0, c
+
+    # (a zero vector: every term is +-0.0 and every chain starts at +0.0 -- the product is +0.0 in every entry whatever the
+    # stored values, so nothing is streamed for it; the solvers' first iterations multiply by x0 = 0 and lambda = 0)
+    def _mv(self, x):
+        x = _f64(x)
+        if not x.any():
+            return np.zeros(self.shape[0])
+        out = np.empty(self.shape[0])
+        for r0, r1, c in self._chunks():
+            out[r0:r1] = matvec(c, x)
+        self.products += 1
+        return out
+
+    def _rmv(self, y):
+        y = _f64(y)
+        out = np.zeros(self._ncol)
+        if not y.any():
+            return out
+        for r0, r1, c in self._chunks():
+            rmatvec_acc(c, np.ascontiguousarray(y[r0:r1]), out)
+        self.products += 1
+        return out
+
+
 def as_csr(a):
     """Accept a Csr, a scipy CSR matrix or None; entry order is preserved."""
     if a is None or isinstance(a, (Csr, ProductsOnly)):

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "slp_cp_destroy": (None, [c_vp]),
     "slp_cp_iterate": (c_int, [c_vp, c_i64]),
     "slp_cp_primal_step": (c_int, [c_vp]),
+    "slp_cp_split_form": (c_int, [c_vp]),
     "slp_cp_dual_step": (c_int, [c_vp]),
     "slp_cp_report": (c_int, [c_vp, c_vp]),
     "slp_cp_get_x": (c_int, [c_vp, c_vp]),
@@ -118,6 +119,7 @@ _SIGNATURES = {
     "slp_admm_cg_get_x": (c_int, [c_vp, c_vp, c_i64]),
     "slp_matrix_random": (c_vp, [c_i64, c_i64, c_dbl, ctypes.c_uint64, c_i64]),
     "slp_random_lp_vectors": (c_int, [c_vp, c_dbl, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "slp_random_lp_vectors_eq": (c_int, [c_vp, c_dbl, ctypes.c_uint64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "slp_comm_unique_id": (c_int, [c_vp]),
     "slp_comm_init": (c_int, [c_int, c_int, c_vp]),
     "slp_comm_init_host": (c_int, [c_int, c_int, c_vp, c_vp]),

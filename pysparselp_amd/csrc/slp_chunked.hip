@@ -24,29 +24,31 @@ slp_matrix::~slp_matrix() {
 
 namespace slp {
 
-static void refresh_composites(slp_matrix *g) {
-    for (int t = 0; t < 2; ++t) {
-        StripJds &f = t ? g->fat : g->fa;
-        f.parts.clear();
-        f.part_off.clear();
-        f.parts_cols = t != 0;
-        f.ok = !g->chunks.empty();
-        f.nrow = t ? g->a.ncol : g->a.nrow;
-        f.ncol = t ? g->a.nrow : g->a.ncol;
-        f.nnz = g->a.nnz;
-        f.D = 0;
-        f.tall = true;
-        bool first = true;
-        for (size_t k = 0; k < g->chunks.size(); ++k) {
-            const StripJds *p = t ? &g->chunks[k]->fat : &g->chunks[k]->fa;
-            f.parts.push_back(p);
-            f.part_off.push_back(g->chunk_row0[k]);
-            f.D = first ? p->D : (p->D > 0 && f.D > 0 ? std::max(f.D, p->D) : 0);  // > 0: every chunk runs on a value dictionary
-            f.tall = f.tall && p->tall;
-            first = false;
-        }
-        f.fused = f.tall && tall_fuse(f);   // one launch per product when every chunk runs on tall cells of one kind
+void composite_of_chunks(const slp_matrix *g, bool transposed, size_t k0, size_t k1, StripJds &f) {
+    f.parts.clear();
+    f.part_off.clear();
+    f.parts_cols = transposed;
+    f.ok = k1 > k0;
+    f.nrow = transposed ? g->a.ncol : g->a.nrow;
+    f.ncol = transposed ? g->a.nrow : g->a.ncol;
+    f.nnz = 0;
+    f.D = 0;
+    f.tall = true;
+    bool first = true;
+    for (size_t k = k0; k < k1; ++k) {
+        const StripJds *p = transposed ? &g->chunks[k]->fat : &g->chunks[k]->fa;
+        f.parts.push_back(p);
+        f.part_off.push_back(g->chunk_row0[k]);
+        f.nnz += g->chunks[k]->a.nnz;
+        f.D = first ? p->D : (p->D > 0 && f.D > 0 ? std::max(f.D, p->D) : 0);  // > 0: every chunk runs on a value dictionary
+        f.tall = f.tall && p->tall;
+        first = false;
     }
+    f.fused = f.tall && tall_fuse(f);   // one launch per product when every chunk runs on tall cells of one kind
+}
+
+static void refresh_composites(slp_matrix *g) {
+    for (int t = 0; t < 2; ++t) composite_of_chunks(g, t != 0, 0, g->chunks.size(), t ? g->fat : g->fa);
     g->at.nrow = g->a.ncol;
     g->at.ncol = g->a.nrow;
     g->at.nnz = g->a.nnz;

@@ -277,6 +277,10 @@ bool value_dictionary(const CsrDev &a, ValueDict &d);
 bool strip_wanted(const CsrDev &a, int variant);   // variant: 0 fp64 entries, 1 dictionary pairs, 2 dictionary quads, 3 wide strips
 bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int variant);
 void strip_spmv(const StripJds &f, const double *x, double *out);
+// > 0 while a caller needs every row sum as the single chain of the CSR walk (matrix_spmv in SLP_ORDER_SEQUENTIAL): LDS-strip
+// copies built with a strip-range split (S > 1: few row blocks, e.g. a 1/8 row partition) then run one workgroup per row block
+extern int g_strip_single_chain;
+bool strip_has_tall_split(const StripJds &f);   // a tall-cell copy (or a part of a composite) whose strips are shared by S > 1 workgroups
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1);  // one pass, two vectors
 void strip_spmv_with_dict(const StripJds &f, const double *table, const double *x, double *out);     // values table[id] instead of dict[id]
 void strip_spmv_pow(const StripJds &f, double pw, const double *x, double *out);                      // fp64 strips: values |v|^pw
@@ -336,5 +340,11 @@ slp_matrix *matrix_standard_form(slp_matrix *a_eq, slp_matrix *a_ineq);
 void invalidate_derived(slp_matrix *m);  // after the CSR values were modified in place
 void require_csr(const slp_matrix *m, const char *what);  // throws once slp_matrix_release_csr has dropped the CSR entries
 bool matrix_dictionary(slp_matrix *m);   // value_dictionary() of the matrix unless its format policy rules the dictionary out
+// rows r0 .. r1 of a plain matrix (with its CSR) as a matrix of its own: a device copy of that part of the CSR
+slp_matrix *matrix_row_slice(slp_matrix *m, i64 r0, i64 r1);
+// a matrix the caller owns keeps only the product copies built so far: the CSR arrays of both orientations go
+void matrix_drop_csr(slp_matrix *m);
+// chunked matrix: the composite of this orientation's copies of chunks k0 .. k1 (a view: the copies stay the chunks')
+void composite_of_chunks(const slp_matrix *g, bool transposed, size_t k0, size_t k1, StripJds &f);
 // two-stage deterministic reductions; result lands in out[0..k) (device), see slp_reduce.hip
 }  // namespace slp

@@ -65,12 +65,14 @@ __global__ void k_cp_rowsum(i64 m, const i64 *__restrict__ ptr, const double *__
 }
 
 // ---------------------------------------------------------------------------
-// primal half-iteration.  `pre` (optional) holds K^T y already summed over the
-// ranks (multi-GPU); otherwise the column walk happens here.
+// primal half-iteration.  `pre` (optional) holds K^T y already formed (strip copies; multi-GPU: summed over the
+// ranks), `pre2` the inequality rows' share when the two kinds of rows are multiplied apart; otherwise the column
+// walk happens here.
 template <int L, bool FROM_PRE>
 __global__ __launch_bounds__(kBlock) void k_cp_primal(i64 n, const i64 *__restrict__ tptr, const i32 *__restrict__ tidx,
                                                       const double *__restrict__ tval, const double *__restrict__ y,
-                                                      const double *__restrict__ pre, const double *__restrict__ c,
+                                                      const double *__restrict__ pre, const double *__restrict__ pre2,
+                                                      const double *__restrict__ c,
                                                       const double *__restrict__ t, const double *__restrict__ lb,
                                                       const double *__restrict__ ub, double *__restrict__ x,
                                                       double *__restrict__ z, double *__restrict__ d_out, i32 m_eq,
@@ -81,7 +83,9 @@ __global__ __launch_bounds__(kBlock) void k_cp_primal(i64 n, const i64 *__restri
     for (i64 j = group; j < n; j += ngroups) {
         double d;
         if (FROM_PRE) {
-            d = c[j] + pre[j];
+            // pre2: equality and inequality rows were multiplied apart (pre = A_e^T y_e, pre2 = A_i^T y_i): the reference's
+            // d = (c + y_eq * a_eq) + y_ineq * a_ineq  (:206,216)
+            d = pre2 ? (c[j] + pre[j]) + pre2[j] : c[j] + pre[j];
         } else {
             double se, si;
             row_dot_split<L>(tptr, tidx, tval, y, j, sub, m_eq, &se, &si);
@@ -428,7 +432,17 @@ struct slp_cp {
     double alpha = 1, theta = 1;
     int order = SLP_ORDER_AUTO;
     int lanes_rows = 1, lanes_cols = 1;
-    DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, kz, rep, rowparts, colparts, out;
+    DevBuf<double> b, c, lb, ub, t, sigma, x, z, y, d, x4, pre, pre2, ymask, kz, rep, rowparts, colparts, out;
+    // Equality AND inequality rows on strip copies (cp_split_setup): the reference adds a column's two partial sums apart,
+    // d = (c + y_eq * a_eq) + y_ineq * a_ineq (ChambollePockPPD.py:206,216).  split = 1: kt[0] / kt[1] are copies of
+    // A_e^T and A_i^T -- views over the chunks of a chunked matrix cut at m_eq, or copies of the two row ranges that the
+    // solver owns -- multiplied by y + kt_off[]; split = 2: two products over the copy of the whole K^T with the other kind
+    // of rows masked out of y (adding +-0.0 to a running sum leaves it as it is: the same two chains, at twice the bytes).
+    int split = 0;
+    StripJds view[2];
+    slp_matrix *own[2] = {nullptr, nullptr};
+    const StripJds *kt[2] = {nullptr, nullptr};
+    i64 kt_off[2] = {0, 0};
     // ELL copies for short rows (0 = not used)
     int ell_w_rows = 0, ell_w_cols = 0;
     int ell_D = 0;                 // > 0: the ELL copies are packed (index | value id << 24), the values are k's dictionary
@@ -438,24 +452,110 @@ struct slp_cp {
     bool distributed = false;
     bool csr_bound = false;  // an iteration half walks the CSR arrays of `k` (counted in k->csr_bound for borrowed matrices)
     IterGraph graph;
+    ~slp_cp() {
+        delete own[0];
+        delete own[1];
+    }
 };
 
 namespace slp {
 
-// Does the primal half run on the strip copy of K^T?  Not in SEQUENTIAL order with both kinds of rows: there the
-// reference's (c + s_eq) + s_ineq needs the two partial sums of a column apart, which only the CSR walk gives.
+// Both kinds of rows, one GPU: the two partial sums of a column are formed apart (see slp_cp::split).
+static bool cp_mixed(const slp_cp *s) { return !s->distributed && s->m_eq > 0 && s->m_ineq > 0; }
+
+// The copy of K^T a single product of the primal half runs on (all rows of one kind, or the rows partitioned over several
+// GPUs, where the all-reduce re-associates the column sums anyway), else NULL.
 static const StripJds *cp_primal_strips(slp_cp *s) {
-    if (s->distributed || s->m_eq == 0 || s->m_ineq == 0 || s->order != SLP_ORDER_SEQUENTIAL) return fast_format(s->k, true);
-    return nullptr;
+    if (cp_mixed(s)) return nullptr;
+    return fast_format(s->k, true);
+}
+
+__global__ void k_cp_mask(i64 m, i64 lo, i64 hi, const double *__restrict__ y, double *__restrict__ out) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) out[i] = (i >= lo && i < hi) ? y[i] : 0.0;
+}
+
+// out = (rows of kind `which` of K)^T y -- which = 0: the equality rows, 1: the inequality rows; pw >= 0: of |K|^pw
+static void cp_kt_product(slp_cp *s, int which, const double *y, double *out, double pw = -1.0) {
+    hipStream_t st = ctx().stream;
+    if (s->split == 1) {
+        if (pw >= 0.0) strip_spmv_abs_pow(*s->kt[which], pw, y + s->kt_off[which], out);
+        else strip_spmv(*s->kt[which], y + s->kt_off[which], out);
+        return;
+    }
+    const StripJds *f = fast_format(s->k, true);
+    SLP_REQUIRE(f, "Chambolle-Pock: no strip copy of K^T");
+    if (s->ymask.n < (size_t)s->m) s->ymask.alloc((size_t)s->m);
+    hipLaunchKernelGGL(k_cp_mask, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, which ? s->m_eq : (i64)0, which ? s->m : s->m_eq, y,
+                       s->ymask.p);
+    SLP_HIP(hipGetLastError());
+    if (pw >= 0.0) strip_spmv_abs_pow(*f, pw, s->ymask.p, out);
+    else strip_spmv(*f, s->ymask.p, out);
+}
+
+// Settles how the two partial column sums are formed when K has both kinds of rows and runs on strip copies (slp_cp::split).
+// SLP_CP_SPLIT=masked forces the two masked products (tests).
+static void cp_split_setup(slp_cp *s) {
+    s->split = 0;
+    if (!cp_mixed(s)) return;
+    slp_matrix *k = s->k;
+    const bool chunked = !k->chunks.empty();
+    // an ordinary matrix whose copy of K^T would be the CSR walk keeps that walk: it forms the two sums in one pass (row_dot_split)
+    if (!chunked && !k->csr_released && !fast_format(k, true)) return;
+    if (!chunked && k->csr_released && !k->fat.ok) return;
+    const char *e = getenv("SLP_CP_SPLIT");
+    const bool want_masked = e && !strcmp(e, "masked");
+    s->pre2.alloc((size_t)s->n);
+    s->split = 2;
+    if (want_masked) return;
+    if (chunked) {
+        // the chunks were cut at m_eq (problems.random_lp_on_device(m_eq=...), ChunkedDeviceMatrix.from_csr(cut_at=...)): the
+        // equality chunks and the inequality chunks are two composites of their own -- two launches over tall cells, no CSR
+        size_t ke = 0;
+        while (ke < k->chunks.size() && k->chunk_row0[ke] < s->m_eq) ++ke;
+        if (ke == 0 || ke >= k->chunks.size() || k->chunk_row0[ke] != s->m_eq) return;
+        composite_of_chunks(k, true, 0, ke, s->view[0]);
+        composite_of_chunks(k, true, ke, k->chunks.size(), s->view[1]);
+        s->kt[0] = &s->view[0];
+        s->kt[1] = &s->view[1];
+        s->kt_off[0] = s->kt_off[1] = 0;   // (a composite's parts name their own slice of y)
+        s->split = 1;
+        return;
+    }
+    // an ordinary matrix with its CSR: copies of (A_e)^T and (A_i)^T of the solver's own, each built from its row range like a
+    // chunk's (the strip kernels stage y + m_eq with 16-byte loads: m_eq even)
+    if (k->csr_released || (s->m_eq & 1)) return;
+    Phase ph("cp_split_setup: copies of A_eq^T and A_ineq^T");
+    try {
+        for (int w = 0; w < 2; ++w) {
+            const i64 r0 = w ? s->m_eq : 0, r1 = w ? s->m : s->m_eq;
+            s->own[w] = matrix_row_slice(k, r0, r1);
+            s->own[w]->format_policy = k->format_policy;
+            const StripJds *f = fast_format(s->own[w], true);
+            if (!f) {   // a row range too small for a strip copy of its own: the masked products over the whole copy
+                delete s->own[0]; delete s->own[1];
+                s->own[0] = s->own[1] = nullptr;
+                return;
+            }
+            matrix_drop_csr(s->own[w]);
+            s->kt[w] = f;
+            s->kt_off[w] = r0;
+        }
+    } catch (...) {
+        delete s->own[0]; delete s->own[1];
+        s->own[0] = s->own[1] = nullptr;
+        throw;
+    }
+    s->split = 1;
 }
 
 static void cp_setup(slp_cp *s) {
     hipStream_t st = ctx().stream;
     // derived formats are settled here, never lazily inside a (possibly captured) iteration; the transposed CSR is formed only
     // when something walks it (no strip copy of K^T, or the (c + s_eq) + s_ineq order of cp_primal_strips)
-    ensure_transposed(s->k);
     s->distributed = comm_active();
-    if (!cp_primal_strips(s) && s->k->chunks.empty()) build_transpose(s->k);
+    ensure_transposed(s->k);
+    cp_split_setup(s);
+    if (!cp_primal_strips(s) && !s->split && s->k->chunks.empty()) build_transpose(s->k);
     if (fast_format(s->k, false)) s->kz.alloc((size_t)s->m);
     const CsrDev &a = s->k->a, &at = s->k->at;
     s->lanes_rows = lanes_for(a, s->order);
@@ -500,7 +600,17 @@ static void cp_setup(slp_cp *s) {
     // need no CSR arrays.  Equality and inequality rows are summed apart ((0 + s_eq) + s_ineq, :134,144): two products.
     const StripJds *ft = fast_format(s->k, true), *fr = fast_format(s->k, false);
     if (s->n) {
-        if (ft && strip_abs_pow_supported(*ft)) {
+        if (s->split) {
+            // both kinds of rows on strip copies: (0 + s_eq) + s_ineq (:134,144) from the two copies / the two masked products
+            DevBuf<double> ones((size_t)std::max<i64>(s->m, 1)), se((size_t)s->n), si((size_t)s->n);
+            hipLaunchKernelGGL(k_cp_indicator, dim3(grid_for(s->m, kBlock)), dim3(kBlock), 0, st, s->m, (i64)0, s->m, ones.p);
+            cp_kt_product(s, 0, ones.p, se.p, 2.0 - s->alpha);
+            cp_kt_product(s, 1, ones.p, si.p, 2.0 - s->alpha);
+            hipLaunchKernelGGL(k_cp_join_sums, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, se.p, si.p, s->t.p);
+            hipLaunchKernelGGL(k_invert_or_one, dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, s->t.p);
+            SLP_HIP(hipGetLastError());
+            SLP_HIP(hipStreamSynchronize(st));
+        } else if (ft && strip_abs_pow_supported(*ft)) {
             DevBuf<double> ones((size_t)std::max<i64>(s->m, 1));
             if (s->m_eq > 0 && s->m_ineq > 0) {
                 DevBuf<double> se((size_t)s->n), si((size_t)s->n);
@@ -548,7 +658,7 @@ static void cp_setup(slp_cp *s) {
         }
     }
     // ELL copies are the solver's own; everything else that is not a strip copy walks the matrix's CSR arrays
-    s->csr_bound = (s->n > 0 && !cp_primal_strips(s) && !s->ell_w_cols) || (s->m > 0 && !fast_format(s->k, false) && !s->ell_w_rows);
+    s->csr_bound = (s->n > 0 && !cp_primal_strips(s) && !s->split && !s->ell_w_cols) || (s->m > 0 && !fast_format(s->k, false) && !s->ell_w_rows);
 }
 
 static void cp_primal(slp_cp *s, bool store_d) {
@@ -570,16 +680,22 @@ static void cp_primal(slp_cp *s, bool store_d) {
         SLP_HIP(hipGetLastError());
         comm_allreduce_dev(s->pre.p, s->n, 0);
         hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
-                           at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
+                           at.val.p, s->y.p, s->pre.p, (const double *)nullptr, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout,
+                           (i32)s->m_eq, s->m_ineq, opt, s->theta);
+    } else if (s->split) {
+        // both kinds of rows, long columns: A_e^T y_e and A_i^T y_i as two products, d = (c + s_eq) + s_ineq in the elementwise
+        // update -- the reference's order (:206,216) bit for bit, on strip / tall-cell / chunked copies alike
+        cp_kt_product(s, 0, s->y.p, s->pre.p);
+        cp_kt_product(s, 1, s->y.p, s->pre2.p);
+        hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
+                           at.val.p, s->y.p, s->pre.p, s->pre2.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
                            s->m_ineq, opt, s->theta);
     } else if (const StripJds *f = cp_primal_strips(s)) {
-        // long columns: LDS-tiled K^T y, then the elementwise update.  With both kinds of rows this adds the equality
-        // and inequality terms of a column in one chain instead of (c + s_eq) + s_ineq: rounding only, and only
-        // outside SEQUENTIAL order
+        // long columns: LDS-tiled K^T y, then the elementwise update
         strip_spmv(*f, s->y.p, s->pre.p);
         hipLaunchKernelGGL((k_cp_primal<1, true>), dim3(grid_for(s->n, kBlock)), dim3(kBlock), 0, st, s->n, at.ptr.p, at.idx.p,
-                           at.val.p, s->y.p, s->pre.p, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout, (i32)s->m_eq,
-                           s->m_ineq, opt, s->theta);
+                           at.val.p, s->y.p, s->pre.p, (const double *)nullptr, s->c.p, s->t.p, s->lb.p, s->ub.p, s->x.p, s->z.p, dout,
+                           (i32)s->m_eq, s->m_ineq, opt, s->theta);
     } else if (s->ell_w_cols) {
         const int grid = grid_for(s->n, kBlock);
 #define SLP_ELL_PRIMAL(W, P)                                                                                                       \
@@ -599,7 +715,7 @@ static void cp_primal(slp_cp *s, bool store_d) {
         const int lanes = s->lanes_cols;
         const int grid = grid_for(s->n * lanes, kBlock);
         SLP_DISPATCH_LANES(lanes, hipLaunchKernelGGL((k_cp_primal<L, false>), dim3(grid), dim3(kBlock), 0, st, s->n, at.ptr.p,
-                                                     at.idx.p, at.val.p, s->y.p, nullptr, s->c.p, s->t.p, s->lb.p, s->ub.p,
+                                                     at.idx.p, at.val.p, s->y.p, nullptr, nullptr, s->c.p, s->t.p, s->lb.p, s->ub.p,
                                                      s->x.p, s->z.p, dout, (i32)s->m_eq, s->m_ineq, opt, s->theta));
     }
     SLP_HIP(hipGetLastError());
@@ -725,6 +841,8 @@ int slp_cp_iterate(slp_cp *s, int64_t k) {
         else for (i64 it = 0; it < k; ++it) one();
     })
 }
+
+int slp_cp_split_form(const slp_cp *s) { return s ? s->split : -1; }
 
 int slp_cp_primal_step(slp_cp *s) { SLP_API_INT({ SLP_REQUIRE(s, "NULL handle"); cp_primal(s, true); }) }
 

@@ -337,9 +337,25 @@ void require_csr(const slp_matrix *m, const char *what) {
 bool matrix_dictionary(slp_matrix *m) { return m->format_policy == 0 && value_dictionary(m->a, m->vdict); }
 
 void matrix_spmv(slp_matrix *m, bool transposed, const double *x, double *y, int order) {
-    // the strip kernel sums every row with one accumulator in storage order: valid for every `order`
+    // the strip kernels sum every row with one accumulator in storage order: valid for every `order` -- unless the copy was built
+    // with a strip-range split (few row blocks: a 1/8 row partition; SLP_TALL_SPLIT), where a row's sum is S partial sums added
+    // in range order.  SLP_ORDER_SEQUENTIAL asks for the single chain of the CSR walk whatever the partition (the generator's
+    // b_upper = ceil((A x_f + ..) 1000) / 1000 shows the order of a row's additions in a tenth of the rows, slp_random.hip): LDS
+    // strips then run one workgroup per row block over all strips; split tall cells hand over to the CSR kernel while the CSR exists.
     if (const StripJds *f = fast_format(m, transposed)) {
-        strip_spmv(*f, x, y);
+        if (order == SLP_ORDER_SEQUENTIAL && strip_has_tall_split(*f) && m->chunks.empty() && !m->csr_released) {
+            if (transposed) build_transpose(m);
+            launch_spmv(transposed ? m->at : m->a, x, y, order);
+            return;
+        }
+        if (order == SLP_ORDER_SEQUENTIAL) ++g_strip_single_chain;
+        try {
+            strip_spmv(*f, x, y);
+        } catch (...) {
+            if (order == SLP_ORDER_SEQUENTIAL) --g_strip_single_chain;
+            throw;
+        }
+        if (order == SLP_ORDER_SEQUENTIAL) --g_strip_single_chain;
         return;
     }
     require_csr(m, "CSR product");
@@ -526,6 +542,22 @@ static slp_matrix *matrix_gather_rows(slp_matrix *a, i64 count, const i64 *rows,
         throw;
     }
     return m;
+}
+
+slp_matrix *matrix_row_slice(slp_matrix *m, i64 r0, i64 r1) {
+    SLP_REQUIRE(m && 0 <= r0 && r0 <= r1 && r1 <= m->a.nrow, "matrix_row_slice: bad row range");
+    std::vector<i64> rows((size_t)(r1 - r0));
+    for (i64 r = r0; r < r1; ++r) rows[(size_t)(r - r0)] = r;
+    std::vector<double> one(rows.size(), 1.0);   // (v * 1.0 = v)
+    return matrix_gather_rows(m, r1 - r0, rows.data(), one.data());
+}
+
+void matrix_drop_csr(slp_matrix *m) {
+    SLP_HIP(hipStreamSynchronize(ctx().stream));
+    m->a.ptr.release(); m->a.idx.release(); m->a.val.release();
+    m->at.ptr.release(); m->at.idx.release(); m->at.val.release();
+    m->tried_fa = m->tried_fat = true;
+    m->csr_released = true;
 }
 
 }  // namespace slp

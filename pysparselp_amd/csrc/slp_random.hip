@@ -129,10 +129,11 @@ __global__ void k_random_cols(i64 n, uint64_t seed, double *__restrict__ xf, dou
     }
 }
 
-// b_upper = ceil((A x_f + |rand_sparse(m, p)|) * 1000) / 1000   (:43-46)
-__global__ void k_random_bupper(i64 m, uint64_t seed, i64 row_offset, double density, const double *__restrict__ axf,
+// b_upper = ceil((A x_f + |rand_sparse(m, p)|) * 1000) / 1000   (:43-46); the first m_eq rows are equalities: b_eq = A_e x_f (:63)
+__global__ void k_random_bupper(i64 m, i64 m_eq, uint64_t seed, i64 row_offset, double density, const double *__restrict__ axf,
                                 double *__restrict__ b) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (i64)gridDim.x * blockDim.x) {
+        if (i < m_eq) { b[i] = axf[i]; continue; }
         const uint64_t g = (uint64_t)(i + row_offset);
         double extra = 0.0;
         if (u01(seed, STREAM_B, g, 0) < density)
@@ -207,8 +208,14 @@ slp_matrix *slp_matrix_random(int64_t nrow, int64_t ncol, double density, uint64
 
 int slp_random_lp_vectors(slp_matrix *m, double density, uint64_t seed, int64_t row_offset, double *feasible_x, double *c,
                           double *lb, double *ub, double *b_upper) {
+    return slp_random_lp_vectors_eq(m, density, seed, row_offset, 0, feasible_x, c, lb, ub, b_upper);
+}
+
+int slp_random_lp_vectors_eq(slp_matrix *m, double density, uint64_t seed, int64_t row_offset, int64_t m_eq, double *feasible_x,
+                             double *c, double *lb, double *ub, double *b_upper) {
     SLP_API_INT({
         SLP_REQUIRE(m, "slp_random_lp_vectors: NULL matrix");
+        SLP_REQUIRE(m_eq >= 0 && m_eq <= m->a.nrow, "slp_random_lp_vectors_eq: m_eq out of range");
         Phase ph("slp_random_lp_vectors");
         hipStream_t st = ctx().stream;
         const i64 n = m->a.ncol, rows = m->a.nrow;
@@ -224,8 +231,8 @@ int slp_random_lp_vectors(slp_matrix *m, double density, uint64_t seed, int64_t 
             // of an LP draws the same b_upper.  (Round 1-4 took it chunk by chunk from the CSR with the rows spread over 64 lanes:
             // every x gathered from L2, 11 x the CSR's bytes in HBM traffic at 1e7 columns, 45 ms per 2.5e9 entries against 3.)
             matrix_spmv(m, false, xf.p, ax.p, SLP_ORDER_SEQUENTIAL);
-            hipLaunchKernelGGL(k_random_bupper, dim3(grid_for(rows, kBlock)), dim3(kBlock), 0, st, rows, seed, row_offset, density,
-                               ax.p, db.p);
+            hipLaunchKernelGGL(k_random_bupper, dim3(grid_for(rows, kBlock)), dim3(kBlock), 0, st, rows, (i64)m_eq, seed, row_offset,
+                               density, ax.p, db.p);
             SLP_HIP(hipGetLastError());
         }
         if (feasible_x) xf.download(feasible_x, (size_t)n);

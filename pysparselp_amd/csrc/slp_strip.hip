@@ -1139,8 +1139,8 @@ static bool nt_loads() {  // SLP_NT_LOADS=0 / 1: plain / non-temporal entry load
         else { constexpr bool ACC = false; CALL; }         \
     } while (0)
 
-static void wide_launch(const StripJds &f, int nv, const double *x0, const double *x1, double *o0, double *o1, int accum) {
-    const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
+static void wide_launch(const StripJds &f, int nv, const double *x0, const double *x1, double *o0, double *o1, int accum, int S = 0) {
+    const dim3 grid((unsigned)f.B, (unsigned)(S > 0 ? S : f.S)), block(kStripT);
     hipStream_t st = ctx().stream;
     const unsigned int *ent = reinterpret_cast<const unsigned int *>(f.ent.p), *col = reinterpret_cast<const unsigned int *>(f.col.p);
 #define SLP_WIDE(DICT)                                                                                                                \
@@ -1152,6 +1152,8 @@ static void wide_launch(const StripJds &f, int nv, const double *x0, const doubl
 #undef SLP_WIDE
 }
 
+int g_strip_single_chain = 0;
+
 static void strip_combine(const StripJds &f, const double *part, double *out, int accum) {
     hipLaunchKernelGGL(k_strip_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, part, out, accum);
 }
@@ -1162,15 +1164,18 @@ static void strip_spmv_one(const StripJds &f, const double *x, double *out, int 
         tall_spmv(f, x, out, accum);
         return;
     }
+    // g_strip_single_chain (matrix_spmv in SLP_ORDER_SEQUENTIAL): one workgroup per row block walks ALL strips, whatever
+    // strip-range split the copy was built with -- every row sum is the single chain of the CSR walk
+    const int S = g_strip_single_chain > 0 ? 1 : f.S;
     if (f.wide) {
-        wide_launch(f, 1, x, x, f.S > 1 ? f.part.p : out, nullptr, accum);
-        if (f.S > 1) strip_combine(f, f.part.p, out, accum);
+        wide_launch(f, 1, x, x, S > 1 ? f.part.p : out, nullptr, accum, S);
+        if (S > 1) strip_combine(f, f.part.p, out, accum);
         SLP_HIP(hipGetLastError());
         return;
     }
-    const dim3 grid((unsigned)f.B, (unsigned)f.S), block(kStripT);
+    const dim3 grid((unsigned)f.B, (unsigned)S), block(kStripT);
     hipStream_t st = ctx().stream;
-    double *dst = f.S > 1 ? f.part.p : out;
+    double *dst = S > 1 ? f.part.p : out;
     if (f.D > 0) {
 #define SLP_QLAUNCH(NT, ABL)                                                                                                      \
     hipLaunchKernelGGL((k_qstrip_spmv<1, NT, ABL, ACC>), grid, block, 0, st, f.nrow, f.ncol, f.T, f.base.p, f.perm.p, f.slen.p,    \
@@ -1193,7 +1198,7 @@ static void strip_spmv_one(const StripJds &f, const double *x, double *out, int 
         else SLP_WITH_ACC(accum, SLP_DLAUNCH(false));
 #undef SLP_QLAUNCH
 #undef SLP_DLAUNCH
-        if (f.S > 1) strip_combine(f, f.part.p, out, accum);
+        if (S > 1) strip_combine(f, f.part.p, out, accum);
         SLP_HIP(hipGetLastError());
         return;
     }
@@ -1212,7 +1217,7 @@ static void strip_spmv_one(const StripJds &f, const double *x, double *out, int 
     else if (nt) SLP_WITH_ACC(accum, SLP_STRIP_LAUNCH(0, true, true));
     else SLP_WITH_ACC(accum, SLP_STRIP_LAUNCH(0, false, true));
 #undef SLP_STRIP_LAUNCH
-    if (f.S > 1) strip_combine(f, f.part.p, out, accum);
+    if (S > 1) strip_combine(f, f.part.p, out, accum);
     SLP_HIP(hipGetLastError());
 }
 
@@ -1330,6 +1335,15 @@ static void strip_spmv2_one(const StripJds &f, const double *x0, const double *x
 void strip_spmv2(const StripJds &f, const double *x0, const double *x1, double *out0, double *out1) {
     if (f.parts.empty()) { strip_spmv2_one(f, x0, x1, out0, out1, 0); return; }
     for_parts(f, [&](const StripJds &g, i64 xo, i64 oo, int accum) { strip_spmv2_one(g, x0 + xo, x1 + xo, out0 + oo, out1 + oo, accum); });
+}
+
+bool strip_has_tall_split(const StripJds &f) {
+    if (!f.parts.empty()) {
+        for (const StripJds *g : f.parts)
+            if (strip_has_tall_split(*g)) return true;
+        return false;
+    }
+    return f.ok && f.tall && f.S > 1;
 }
 
 size_t strip_format_bytes(const StripJds &f) {

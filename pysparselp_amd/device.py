@@ -148,14 +148,15 @@ class DeviceMatrix:
         _lib.check(self._l.slp_matrix_bench_spmv(self._h, int(transposed), int(order), int(reps), _lib.ptr(ms)))
         return float(ms[0])
 
-    def random_lp_vectors(self, density, seed, row_offset=0, columns=True):
+    def random_lp_vectors(self, density, seed, row_offset=0, columns=True, m_eq=0):
         """``(feasible_x, c, lb, ub, b_upper)`` of the synthetic LP whose rows this matrix holds
-        (``columns=False``: only ``b_upper``, the others ``None`` -- a row chunk of a chunked matrix)."""
+        (``columns=False``: only ``b_upper``, the others ``None`` -- a row chunk of a chunked matrix).
+        ``m_eq``: the first ``m_eq`` rows of this matrix are equalities, ``b[:m_eq] = A_e feasible_x`` (randomLP.py:62-68)."""
         n, m = self.shape[1], self.shape[0]
         xf, c, lb, ub = (np.empty(n), np.empty(n), np.empty(n), np.empty(n)) if columns else (None, None, None, None)
         b = np.empty(m)
-        _lib.check(self._l.slp_random_lp_vectors(self._h, float(density), int(seed), int(row_offset), _lib.ptr(xf),
-                                                 _lib.ptr(c), _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(b)))
+        _lib.check(self._l.slp_random_lp_vectors_eq(self._h, float(density), int(seed), int(row_offset), int(m_eq), _lib.ptr(xf),
+                                                    _lib.ptr(c), _lib.ptr(lb), _lib.ptr(ub), _lib.ptr(b)))
         return xf, c, lb, ub, b
 
 
@@ -182,10 +183,19 @@ class ChunkedDeviceMatrix(DeviceMatrix):
         return self
 
     @classmethod
-    def from_csr(cls, a, chunk_entries=2_500_000_000):
+    def from_csr(cls, a, chunk_entries=2_500_000_000, cut_at=0):
         """A host scipy CSR matrix uploaded in row chunks of about ``chunk_entries`` stored entries (even inner cuts): the way a
-        host LP whose CSR does not fit the device twice over gets resident.  Every chunk must qualify for strip copies."""
+        host LP whose CSR does not fit the device twice over gets resident.  Every chunk must qualify for strip copies.
+        ``cut_at`` (even): a row that must be a chunk boundary -- the number of equality rows in front, so that Chambolle-Pock
+        finds the equality and the inequality rows in chunks of their own (``DeviceCP``: the reference's
+        ``(c + y_eq * a_eq) + y_ineq * a_ineq``, ChambollePockPPD.py:206,216, as two products over the chunks' copies)."""
         cuts = cls.balanced_cuts(a.indptr, chunk_entries)
+        if 0 < cut_at < a.shape[0]:
+            assert cut_at % 2 == 0, "every chunk but the last needs an even row count"
+            indptr = np.asarray(a.indptr, dtype=np.int64)
+            head = cls.balanced_cuts(indptr[:cut_at + 1], chunk_entries)
+            tail = cls.balanced_cuts(indptr[cut_at:] - indptr[cut_at], chunk_entries)
+            cuts = head + [cut_at + c for c in tail[1:]]
         g = cls(a.shape[1], expect_chunks=len(cuts) - 1)
         for r0, r1 in zip(cuts, cuts[1:]):
             g.append(DeviceMatrix.from_csr(a[r0:r1]))
@@ -213,7 +223,14 @@ class ChunkedDeviceMatrix(DeviceMatrix):
         return int(self._l.slp_matrix_chunks(self._h))
 
     @staticmethod
-    def cuts(rows, chunks):
-        """Row boundaries of ``chunks`` nearly equal chunks of ``rows`` rows, every inner boundary even."""
+    def cuts(rows, chunks, cut_at=0):
+        """Row boundaries of ``chunks`` nearly equal chunks of ``rows`` rows, every inner boundary even.  ``cut_at`` (even,
+        inside the rows): a row that must be a boundary -- the equality rows in front of it and the inequality rows behind it
+        are then chunked on their own, in proportion (at least one chunk each, so ``chunks`` is raised to 2 if need be)."""
+        if 0 < cut_at < rows:
+            assert cut_at % 2 == 0, "every chunk but the last needs an even row count"
+            chunks = max(2, chunks)
+            head = min(chunks - 1, max(1, int(round(chunks * cut_at / rows))))
+            return ChunkedDeviceMatrix.cuts(cut_at, head) + [cut_at + c for c in ChunkedDeviceMatrix.cuts(rows - cut_at, chunks - head)[1:]]
         cuts = [(rows * k // chunks) & ~1 for k in range(chunks)] + [rows]
         return [c for i, c in enumerate(cuts) if i == 0 or c > cuts[i - 1]]

@@ -76,8 +76,11 @@ def potts_lp(image_size, coef_potts=0.5, coef_mul=500, seed=1):
     return lp, ground_truth, pix, unary
 
 
-def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1, chunked=False, columns=True):
-    """Synthetic random LP ``min c.x  s.t.  A x <= b_upper, lb <= x <= ub`` (all inequalities).
+def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1, chunked=False, columns=True, m_eq=0):
+    """Synthetic random LP ``min c.x  s.t.  A x <= b_upper, lb <= x <= ub`` (all inequalities; ``m_eq`` > 0: the 10 %-equality
+    variant of randomLP.py:62-68 -- the first ``m_eq`` of the generated rows are equalities ``a_i x = b_i``, ``b[:m_eq] = A_e
+    feasible_x``; a chunked matrix is then cut at ``m_eq`` (even), so that the two kinds of rows live in chunks of their own and
+    Chambolle-Pock forms ``(c + y_eq * a_eq) + y_ineq * a_ineq`` from two products over the chunks' copies).
 
     Generates rows ``row_offset .. row_offset + rows`` (default: all ``m``) of the
     m x n matrix directly in HBM.  Returns ``(DeviceMatrix, feasible_x, c, lb, ub, b_upper)``;
@@ -93,16 +96,17 @@ def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1
     """
     rows = m if rows is None else rows
     assert 0 <= row_offset and row_offset + rows <= m
+    assert 0 <= m_eq <= rows
     if chunks <= 1 and not chunked:
         a = DeviceMatrix.random(rows, n, density, seed, row_offset)
-        xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset, columns=columns)
+        xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset, columns=columns, m_eq=m_eq)
         return a, xf, c, lb, ub, b
-    cuts = ChunkedDeviceMatrix.cuts(rows, max(1, chunks))
+    cuts = ChunkedDeviceMatrix.cuts(rows, max(1, chunks), cut_at=m_eq)
     a = ChunkedDeviceMatrix(n, expect_chunks=len(cuts) - 1)
     for r0, r1 in zip(cuts, cuts[1:]):
         a.append(DeviceMatrix.random(r1 - r0, n, density, seed, row_offset + r0))
     # b_upper = ceil((A x_f + ...) 1000) / 1000 of all rows at once, through the product copies (one launch of the fused product)
-    xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset, columns=columns)
+    xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset, columns=columns, m_eq=m_eq)
     return a, xf, c, lb, ub, b
 
 

@@ -95,12 +95,19 @@ class DeviceCP:
         _lib.check(self._l.slp_cp_dual_step(self._h))
 
     def report(self):
-        """``(energy1, energy2, max_violated_equality, max_violated_inequality_at_z, max_violated_inequality)`` between the
-        two halves of an iteration, as the reference's periodic report computes them (ChambollePockPPD.py:242-329).  Runs on
-        the strip copies when the matrix has them -- also after ``release_csr``."""
+        """``(energy1, energy2, max_violated_equality [max |A_e z - b_e|, :235,275], max_violated_inequality [max (A_i x - b_i),
+        :283], max |A_e x - b_e|)`` between the two halves of an iteration, as the reference's periodic report computes them
+        (ChambollePockPPD.py:242-329).  Runs on the strip copies when the matrix has them -- also after ``release_csr``."""
         out = np.zeros(5)
         _lib.check(self._l.slp_cp_report(self._h, _lib.ptr(out)))
         return out
+
+    def split_form(self):
+        """How ``d = (c + y_eq * a_eq) + y_ineq * a_ineq`` (ChambollePockPPD.py:206,216) is formed when the LP has both kinds of
+        rows and runs on strip copies: 1 -- two products over copies of ``A_e^T`` and ``A_i^T`` (the chunks of a chunked matrix cut at
+        ``m_eq``, or copies of the two row ranges built for this solver); 2 -- two products over the copy of the whole ``K^T`` with
+        the other kind of rows masked out of ``y``; 0 -- one kind of rows only, or the CSR / ELL walk that forms both sums in one pass."""
+        return int(self._l.slp_cp_split_form(self._h))
 
     def x_reduced(self):
         """The iterate over the free variables (what the solver works on)."""

@@ -147,6 +147,47 @@ def _launch(nproc, extra_env, port, more=()):
     return json.loads(lines[0])
 
 
+def _self_launch(nproc, extra_env, more=()):
+    """``python bench.py --gpus N`` as the driver's N = 1 command is shaped: bench.py starts its own ranks (no torch, no launcher)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(nproc), "--steps", "4", "--warmup", "2",
+           "--vars", "30000", "--rows", "40000", "--density", "0.001", "--no-cpu-baseline", "--no-general"] + list(more)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+
+
+def test_self_launched_ranks_fail_loudly_without_a_gpu_or_with_a_dead_rank():
+    """No launcher: ``bench.py --gpus 2`` spawns its two ranks itself.  A rank that cannot run (here: a device index no box has) ends
+    the whole job with a non-zero exit code and no JSON line -- never a hang, never a line from a partial job."""
+    r = _self_launch(2, {"SLP_DEVICE": "63"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "job ended" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_launched_two_ranks_equal_the_launcher_run():
+    """``python bench.py --gpus 2`` (self-launched: child processes + the TCP id exchange of pysparselp_amd/parallel.py, no torch
+    anywhere in the multi-GPU path) gives the line the ``torch.distributed.run`` launch gives: two ranks on one GPU through the
+    host transport, same stored entries, same collectives, the same objective bit for bit."""
+    env = {"SLP_DEVICE": "0", "SLP_COMM_TRANSPORT": "host", "SLP_STRIP_MIN_NNZ": "1"}
+    r = _self_launch(2, env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    mine = json.loads(lines[0])
+    check_line(mine, need_cpu_baseline=False)
+    assert mine["n_gpus"] == 2 and mine["scaling"] == "strong" and mine["config"]["collectives_per_iteration"] == 2.0
+    theirs = _launch(2, env, 29731)
+    assert mine["config"]["nnz"] == theirs["config"]["nnz"] and mine["objective_after_run"] == theirs["objective_after_run"]
+    # no torch in any rank of the self-launched job
+    probe = subprocess.run([sys.executable, "-c", "import sys, runpy; sys.argv = ['bench.py', '--help']\n"
+                            "try:\n    runpy.run_path('bench.py', run_name='__main__')\nexcept SystemExit:\n    pass\n"
+                            "import pysparselp_amd.parallel, pysparselp_amd.scale, pysparselp_amd.admm_cg\n"
+                            "assert 'torch' not in sys.modules, 'torch was imported'"], capture_output=True, text=True, cwd=REPO, timeout=120)
+    assert probe.returncode == 0, probe.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_bench_under_the_launcher_one_rank_rccl():
     """The driver's launch line with N = 1 and the N > 1 plumbing forced on: launcher env, TCP id exchange, a one-rank
