@@ -36,6 +36,10 @@ enum { SLP_ORDER_AUTO = 0, SLP_ORDER_SEQUENTIAL = 1, SLP_ORDER_TREE = 2 };
 
 /* ---- library / device -------------------------------------------------- */
 int slp_version(void);
+/* 0 for the shipped library.  Bit 0: a -DSLP_ABLATION build (timing experiments whose kernels give WRONG results by
+ * design), bit 1: a kernel-lab variant (`make variant`).  The Python loader refuses a non-zero library unless
+ * SLP_LIB_VARIANT names it. */
+int slp_build_flags(void);
 /* Number of HIP devices visible, or -1 (see slp_last_error). */
 int slp_device_count(void);
 /* Bind this process to `device` and create the library's stream. */

@@ -159,6 +159,13 @@ class StreamedCsr(ProductsOnly):
         return StreamedCsr(self._ncol, self._all_cuts, self._source, power=self._power, rows=(r0, r1), cache_bytes=self._cache_bytes,
                            _cache=self._cache)
 
+    def stacked_rmatvec(self, front, y):
+        """``y * [front; self]`` for the row range right in front of this one (the equality rows of the same LP): ONE chain of
+        additions per column over both ranges, as the stored standard form [A_e 0; A_i -I] has it (ADMM.py:148)."""
+        assert isinstance(front, StreamedCsr) and front._source is self._source and front._r0 + front.shape[0] == self._r0
+        assert front._power == self._power
+        return self.row_range(front._r0, self._r0 + self.shape[0])._rmv(y)
+
     def _chunks(self):
         for k in self._ks:
             c = self._cache.get(k)
@@ -602,9 +609,9 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
     n = np.asarray(c).size
     c = _f64(c)
     if isinstance(a_ineq, ProductsOnly):
-        assert a_eq is None and b_lower is None and use_preconditioning and not explicit_m
+        assert (a_eq is None or isinstance(a_eq, ProductsOnly)) and b_lower is None and use_preconditioning and not explicit_m
         return _lp_admm_cg_over_products(c, a_ineq, b_upper, lb, ub, x0, gamma_eq, gamma_ineq, nb_iter, callback_func, max_time,
-                                         nb_iter_plot, iterate_hook)
+                                         nb_iter_plot, iterate_hook, a_eq, beq)
     a_eq, a_ineq = as_csr(a_eq), as_csr(a_ineq)
     if x0 is None:
         x0 = np.zeros(c.size)
@@ -622,36 +629,54 @@ def lp_admm_cg(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, x0=None, gamma_eq
 
 
 def _lp_admm_cg_over_products(c, ops, b_upper, lb, ub, x0, gamma_eq, gamma_ineq, nb_iter, callback_func, max_time, nb_iter_plot,
-                              iterate_hook):
-    """``lp_admm_cg`` for an all-inequality LP ``A x <= b_upper`` known through its products only (``ProductsOnly``: a size whose
-    CSR no host holds).  The same set-up and the same iteration, with the two row scalings of ADMM.py:82,91 (tools.py:272-290)
-    and the slack columns of tools.py:88-127 carried BESIDE the products instead of inside stored entries:
-        a v   = s2 * (s1 * (A v[:n]) - v[n:])          a^T y = [A^T (s1 * s2 * y) ; -(s2 * y)]
-    with s1 = 1 / |row of A|, s2 = 1 / |row of [s1 A, -I]|.  Equal to the stored-entry form in exact arithmetic; in fp64 the
-    roundings differ (s * (sum of a x) for sum of (s a) x; the norms from one sum of squares), as the device's deferred row
-    scaling does.  Pinned against the stored-entry form on host CSRs by tests/test_oracle_golden.py (1e-12)."""
-    m, n = ops.shape
+                              iterate_hook, ops_eq=None, beq=None):
+    """``lp_admm_cg`` for an LP ``A_e x = b_e, A_i x <= b_upper`` known through its products only (``ProductsOnly``: a size whose
+    CSR no host holds; ``ops_eq`` None: all inequalities).  The same set-up and the same iteration, with the two row scalings of
+    ADMM.py:77,82,91 (tools.py:272-290) and the slack columns of tools.py:88-127 (inequality rows only) carried BESIDE the products
+    instead of inside stored entries: with K = [A_e; A_i], s1 = 1 / |row of K|, s2 = 1 / |row of [s1 A_e, 0; s1 A_i, -I]|,
+        a v   = s2 * (s1 * (K v[:n]) - [0; v[n:]])          a^T y = [K^T (s1 * s2 * y) ; -(s2 * y)[m_e:]]
+    Equal to the stored-entry form in exact arithmetic; in fp64 the roundings differ (s * (sum of a x) for sum of (s a) x; the
+    norms from one sum of squares), as the device's deferred row scaling does.  Pinned against the stored-entry form on host
+    CSRs by tests/test_oracle_golden.py (1e-12)."""
+    mi, n = ops.shape
+    me = ops_eq.shape[0] if ops_eq is not None else 0
+    m = me + mi
     ones = np.ones(n)
+
+    def k_mv(v):      # K v, equality rows first
+        return ops._matvec(v) if not me else np.concatenate((ops_eq._matvec(v), ops._matvec(v)))
+
+    def k_rmv(y):     # K^T y: the stacked matrix's single chain per column = the equality rows' chain continued by the others'
+        if not me:
+            return ops._rmatvec(y)
+        if hasattr(ops, "stacked_rmatvec"):
+            return ops.stacked_rmatvec(ops_eq, y)
+        return ops_eq._rmatvec(np.ascontiguousarray(y[:me])) + ops._rmatvec(np.ascontiguousarray(y[me:]))
+
     rowsq = ops._abs_pow_matvec(ones, 2.0)  # sum_j a_ij^2, storage order (orc_row_scale_l2)
+    if me:
+        rowsq = np.concatenate((ops_eq._abs_pow_matvec(ones, 2.0), rowsq))
     norm1 = np.sqrt(rowsq)
     norm1[norm1 == 0] = 1
     s1 = 1 / norm1
-    bu1 = s1 * _f64(b_upper)
-    norm2 = np.sqrt((s1 * s1) * rowsq + 1.0)   # rows of [s1 A, -I]
+    bu1 = s1[me:] * _f64(b_upper)
+    slack_sq = np.concatenate((np.zeros(me), np.ones(mi)))
+    norm2 = np.sqrt((s1 * s1) * rowsq + slack_sq)   # rows of [s1 A_e, 0; s1 A_i, -I]
+    norm2[norm2 == 0] = 1
     s2 = 1 / norm2
     s12 = s1 * s2
     x0 = np.zeros(n) if x0 is None else _f64(x0)
-    x = np.hstack((x0, s1 * ops._matvec(x0)))            # tools.py:125  [x0 ; Ai x0]
-    c2 = np.hstack((c, np.zeros(m)))
-    lb2 = np.hstack((_f64(lb), np.full(m, -np.inf)))
+    x = np.hstack((x0, s1[me:] * ops._matvec(x0)))            # tools.py:125  [x0 ; Ai x0]
+    c2 = np.hstack((c, np.zeros(mi)))
+    lb2 = np.hstack((_f64(lb), np.full(mi, -np.inf)))
     ub2 = np.hstack((_f64(ub), bu1))
-    b = s2 * np.zeros(m)
+    b = s2 * np.concatenate((s1[:me] * _f64(beq) if me else np.zeros(0), np.zeros(mi)))
 
     def a_mv(v):
-        return s2 * (s1 * ops._matvec(np.ascontiguousarray(v[:n])) - v[n:])
+        return s2 * (s1 * k_mv(np.ascontiguousarray(v[:n])) - np.concatenate((np.zeros(me), v[n:])))
 
     def a_rmv(y):
-        return np.hstack((ops._rmatvec(s12 * y), -(s2 * y)))
+        return np.hstack((k_rmv(s12 * y), -(s2 * y)[me:]))
 
     return _admm_cg_iterations(n, c2, a_mv, a_rmv, m, b, lb2, ub2, x, gamma_eq, gamma_ineq, nb_iter, callback_func, max_time,
                                nb_iter_plot, iterate_hook, None)

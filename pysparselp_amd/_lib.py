@@ -28,6 +28,7 @@ c_vp = ctypes.c_void_p
 # name -> (restype, argtypes); mirrors include/slp_hip.h one to one
 _SIGNATURES = {
     "slp_version": (c_int, []),
+    "slp_build_flags": (c_int, []),
     "slp_device_count": (c_int, []),
     "slp_init": (c_int, [c_int]),
     "slp_synchronize": (c_int, []),
@@ -160,6 +161,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    flags = int(lib.slp_build_flags())
+    if flags and not _VARIANT:
+        raise SlpError(f"{LIB_PATH} is a kernel-lab build (slp_build_flags() = {flags}: bit 0 = -DSLP_ABLATION kernels with parts removed, "
+                       "WRONG results; bit 1 = `make variant`): it is only loaded when SLP_LIB_VARIANT names it.  Rebuild with "
+                       "`make -C pysparselp_amd/csrc clean all`.")
     _lib = lib
     return lib
 

@@ -434,10 +434,6 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     const int l = l0 + d;
-#ifdef SLP_GS_BANDS_ABLATE_FETCH  // (lab: wrong results) the fetch wave only keeps the barriers company
-                    if (l < nlev) __syncthreads();
-                    continue;
-#endif
                     wait_for(rqv[d]);        // the lower bands have stored what level l + D reads
                     rqv[d] = rq[(l + D + 1) * 16];
 #pragma unroll
@@ -459,9 +455,6 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
                         m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
                         m = min(m, min(min(min(c.x, c.y), min(c.z, c.w)), min(min(e.x, e.y), min(e.z, e.w))));
                     }
-#ifdef SLP_GS_BANDS_ABLATE_PUBLISH
-                    if (l + 1 < nlev) m = kGsDone;   // (lab: wrong results)
-#endif
                     __hip_atomic_store(mine, m, __ATOMIC_RELAXED, SLP_GS_FSCOPE);
                     if (l < nlev) __syncthreads();
                 }
@@ -496,18 +489,13 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
         double xv[kGsEntries];
 #pragma unroll
         for (int e = 0; e < kGsEntries; ++e) xv[e] = win[me.code[e]];
-#if defined(SLP_GS_ABLATE) && SLP_GS_ABLATE == 4
-        for (int e = 0; e < kGsEntries; ++e) xv[e] = 1.0 + me.code[e];
-#endif
         // (the scheduler must not issue the load into rec[j] above the reads of its old value: the two would then be live
         // together, in two registers, and the copy between them lands right behind the load and waits for it)
         __builtin_amdgcn_sched_barrier(0);
         load_rec(j, s + RA);                                  // the header of wave slot s has been read out
-#if !defined(SLP_GS_ABLATE) || SLP_GS_ABLATE != 1
         la[(j + 4) % RA] = lanes[slot_a];
         lrow[(j + 4) % RA] = lane_row[slot_a];
         dv[(jb + 2) % RB] = dyn[slot_b];
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if (FAR) {
             if (meta & 128u) {  // uniform over the wave
@@ -520,11 +508,7 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
         double term[kGsEntries];
 #pragma unroll
         for (int e = 0; e < kGsEntries; ++e) term[e] = xv[e] * dv[jb].v[e];
-#if defined(SLP_GS_ABLATE) && SLP_GS_ABLATE == 3
-        const int seg = me.info & 15, rounds = 1;
-#else
         const int seg = me.info & 15, rounds = (int)((meta >> 1) & 31u);
-#endif
         double v = 0.0, carry = 0.0;
         for (int r = 0; r < rounds; ++r) {
             if (seg == r) {
@@ -545,11 +529,7 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
                 v = w * nv + (1 - w) * r.xi;
             }
             const bool last = me.info & 16;
-#ifdef SLP_GS_BANDS_ABLATE_SC1
-            if (BANDS) *(last ? x + lrow[j] : spill) = v;   // (lab: wrong results)
-#else
             if (BANDS) __hip_atomic_store(last ? x + lrow[j] : spill, v, __ATOMIC_RELAXED, SLP_GS_XSCOPE);  // written through: other CUs read it
-#endif
             else *(last ? x + lrow[j] : spill) = v;
             win[last && me.ldsw != 0xffff ? (int)me.ldsw : kGsOne + 1 + lane] = v;
             if (BANDS) {
@@ -564,12 +544,8 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_gs_sweep_windowed(const int *
                 if (lane == 0) progw[wave] = stored;
             }
         }
-#if !defined(SLP_GS_ABLATE) || SLP_GS_ABLATE != 1
         issue_c(jc, (j + 2) % RA);                            // rw[jc] is free again
-#endif
-#if !defined(SLP_GS_ABLATE) || SLP_GS_ABLATE != 2
         if (meta & 64u) __syncthreads();                      // the wave's last wave slot of a level: the next level reads these x
-#endif
     };
 #pragma unroll
     for (int j = 0; j < RA; ++j) load_rec(j, j);

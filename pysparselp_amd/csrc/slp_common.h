@@ -13,6 +13,15 @@
 
 #include "../../include/slp_hip.h"
 
+// Kernel-lab switches never reach libslp_hip.so.  Timing experiments with parts of a kernel removed (WRONG results by design)
+// exist only behind -DSLP_ABLATION (`make ablation` / `make variant`, separate objects, a library of its own that
+// pysparselp_amd/_lib.py loads only when SLP_LIB_VARIANT names it: slp_build_flags() != 0).  The lab forms of the tall-cell and
+// Gauss-Seidel kernels are patches under tools/lab/patches/; their macros must not appear in an ordinary build:
+#if !defined(SLP_ABLATION) && (defined(SLP_TALL_ABL) || defined(SLP_GS_ABLATE) || defined(SLP_GS_BANDS_ABLATE_FETCH) || \
+                               defined(SLP_GS_BANDS_ABLATE_PUBLISH) || defined(SLP_GS_BANDS_ABLATE_SC1) || defined(SLP_STRIP_ABLATE))
+#error "a kernel-lab macro (SLP_TALL_ABL / SLP_GS_ABLATE / SLP_GS_BANDS_ABLATE_* / SLP_STRIP_ABLATE) without -DSLP_ABLATION: ablated kernels give wrong results and must not be built into libslp_hip.so"
+#endif
+
 namespace slp {
 
 typedef int64_t i64;

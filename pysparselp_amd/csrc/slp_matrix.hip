@@ -568,6 +568,19 @@ extern "C" {
 
 int slp_version(void) { return 100; }
 
+// 0 for the shipped library.  Bit 0: built with -DSLP_ABLATION (kernels with parts removed: wrong results); bit 1: a kernel-lab
+// variant (`make variant`, -DSLP_LAB_VARIANT).  pysparselp_amd/_lib.py refuses a non-zero library unless SLP_LIB_VARIANT asked for it.
+int slp_build_flags(void) {
+    int f = 0;
+#ifdef SLP_ABLATION
+    f |= 1;
+#endif
+#ifdef SLP_LAB_VARIANT
+    f |= 2;
+#endif
+    return f;
+}
+
 slp_matrix *slp_matrix_gather_rows(slp_matrix *a, int64_t count, const int64_t *rows, const double *scale) {
     SLP_API_PTR({ return matrix_gather_rows(a, count, rows, scale); })
 }

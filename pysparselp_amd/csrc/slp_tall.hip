@@ -177,12 +177,7 @@ __device__ __forceinline__ unsigned long long tall_block_scan(unsigned long long
 // ordered against them, so no release / acquire -- on this chip those are write-backs and invalidations of a whole L2, twice
 // per cell and once per poll (measured: 132 ms per 2.5e9 entries with them).  The writer stamps `w` first, then `p`; a reader takes `w`,
 // then `p`, and retries until both carry the same level.
-#ifdef SLP_TALL_BUILD_PROF   // lab: where a cell's time goes -- 100 MHz ticks between marks, summed over all cells by thread 0 of every workgroup
-__device__ unsigned long long g_tb_prof[16];
-#define SLP_TB_PROF(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_tb_prof[k], now_ - tb_last_); tb_last_ = now_; } } while (0)
-#else
 #define SLP_TB_PROF(k) do {} while (0)
-#endif
 struct TallScan {
     unsigned long long *w;       // level << 62 | payload words (own, or up to and including the cell)
     unsigned long long *p;       // level << 62 | packets
@@ -232,9 +227,6 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
     __shared__ i64 s_cell;
     __shared__ unsigned long long s_before_w, s_before_p;
     const int p = threadIdx.x;
-#ifdef SLP_TALL_BUILD_PROF
-    unsigned long long tb_last_ = wall_clock64();
-#endif
     auto tile_of = [&](i64 t) -> unsigned int { return t >= 0 ? (unsigned int)(t << cshift) : kNoTile; };
     for (;;) {
         if (p == 0) {
@@ -388,11 +380,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
             // classes ran dry at different lanes, the lists of the last ~150 lanes came out between 0 and the target at random, and
             // the non-increasing envelope over them was paid in skip items: 2 % of the words at the metric's density (lists of 4
             // from 3983 items), 20 % where lists are 5 long.
-#ifdef SLP_TALL_DEAL_CEIL
-            const unsigned int tau = ((unsigned)n + kTallT - 1) / kTallT;
-#else
             const unsigned int tau = (unsigned)n / kTallT + ((unsigned)p < (unsigned)n % kTallT ? 1u : 0u);
-#endif
             const unsigned int want = (fill && c0p < tau) ? tau - c0p : 0u;
             ccls[(p >> 5) * 32 + rho] = want;
             __syncthreads();
@@ -878,16 +866,6 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
         hipLaunchKernelGGL(k_tall_streams, dim3(grid_for(V, kBlock)), dim3(kBlock), 0, st, V, T, S, cellptr.p, sc, ext.p);
         SLP_HIP(hipGetLastError());
         ext.download(hext.data(), hext.size());
-#ifdef SLP_TALL_BUILD_PROF
-        {
-            unsigned long long hp[16], zero[16] = {0};
-            SLP_HIP(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_tb_prof), sizeof hp));
-            SLP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tb_prof), zero, sizeof zero));
-            fprintf(stderr, "[tall build prof] cells %lld, us per cell and mark:", (long long)ncell);
-            for (int i = 0; i < 11; ++i) fprintf(stderr, " %d:%.2f", i, (double)hp[i] / 100.0 / (double)ncell);
-            fprintf(stderr, "\n");
-        }
-#endif
         tot_w = hext[4 * (V - 1)] + hext[4 * (V - 1) + 1];
         tot_p = hext[4 * (V - 1) + 2] + hext[4 * (V - 1) + 3];
         if (tot_w <= cap_w && tot_p <= cap_p) break;

@@ -66,12 +66,8 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
     }
     // this lane's dword of every header -- through a GLOBAL-address-space pointer: a pointer read from a structure in memory is
     // a generic one to the compiler, its loads become flat_load (complete out of order: every wait a vmcnt(0), the pipeline gone)
-#ifdef SLP_TALL_FLAT  // lab: the generic-pointer form (drains the pipeline at every packet group), for re-measurement
-    const unsigned int *hd = wg.dir + (p & 7);
-#else
     typedef const unsigned int __attribute__((address_space(1))) *gptr_t;
     const gptr_t hd = (gptr_t)(unsigned long long)wg.dir + (p & 7);
-#endif
     const int npk = (int)wg.npk - 2 * kTallDepth;                             // the last 2 x depth packets are prefetch targets only
     // buffer descriptors: lanes without work address past num_records (the load returns 0 without a memory request)
     const __amdgpu_buffer_rsrc_t rs_pay =
@@ -96,21 +92,12 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
     // this lane's two 16-byte pieces of an x-tile (doubles 2p, 2p + 1 of each tile half).  A piece that straddles the end of x
     // (odd width) may fetch the 8 bytes behind it: every device block carries 16 bytes of slack, and no item names that column
     auto load_tile = [&](TallRegs<DICT> &g, const unsigned int xo) {
-#ifdef SLP_TALL_X64   // lab: four 8-byte loads (rounds 3-4)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            static_assert(C == kTallC, "SLP_TALL_X64: 4096-column strips only");
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo + 8u * (unsigned int)(i & 1) + (i >> 1) * (unsigned int)(kTallC * 4), 0, 0);
-            g.x[i] = __hiloint2double((int)v[1], (int)v[0]);
-        }
-#else
 #pragma unroll
         for (int i = 0; i < kPieces; ++i) {
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo + (unsigned int)i * (unsigned int)(C * 4), 0, 0);
             g.x[2 * i] = __hiloint2double((int)v[1], (int)v[0]);
             g.x[2 * i + 1] = __hiloint2double((int)v[3], (int)v[2]);
         }
-#endif
     };
 
     auto issue = [&](TallRegs<DICT> &g, unsigned int h) {
@@ -136,18 +123,13 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
         }
         // columns past ncol read 0: the displacement of each double is part of the voffset, which the descriptor's range check
         // covers (an soffset is not checked on gfx9 raw buffers)
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 6 || SLP_TALL_ABL == 7)   // lab (wrong results): no x-tile loads
-        const unsigned int xo = kOob + 0u * xs;
-#else
         // lane p carries doubles 2p, 2p + 1 of the tile's first half and of its second half: consecutive lanes then write
         // consecutive 16-byte pieces of the LDS tile (no bank conflicts; with 4p .. 4p + 3 per lane the two 16-byte writes of a
         // lane pair collided -- the tile write was the largest single item of the kernel's ablation, 0.9 of 4.1 ms)
         const unsigned int xo = (xs == kNoTile || !tile_lane) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
-#endif
         load_tile(g, xo);
     };
 
-#ifndef SLP_TALL_WHOLE_ISSUE   // (lab: SLP_TALL_WHOLE_ISSUE = all loads of a packet behind all of its items, as in rounds 3-4)
     // issue() in two halves: the registers of slots 0-3 are free once the first four items are done, so their loads for the packet
     // `depth` ahead go out BETWEEN the two groups of items (in the shadow of the LDS latency) instead of behind all of them
     auto issue_part = [&](TallRegs<DICT> &g, unsigned int h, const int part) {
@@ -161,61 +143,40 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
         // loads for slots 4-7 and their fifth bytes -- a uniform branch; consume() takes the second group under the same test.  The
         // compiler then counts the loads in flight by the path without them (vmcnt(24-26) instead of 36-41): exact for those
         // packets, a shorter prefetch distance behind a packet that has the second group.  3.30 / 3.30 -> 3.25 / 3.22 ms on the
-        // slice, unchanged where lists are five long (-DSLP_TALL_FULL_ISSUE = rounds 3-5a, profiles/r05_tall_half_packets.log).
-#ifndef SLP_TALL_FULL_ISSUE
+        // slice, unchanged where lists are five long (profiles/r05_tall_half_packets.log).
         if (part == 0 || wbase < c[4]) {   // (per wave: the waves past the fifth items' lanes skip them too)
-#else
-        {
-#endif
 #pragma unroll
-        for (int k = 4 * part; k < 4 * part + 4; ++k) {
-            g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);
-            if (!DICT) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_val, (unsigned)p < c[k] ? 2u * mine : kOob, 2u * so, 2);
-                g.val[DICT ? 0 : k] = __hiloint2double((int)v[1], (int)v[0]);
+            for (int k = 4 * part; k < 4 * part + 4; ++k) {
+                g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);
+                if (!DICT) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_val, (unsigned)p < c[k] ? 2u * mine : kOob, 2u * so, 2);
+                    g.val[DICT ? 0 : k] = __hiloint2double((int)v[1], (int)v[0]);
+                }
+                so += c[k] * 4u;
             }
-            so += c[k] * 4u;
+            if (DICT) {
+                if (part == 0) so += (c[4] + c[5] + c[6] + c[7]) * 4u;   // the fifth bytes follow the eight slots: slots 0-3, then slots 4-7
+                else so += c[0] * 4u;
+                g.hi[DICT ? part : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4 * part] ? mine : kOob, so, 2);
+            }
         }
-        if (DICT) {
-            if (part == 0) so += (c[4] + c[5] + c[6] + c[7]) * 4u;   // the fifth bytes follow the eight slots: slots 0-3, then slots 4-7
-            else so += c[0] * 4u;
-            g.hi[DICT ? part : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4 * part] ? mine : kOob, so, 2);
-        }
-        }
-#ifndef SLP_TALL_XLOAD
-#define SLP_TALL_XLOAD 0   // lab: where the tile loads of the packet `depth` ahead are issued: 0 behind all items, 1 between the groups, 2 behind the tile store
-#endif
-        if (part == (SLP_TALL_XLOAD == 1 ? 0 : 1) && SLP_TALL_XLOAD != 2) {
+        if (part == 1) {   // the tile of the packet `depth` ahead: behind all of this packet's items
             const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
             const unsigned int xo = (xs == kNoTile || !tile_lane) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
             load_tile(g, xo);
         }
     };
-#if SLP_TALL_XLOAD == 2
-    auto issue_tile = [&](TallRegs<DICT> &g, unsigned int h) {
-        const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
-        const unsigned int xo = (xs == kNoTile || !tile_lane) ? kOob : (xs + 2u * (unsigned int)p) * 8u;
-        load_tile(g, xo);
-    };
-#endif
-#endif
 
     auto consume = [&](TallRegs<DICT> &g, unsigned int h, unsigned int hnext, auto &&between) {
         const unsigned int xw = (unsigned int)__builtin_amdgcn_readlane((int)h, 1);
         const unsigned int c4 = (unsigned int)__builtin_amdgcn_readlane((int)h, 4) & 0xffffu;   // lanes with a fifth item
         if (xw & kPktNewCell) {
             // sums of the previous cell (other lanes owned these rows there) and the x-tile: LDS only, loads stay in flight
-#if !defined(SLP_TALL_ABL) || (SLP_TALL_ABL != 4 && SLP_TALL_ABL != 7)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
             cur ^= 1;
         }
         auto stage_tile = [&]() {
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 5 || SLP_TALL_ABL == 7)   // lab: no x-tile LDS write
-            if (false) {
-#else
             if ((xw & 0x7fffffffu) != kNoTile) {
-#endif
                 // (Bringing the tile in by LDS-DMA -- __builtin_amdgcn_global_load_lds, no registers, no ds_write -- was built and
                 // measured: 4.71 ms against 3.99.  With two tile buffers the DMA can only start at the cell's barrier and must
                 // have landed by the next one, 1.6 us later; the register path issues the loads four cells ahead.  A third buffer
@@ -225,22 +186,14 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
                 if (kPieces == 2) *reinterpret_cast<double2 *>(dst + C / 2) = make_double2(g.x[2], g.x[3]);
             }
         };
-        // WHERE the wave stores its share of the NEXT cell's x-tile (it only has to be there by the next cell's barrier; lab:
-        // -DSLP_TALL_STAGE=0..3).  Round 5, with the predicate-free item code: right behind the barrier (0) 3.28-3.29 ms on the
+        // WHERE the wave stores its share of the NEXT cell's x-tile (it only has to be there by the next cell's barrier; lab
+        // patch: tools/lab/patches).  Round 5, with the predicate-free item code: right behind the barrier (0) 3.28-3.29 ms on the
         // 2.5e6 x 1e7 slice; behind the first four items (1) 3.74-3.77; between the two item groups' loads (2) 3.44-3.46; behind all
         // of the packet's items (3) 3.44 (profiles/r05_tall_stage_position.log).  Round 4's kernel -- a select and a compare
         // per store -- had it the other way round (behind the items 3.92 against 3.99 behind the barrier: there every wave's
         // gathers queued behind 32 KB of stores): with the shorter item code the stores are out of the way before the first
         // gathers are ready to issue, and they no longer sit between a packet's items and the next packet's.
-#ifndef SLP_TALL_STAGE
-#define SLP_TALL_STAGE 0
-#endif
-#if SLP_TALL_STAGE == 0
         stage_tile();
-#endif
-#if !defined(SLP_TALL_WHOLE_ISSUE) && SLP_TALL_XLOAD == 2
-        issue_tile(g, hnext);   // (the tile's registers are free again)
-#endif
         const double *__restrict__ tile = xt[cur];
         // Four slots at a time: all twelve LDS reads (running sums, values, x) are issued together, the products do not
         // depend on the sums, and a sum that the lane has just updated is carried in a register (a lane's items of one
@@ -253,76 +206,31 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
             for (int k = 0; k < 4; ++k) {
                 w[k] = g.lo[k0 + k];
                 if (DICT) {
-#if defined(SLP_TALL_ABL) && SLP_TALL_ABL == 9   // lab (wrong results): what a 4-byte item would cost -- no fifth byte
-                    hb[k] = 0;
-                    row[k] = (w[k] >> 23) | ((unsigned)(p & 7) << 9);
-#else
                     hb[k] = (g.hi[DICT ? (k0 >> 2) : 0] >> (8 * k)) & 0xffu;
                     row[k] = (w[k] >> 23) | (hb[k] << 9);          // local row + 1; 0 = the scratch cell
-#endif
                 } else {
                     hb[k] = 0;
                     row[k] = w[k] >> kTallColBits;
                 }
             }
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)   // lab: no running-sum traffic
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ar[k] = (double)row[k];
-#else
 #pragma unroll
             for (int k = 0; k < 4; ++k) ar[k] = acc[row[k]];
-#endif
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 1 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)   // lab: no value / x gathers
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pr[k] = (double)(w[k] & 0x7fffffu) * tile[p];
-#elif defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 10 || SLP_TALL_ABL == 11 || SLP_TALL_ABL == 12)   // lab (wrong results): gathers without bank conflicts -- the index's low five bits are the lane's (10 both, 11 values only, 12 x only)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned int iv = w[k] & ((1u << kTallIdBits) - 1), ix = (w[k] >> kTallIdBits) & (kTallC - 1);
-                pr[k] = dv[SLP_TALL_ABL != 12 ? ((iv & ~31u) | ((unsigned)p & 31u)) : iv] * tile[SLP_TALL_ABL != 11 ? ((ix & ~31u) | ((unsigned)p & 31u)) : ix];
-            }
-#else
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 pr[k] = DICT ? dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)]
                              : (POW ? abs_pow(g.val[DICT ? 0 : k0 + k], pw) * 1.0 : g.val[DICT ? 0 : k0 + k]) * tile[w[k] & (kTallC - 1)];
-#endif
             t[0] = ar[0] + pr[0];
-#if defined(SLP_TALL_ABL) && SLP_TALL_ABL == 8   // lab (wrong results): no carry between a lane's items of one row
-#pragma unroll
-            for (int k = 1; k < 4; ++k) t[k] = ar[k] + pr[k];
-#else
 #pragma unroll
             for (int k = 1; k < 4; ++k) t[k] = ((row[k] == row[k - 1]) ? t[k - 1] : ar[k]) + pr[k];
-#endif
-#if defined(SLP_TALL_ABL) && (SLP_TALL_ABL == 2 || SLP_TALL_ABL == 3 || SLP_TALL_ABL == 7)
-            acc[p] = ((t[0] + t[1]) + t[2]) + t[3];   // one store per group keeps the work alive
-#else
             // Unconditional stores, no predicate at all: what is not this lane's item lands in the scratch cell acc[0] by its own
             // decoding -- a packet's items stay ONE basic block, which the instruction scheduler may interleave with the loads of
             // the packets ahead (rounds 3-4: a branch, then a select, per store: 3 vector instructions per item more)
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[row[k]] = t[k];
-#endif
         };
-#ifndef SLP_TALL_WHOLE_ISSUE
         group(0);   // (a wave without items -- nearly never -- reads cell 0 of the arrays and stores into the scratch cell)
-#if SLP_TALL_STAGE == 1
-        stage_tile();
-#endif
         between();
-#if SLP_TALL_STAGE == 2
-        stage_tile();
-#endif
         if (wbase < c4) group(4);
-#else
-        group(0);
-        if (wbase < c4) group(4);
-        between();
-#endif
-#if SLP_TALL_STAGE == 3
-        stage_tile();
-#endif
     };
 
     // prologue: headers of the first 2 x depth packets, payload of the first depth
@@ -334,13 +242,8 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
     for (int jj = 0; jj < npk; jj += 2 * kDepth) {
 #pragma unroll
         for (int u = 0; u < 2 * kDepth; ++u) {
-#ifndef SLP_TALL_WHOLE_ISSUE
             consume(regs[u % kDepth], hw[u], hw[(u + kDepth) % (2 * kDepth)], [&]() { issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 0); });   // packet jj + u
             issue_part(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)], 1);                                               // (payload of packet jj + u + depth)
-#else
-            consume(regs[u % kDepth], hw[u], 0u, []() {});                  // packet jj + u
-            issue(regs[u % kDepth], hw[(u + kDepth) % (2 * kDepth)]);       // payload of packet jj + u + depth
-#endif
             hw[u] = hd[(i64)(jj + u + 2 * kDepth) * 8];                     // header of packet jj + u + 2 depth
         }
     }

@@ -230,7 +230,30 @@ class ChunkedDeviceMatrix(DeviceMatrix):
         if 0 < cut_at < rows:
             assert cut_at % 2 == 0, "every chunk but the last needs an even row count"
             chunks = max(2, chunks)
-            head = min(chunks - 1, max(1, int(round(chunks * cut_at / rows))))
+
+            def fill(part, k):
+                # how full the tall row blocks of `k` equal chunks of `part` rows come out (csrc/slp_tall.hip tall_geometry: blocks of
+                # at most 9984 rows, in multiples of 256 / gcd(256, chunks) per chunk when the chunks run in one grid)
+                import math
+
+                mult = 256 // math.gcd(256, chunks)
+                per = -(-part // k)
+                blocks = -(-per // (9984 * mult)) * mult
+                return per / (blocks * 9984.0)
+
+            # how many of the chunks the rows in front of the cut get: in proportion, give or take -- a chunk up to twice the even
+            # share is fine in front (the first chunks are converted while the device is still empty) -- whichever split leaves the
+            # row blocks fullest (config 4 with 2e6 equality rows of 2e7 in 16 chunks: 1 + 15 gives blocks of 9616 / 9375 rows,
+            # 2 + 14 blocks of 8929)
+            share = rows / chunks
+            best = None
+            for head in range(1, chunks):
+                if cut_at / head > 2.05 * share or (rows - cut_at) / (chunks - head) > 1.25 * share:
+                    continue
+                score = (cut_at * fill(cut_at, head) + (rows - cut_at) * fill(rows - cut_at, chunks - head)) / rows
+                if best is None or score > best[0] + 1e-12:
+                    best = (score, head)
+            head = best[1] if best else min(chunks - 1, max(1, int(round(chunks * cut_at / rows))))
             return ChunkedDeviceMatrix.cuts(cut_at, head) + [cut_at + c for c in ChunkedDeviceMatrix.cuts(rows - cut_at, chunks - head)[1:]]
         cuts = [(rows * k // chunks) & ~1 for k in range(chunks)] + [rows]
         return [c for i, c in enumerate(cuts) if i == 0 or c > cuts[i - 1]]

@@ -249,6 +249,74 @@ def test_c4slice_whole_solvers_match_the_cpu_oracle_at_full_size(c4slice):
         json.dump(record, f, indent=1)
 
 
+def test_c3_equality_variant_whole_solvers_match_the_cpu_oracle_at_full_size(c3):
+    """SURVEY.md 8(d)'s 10 %-equality variant (randomLP.py:62-68) at config 3's FULL size: the first 2e5 rows are equalities
+    ``a_i x = a_i x_f``.  Chambolle-Pock forms ``(c + y_eq * a_eq) + y_ineq * a_ineq`` (ChambollePockPPD.py:206,216) from two
+    products over strip copies of ``A_e^T`` and ``A_i^T`` -- row-range copies built for the solver on the ordinary matrix, the
+    chunks' own copies on a chunked matrix cut at m_eq, two masked products where neither exists -- x BIT FOR BIT against the
+    oracle on the downloaded matrix in all three forms; matrix-free ADMM 1e-9 / 1e-6 in the objective."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    a, xf, c, lb, ub, _ = c3
+    if _mem_available_gb() < 250:
+        pytest.skip("less than 250 GB of host memory available for the full-size oracle run")
+    m_eq = M // 10
+    a.set_format(0)
+    b = a.random_lp_vectors(P, SEED, m_eq=m_eq)[4]
+    cp_iters, admm_iters = 4, 3
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    record = {"n": N, "m": M, "equality_rows": m_eq, "stored_entries": a.nnz}
+    try:
+        host = a.download()
+        ae, ai = oracle.as_csr(host[:m_eq]), oracle.as_csr(host[m_eq:])
+        del host
+        assert np.array_equal(b[:m_eq], oracle.matvec(ae, xf))     # b_eq = A_e x_f in csr_matvec order (randomLP.py:63)
+        x_cpu, _ = oracle.chambolle_pock_ppd(c, ae, b[:m_eq], ai, None, b[m_eq:], lb, ub, nb_max_iter=cp_iters, nb_iter_plot=10 ** 9)
+        ae._csc = ai._csc = None
+        forms = {}
+        for name, env in (("row-range copies", None), ("masked products", "masked")):
+            if env:
+                os.environ["SLP_CP_SPLIT"] = env
+            try:
+                s = DeviceCP(a, b, c, lb, ub, m_eq=m_eq)
+            finally:
+                os.environ.pop("SLP_CP_SPLIT", None)
+            forms[name] = s.split_form()
+            s.iterate(cp_iters)
+            x_gpu = s.x()
+            s.close()
+            assert np.array_equal(x_gpu, x_cpu), (name, float(np.max(np.abs(x_gpu - x_cpu))))
+        assert forms == {"row-range copies": 1, "masked products": 2}, forms
+        ch, _, _, _, _, b2 = random_lp_on_device(N, M, P, seed=SEED, chunks=2, m_eq=m_eq)   # (two chunks: the equality rows, the others)
+        try:
+            assert ch.chunks == 2 and np.array_equal(b2, b)
+            s = DeviceCP(ch, b, c, lb, ub, m_eq=m_eq)
+            assert s.split_form() == 1
+            s.iterate(cp_iters)
+            assert np.array_equal(s.x(), x_cpu)
+            s.close()
+        finally:
+            ch.close()
+        record["chambolle_pock_ppd"] = {"iterations": cp_iters, "x_bit_for_bit": True, "forms": forms, "objective": float(c.dot(x_cpu))}
+        x_cpu = oracle.lp_admm_cg(c, ae, b[:m_eq], ai, None, b[m_eq:], lb, ub, nb_iter=admm_iters - 1, nb_iter_plot=10 ** 9)
+        del ae, ai
+        s = DeviceADMM(a, b, c, lb, ub, m_eq=m_eq)
+        s.iterate(admm_iters)
+        x_gpu = s.x(N)
+        s.close()
+        err = float(np.max(np.abs(x_gpu - x_cpu) / (1 + np.abs(x_cpu))))
+        record["admm"] = {"iterations": admm_iters, "max_scaled_error": err, "objective": float(c.dot(x_cpu))}
+        assert err <= 1e-9, err
+        assert abs(float(c.dot(x_gpu)) - float(c.dot(x_cpu))) <= 1e-6 * abs(float(c.dot(x_cpu)))
+    finally:
+        oracle.set_threads(1)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "c3_eq10_oracle_parity.json"), "w") as f:
+        json.dump(record, f, indent=1)
+
+
 def _mem_available_gb():
     for line in open("/proc/meminfo"):
         if line.startswith("MemAvailable"):

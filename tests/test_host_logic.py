@@ -58,6 +58,29 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
 
 
+def test_shipped_kernels_carry_no_lab_switches():
+    """timing experiments with parts of a kernel removed give WRONG sums by design.  The tall-cell and Gauss-Seidel
+    sources carry none of those switches any more (their lab forms are patches under tools/lab/patches), the strip kernels fence
+    theirs behind SLP_ABLATION, slp_common.h stops a build that defines a lab macro without it, and the loader refuses a library
+    whose slp_build_flags() is not 0 unless SLP_LIB_VARIANT names it."""
+    csrc = os.path.join(REPO, "pysparselp_amd", "csrc")
+    lab = ("SLP_TALL_ABL", "SLP_GS_ABLATE", "SLP_GS_BANDS_ABLATE", "SLP_TALL_FLAT", "SLP_TALL_X64", "SLP_TALL_WHOLE_ISSUE",
+           "SLP_TALL_FULL_ISSUE", "SLP_TALL_XLOAD", "SLP_TALL_STAGE", "SLP_TALL_DEAL_CEIL", "SLP_TALL_BUILD_PROF")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip") or (f.endswith(".h") and f != "slp_common.h"):
+            text = open(os.path.join(csrc, f)).read()
+            for line in text.splitlines():
+                if line.lstrip().startswith("#"):
+                    assert not any(name in line for name in lab), (f, line)
+    guard = open(os.path.join(csrc, "slp_common.h")).read()
+    assert "#error" in guard and "SLP_TALL_ABL" in guard and "SLP_GS_ABLATE" in guard
+    for f in ("slp_tall_spmv", "slp_tall", "slp_admm"):
+        assert os.path.exists(os.path.join(REPO, "tools", "lab", "patches", f + "_lab_switches.patch"))
+    from pysparselp_amd import _lib
+
+    assert int(_lib.load().slp_build_flags()) == 0
+
+
 def test_admm_setup_matches_reference_arrays():
     """tools.py against the reference's precondition/standard-form/M chain (ADMM.py:76-101)."""
     d = load_golden("kernel_kats")
