@@ -204,7 +204,7 @@ def spmv_block(lib, a, transposed, shape, reps=5):
     return out, which
 
 
-def cpu_baseline(args, method):
+def cpu_baseline(args, method, also_cp=False):
     """Oracle (port of the reference algorithm, 1 thread) on a bounded sample: the first m/10 rows of the same LP with all n
     columns (>= 1/10 of the stored entries; per-entry cost on a CPU depends on the size of the gathered vector, which is the
     full one here).  Only iterations are timed (timestamps taken by the oracle's per-iteration hook); the rate is scaled by
@@ -218,22 +218,31 @@ def cpu_baseline(args, method):
     xf, c, lb, ub, b = a.random_lp_vectors(args.density, args.seed)
     s = a.download()
     a.close()
-    stamps = []
+    def timed(which):
+        """(iterations / s on the sample, set-up seconds, iterations run, stamps) of one oracle solver on the resident sample."""
+        stamps = []
 
-    def hook(i, *_):
-        stamps.append(time.perf_counter())
+        def hook(i, *_):
+            stamps.append(time.perf_counter())
 
-    t_start = time.perf_counter()
-    if method == "chambolle_pock_ppd":
-        iters = 8
-        oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9, iterate_hook=hook)
-    else:
-        iters = 5
-        oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9, iterate_hook=hook)
-    # stamp k is taken at the same point of iteration k: differences are whole iterations, setup is before stamp 0
-    per_iter = (stamps[-1] - stamps[1]) / (len(stamps) - 2)
-    its = 1.0 / per_iter
-    setup_s = stamps[0] - t_start - per_iter
+        t_start = time.perf_counter()
+        if which == "chambolle_pock_ppd":
+            iters = 8
+            oracle.chambolle_pock_ppd(c, None, None, s, None, b, lb, ub, nb_max_iter=iters, nb_iter_plot=10 ** 9, iterate_hook=hook)
+        else:
+            iters = 5
+            oracle.lp_admm_cg(c, None, None, s, None, b, lb, ub, nb_iter=iters - 1, nb_iter_plot=10 ** 9, iterate_hook=hook)
+        # stamp k is taken at the same point of iteration k: differences are whole iterations, setup is before stamp 0
+        per_iter = (stamps[-1] - stamps[1]) / (len(stamps) - 2)
+        return 1.0 / per_iter, stamps[0] - t_start - per_iter, iters, len(stamps)
+
+    # matrix products per iteration as each side forms them: the oracle runs the reference's code shape -- ADMM with the
+    # conjugate-gradient x-step (ADMM.py:148,182-201,262 + conjugateGradientLinearSolver.py:36-46) = A^T lambda, four M v =
+    # A^T (A v) and A x: 10; Chambolle-Pock (ChambollePockPPD.py:206/216, 235/240) = A^T y and A z: 2 -- while the device
+    # rearranges the ADMM iteration into 4 passes over the matrix (reuse level 4, same iterates to rounding) and runs
+    # Chambolle-Pock as the same 2
+    products_cpu = {"admm": 10, "chambolle_pock_ppd": 2}
+    its, setup_s, iters, nstamps = timed(method)
     out = {
         "value": its * rows / args.m,
         "unit": "it/s",
@@ -241,17 +250,32 @@ def cpu_baseline(args, method):
         "kind": "port",
         "extrapolated": True,
         "sample": f"first {rows} of the {args.m} rows of the same LP (all {args.n} columns, density {args.density}: {s.nnz} stored "
-                  f"entries), iterations {1}..{len(stamps) - 1} of {iters} timed without setup: {its:.4f} it/s measured; value = "
+                  f"entries), iterations {1}..{nstamps - 1} of {iters} timed without setup: {its:.4f} it/s measured; value = "
                   f"that rate x {rows}/{args.m} (cost per iteration is linear in the rows)",
         "measured_it_per_s_on_sample": its,
         "sample_setup_seconds": setup_s,
         "host_cores_present": os.cpu_count(),
+        "matrix_products_per_iteration": products_cpu[method],
+        "note_on_product_counts": "the CPU figure times the reference's form of the iteration (matrix_products_per_iteration); the GPU line's "
+                                  "config.matrix_passes_per_iteration is what the device's rearranged iteration spends (ADMM: 4 passes for "
+                                  "the reference's 10 products; Chambolle-Pock: 2 and 2)",
     }
+    if method == "admm" and also_cp:
+        # the method where both sides do the SAME two products per iteration, on the sample that is resident anyway
+        its_cp, setup_cp, iters_cp, n_cp = timed("chambolle_pock_ppd")
+        out["chambolle_pock"] = {"value": its_cp * rows / args.m, "unit": "it/s", "cores": 1, "extrapolated": True,
+                                 "measured_it_per_s_on_sample": its_cp, "sample_setup_seconds": setup_cp,
+                                 "iterations_timed": n_cp - 2, "matrix_products_per_iteration": products_cpu["chambolle_pock_ppd"]}
     if (args.n, args.m, args.density) == CONFIGS["c4"]:
         # is the row-sample extrapolation valid at n = 1e7?  tools/cpu_sample_scaling.py: the same measurement on 1 %, 2 %, 5 % of the rows
         try:
             rec = json.load(open(os.path.join(REPO, "profiles", "r05_cpu_sample_scaling_c4.json")))
             key = "admm" if method == "admm" else "chambolle_pock_ppd"
+            if "chambolle_pock" in out:
+                out["chambolle_pock"]["sample_validation"] = {
+                    "source": "profiles/r05_cpu_sample_scaling_c4.json",
+                    "extrapolated_full_size_it_per_s": {str(r["fraction"]): r["chambolle_pock_ppd"]["extrapolated_full_size_it_per_s"] for r in rec["samples"]},
+                    "spread": rec["chambolle_pock_ppd_extrapolations_spread"]}
             out["sample_validation"] = {
                 "source": "profiles/r05_cpu_sample_scaling_c4.json",
                 "what": "the same oracle timing on 1 % / 2 % / 5 % of the rows at n = 1e7 (1 thread): full-size rates extrapolated from each",
@@ -327,16 +351,18 @@ def cpu_baseline_blocks(args, rows_per_block, cg_steps_full):
     s = a.download()
     a.close()
     stamps, steps_at = [time.perf_counter()], [0]
-    state = {}
 
-    def hook(i):
+    def hook(i, steps_so_far):
         stamps.append(time.perf_counter())
+        steps_at.append(steps_so_far)
 
+    hook.wants_steps = True
     iters = 3
     t_start = time.perf_counter()
-    _, steps = oracle.lp_admm_blocks_cg(c, [(oracle.as_csr(s), None, b)], lb, ub, nb_iter=iters, iterate_hook=hook)
+    oracle.lp_admm_blocks_cg(c, [(oracle.as_csr(s), None, b)], lb, ub, nb_iter=iters, iterate_hook=hook)
     per_iter = (stamps[-1] - stamps[1]) / (len(stamps) - 2)       # iterations 1 .. (warm-started projections, like the timed GPU steps)
-    passes_sample = 3 + 2 * steps / iters
+    # conjugate-gradient steps of the TIMED iterations only (iteration 0 starts cold and needs the most)
+    passes_sample = 3 + 2 * (steps_at[-1] - steps_at[1]) / (len(steps_at) - 2)
     passes_full = 3 + 2 * cg_steps_full
     blocks_total = args.m // rows_per_block
     scale = (rows_per_block / rows) * (passes_full / passes_sample) * blocks_total
@@ -694,6 +720,18 @@ def run_workload(lib, args, rank, world, distributed):
         }
         solver.close()
         solver = None
+        if world == 1 and args.method == "admm" and args.default_workload and not args.no_cpu_baseline:
+            # Chambolle-Pock on the same resident LP, beside the ADMM figure: the method where the CPU path and the device do the SAME
+            # two products per iteration (cpu_baseline.chambolle_pock is its partner)
+            try:
+                cp = make_solver("chambolle_pock_ppd", a, b, c, lb, ub, m_eq=m_eq_local)
+                dt_cp = timed_steps(lib, cp, 2, args.steps)
+                out["chambolle_pock"] = {"value": args.steps / dt_cp, "unit": "it/s", "ms_per_step": 1e3 * dt_cp / args.steps,
+                                         "steps": args.steps, "matrix_passes_per_iteration": cp.matrix_passes_per_iteration(),
+                                         "objective_after_run": cp.objective()}
+                cp.close()
+            except Exception as e:  # noqa: BLE001 -- never a reason to lose the headline line
+                out["chambolle_pock"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_general and args.format == 0 and which >= 2 and args.method != "admm_blocks" and chunks == 1:
             if released:  # the CSR entries are gone: the same rows again from the counter-based generator
                 a.close()
@@ -727,7 +765,7 @@ def run_workload(lib, args, rank, world, distributed):
                 # sample: the oracle's matrix-free form of the same iteration is timed, oracle.lp_admm_blocks_cg)
                 out["cpu_baseline"] = cpu_baseline_blocks(args, rows // args.blocks_per_rank, out["config"]["cg_steps_per_block_update"])
             else:
-                out["cpu_baseline"] = cpu_baseline(args, args.method)
+                out["cpu_baseline"] = cpu_baseline(args, args.method, also_cp="chambolle_pock" in out)
     if solver is not None:
         solver.close()
     if a is not None:

@@ -439,6 +439,11 @@ int slp_comm_finalize(void);
  * device, for bench timing and report scalars. */
 int slp_comm_allreduce_host(double *v, int64_t count, int op);
 int slp_comm_barrier(void);
+/* Preflight of the exchange (tools/rccl_preflight.py; no reference counterpart): `reps` sum-all-reduces of `count`
+ * doubles on a device buffer through the path the solvers' exchange takes -- the vector all-reduced once per
+ * Chambolle-Pock iteration is A^T y, n doubles (ChambollePockPPD.py:206,216).  The first one is checked (every rank
+ * contributes rank + 1).  out[0] = ms per all-reduce (HIP events), out[1] = max |error|, out[2] = ranks. */
+int slp_comm_bench_allreduce(int64_t count, int reps, double out[3]);
 /* All-reduces this process has issued since slp_comm_init (0 without a communicator): the data-path exchange steps
  * can be counted per iteration (Chambolle-Pock 1, matrix-free ADMM at reuse level 4: 2, block-splitting ADMM 1). */
 long long slp_comm_collectives(void);

@@ -892,7 +892,8 @@ def lp_admm_block_decomposition(c, a_eq, beq, a_ineq, b_lower, b_upper, lb, ub, 
 def lp_admm_blocks_cg(c, blocks, lb, ub, gamma=0.7, alpha=1.95, nb_iter=10, cg_tol=1e-13, cg_max_steps=500, check_every=10,
                       primal=None, iterate_hook=None):
     """``blocks``: list of ``(a_g, b_lower_g or None, b_upper_g)`` with ``a_g`` the block's rows over all n variables.
-    Runs ``nb_iter`` iterations from x0 = 0; returns ``(xp, cg_steps)``; ``iterate_hook(i)`` is called after iteration i."""
+    Runs ``nb_iter`` iterations from x0 = 0; returns ``(xp, cg_steps)``; ``iterate_hook(i)`` is called after iteration i (a hook with
+    the attribute ``wants_steps = True`` is called as ``iterate_hook(i, cg_steps_so_far)``)."""
     c, lb, ub = _f64(c), _f64(lb), _f64(ub)
     n = c.size
     st = []
@@ -970,5 +971,8 @@ def lp_admm_blocks_cg(c, blocks, lb, ub, gamma=0.7, alpha=1.95, nb_iter=10, cg_t
         for s in st:
             s["lam"] = np.where(s["used"], s["lam"] + gamma * (s["x"] - xp), s["lam"])
         if iterate_hook is not None:
-            iterate_hook(i)
+            if getattr(iterate_hook, "wants_steps", False):
+                iterate_hook(i, steps)      # (cumulative conjugate-gradient steps so far)
+            else:
+                iterate_hook(i)
     return xp, steps

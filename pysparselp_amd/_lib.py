@@ -127,6 +127,7 @@ _SIGNATURES = {
     "slp_comm_finalize": (c_int, []),
     "slp_comm_allreduce_host": (c_int, [c_vp, c_i64, c_int]),
     "slp_comm_barrier": (c_int, []),
+    "slp_comm_bench_allreduce": (c_int, [c_i64, c_int, c_vp]),
     "slp_comm_info": (c_int, [c_vp, c_vp]),
     "slp_comm_collectives": (ctypes.c_longlong, []),
     "slp_comm_timing": (c_int, [c_int]),

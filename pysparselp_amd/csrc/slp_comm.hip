@@ -246,8 +246,10 @@ void comm_allreduce_dev(double *buf, i64 count, int op) {
         // compute side of one rank of N on one GPU without the host transport's PCIe copies in the way
         static const bool null_comm = [] { const char *e = getenv("SLP_COMM_NULL"); return e && e[0] == '1'; }();
         if (null_comm) return;
-        TimedCollective timed(st, count, false);
         if (hw.running) host_worker_drain(true);  // (collectives reach the callback in issue order)
+        // opened AFTER the wait for earlier asynchronous jobs: their time is already in hw.timed_ms (host clock), it must not be
+        // counted again inside this collective's event pair (exchange.ms_per_iteration counted it twice)
+        TimedCollective timed(st, count, false);
         if (g.host_buf.size() < (size_t)count) g.host_buf.resize((size_t)count);
         SLP_HIP(hipMemcpyAsync(g.host_buf.data(), buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
         SLP_HIP(hipStreamSynchronize(st));
@@ -495,6 +497,44 @@ int slp_comm_info(int *nranks, int *rank) {
     if (nranks) *nranks = g.active ? g.nranks : 1;
     if (rank) *rank = g.active ? g.rank : 0;
     return g.active ? 1 : 0;
+}
+
+__global__ void k_comm_fill(i64 n, double v, double *__restrict__ buf) {
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) buf[j] = v;
+}
+
+// `reps` sum-all-reduces of `count` doubles on a device buffer through the path the solvers use (comm_allreduce_dev), the first
+// one checked: every rank contributes rank + 1 in every entry.  out[0] = ms per all-reduce (HIP events around all of them on the
+// compute stream), out[1] = max |error| of the checked one, out[2] = ranks.  tools/rccl_preflight.py.
+int slp_comm_bench_allreduce(int64_t count, int reps, double out[3]) {
+    SLP_API_INT({
+        SLP_REQUIRE(comm_active(), "slp_comm_bench_allreduce: slp_comm_init has not been called");
+        SLP_REQUIRE(count > 0 && reps > 0 && out, "slp_comm_bench_allreduce: bad arguments");
+        Context &c = ctx();
+        DevBuf<double> buf((size_t)count);
+        const int grid = grid_for(count, 256);
+        hipLaunchKernelGGL(k_comm_fill, dim3(grid), dim3(256), 0, c.stream, (i64)count, (double)(g.rank + 1), buf.p);
+        SLP_HIP(hipGetLastError());
+        comm_allreduce_dev(buf.p, count, 0);
+        const double want = 0.5 * (double)g.nranks * (double)(g.nranks + 1);
+        double probe[3] = {0, 0, 0};
+        SLP_HIP(hipMemcpyAsync(&probe[0], buf.p, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        SLP_HIP(hipMemcpyAsync(&probe[1], buf.p + count / 2, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        SLP_HIP(hipMemcpyAsync(&probe[2], buf.p + (count - 1), sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        SLP_HIP(hipStreamSynchronize(c.stream));
+        double err = 0.0;
+        for (double v : probe) err = std::max(err, fabs(v - want));
+        hipLaunchKernelGGL(k_comm_fill, dim3(grid), dim3(256), 0, c.stream, (i64)count, 0.0, buf.p);   // (zeros stay zeros over the reps)
+        SLP_HIP(hipEventRecord(c.ev0, c.stream));
+        for (int r = 0; r < reps; ++r) comm_allreduce_dev(buf.p, count, 0);
+        SLP_HIP(hipEventRecord(c.ev1, c.stream));
+        SLP_HIP(hipEventSynchronize(c.ev1));
+        float ms = 0.f;
+        SLP_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+        out[0] = (double)ms / (double)reps;
+        out[1] = err;
+        out[2] = (double)g.nranks;
+    })
 }
 
 int slp_comm_barrier(void) {

@@ -1024,7 +1024,10 @@ static bool gs_plan_device(GsPlan &g, i64 n, i64 nnz, const i64 *dptr, const i32
             const std::vector<i64> ht = gsp_download(totals.p, (size_t)nunits);
             i64 S = 0;
             for (int u = 0; u < nunits; ++u) { units[(size_t)u].slot0 = S; S += ht[(size_t)u]; }
-            if (S > 0 && S < ((i64)1 << 31)) {
+            // lane slots beyond the 32-bit slot indices (or units without a single slot): declined -- the caller resets the plan and
+            // takes the host's, whose decisions for such a matrix are the ones the sweep kernels were written against
+            if (S <= 0 || S >= ((i64)1 << 31)) return false;
+            {
                 dunits.upload(units.data(), units.size());
                 g.ents.alloc((size_t)S);
                 g.lanes.alloc((size_t)S);

@@ -36,6 +36,8 @@
 
 namespace slp {
 
+bool comm_active();  // slp_comm.hip
+
 constexpr int kStripC = 7680;    // columns per strip: 60 KB of x in LDS
 constexpr int kDictC = 5888;     // value-dictionary variant: 46 KB of x + 16 KB of distinct values in LDS
 constexpr int kDictMax = 2048;   // most distinct stored values the dictionary variant takes
@@ -1099,10 +1101,14 @@ static bool strip_build_c(const CsrDev &a, StripJds &f, const ValueDict *dict) {
     SLP_HIP(hipStreamSynchronize(st));
     f.nrow = a.nrow; f.ncol = a.ncol; f.nnz = a.nnz; f.T = T; f.B = B; f.C = C; f.rpl = RPL;
     // Few row blocks (a 1/4 or 1/8 row partition of the constraints): split every block's strips over S
-    // workgroups so that the launch still fills the 256 CUs x 2 resident workgroups.
+    // workgroups so that the launch still fills the 256 CUs x 2 resident workgroups -- under a communicator only: the split
+    // re-associates a row's sum (S partial sums added in range order), which the all-reduce of a row partition does anyway;
+    // on ONE GPU every product stays the sequential CSR sum bit for bit, also for a short matrix or a short row chunk of a
+    // chunked one (round 6: a 2e5-row chunk of config 3 came out with S = 8 and Chambolle-Pock lost its last bits).
+    // SLP_STRIP_SPLIT=S forces a split (tests, lab).
     const char *es = getenv("SLP_STRIP_SPLIT");
     int S = es ? atoi(es) : 1;
-    if (!es && a.nnz >= 30000000) while (S < 8 && B * S < 384 && 2 * S <= T) S *= 2;
+    if (!es && a.nnz >= 30000000 && comm_active()) while (S < 8 && B * S < 384 && 2 * S <= T) S *= 2;
     if (S < 1) S = 1;
     if (S > T) S = (int)T;
     f.S = S;

@@ -143,28 +143,58 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300
                 s.close()
         if srv is None:
             raise OSError(f"rendezvous: no free port in {port}..{port + PORT_TRIES - 1} on {addr}")
-        with srv:
-            srv.listen(world)
-            srv.settimeout(timeout)
-            served = set()
+        def answer(conn, served):
+            """One connection: hello -> id -> OK -> final byte.  The peer counts as served once it has acknowledged the id; the
+            final byte tells the CLIENT that rank 0 has seen its acknowledgement -- a client that misses it connects again."""
+            with conn:
+                conn.settimeout(10.0)
+                try:
+                    hello = _recv_exact(conn, len(hello_tag) + 4)
+                    peer = int.from_bytes(hello[len(hello_tag):], "little")
+                    if hello[:len(hello_tag)] != hello_tag or not 0 < peer < world:
+                        return
+                    # a client that gave this connection up meanwhile (it retries on a new one) leaves a dead socket whose
+                    # sendall may well "succeed": only the acknowledgement counts -- and its retry is answered too
+                    conn.sendall(hello_tag + bytes(uid))
+                    if _recv_exact(conn, 2) == b"OK":
+                        served.add(peer)
+                        conn.sendall(b"K")
+                except (ConnectionError, socket.timeout, OSError):
+                    return
+
+        srv.listen(world)
+        srv.settimeout(timeout)
+        served = set()
+        try:
             while len(served) < world - 1:
                 conn, _ = srv.accept()
-                with conn:
-                    conn.settimeout(10.0)
+                answer(conn, served)
+        except socket.timeout:
+            srv.close()
+            # the other ranks are about to sit in ncclCommInitRank waiting for this one: end the job loudly instead
+            raise TimeoutError(f"rendezvous: only ranks {sorted(served)} of 1..{world - 1} fetched the unique id within {timeout} s")
+        except BaseException:
+            srv.close()
+            raise
+
+        # A peer whose acknowledgement arrived but whose final byte got lost connects again: keep answering for a while in the
+        # background (the id is the same); rank 0 itself goes on to the communicator's initialisation at once.
+        def linger():
+            srv.settimeout(1.0)
+            end = time.monotonic() + 30.0
+            with srv:
+                while time.monotonic() < end:
                     try:
-                        hello = _recv_exact(conn, len(hello_tag) + 4)
-                    except (ConnectionError, socket.timeout, OSError):
+                        conn, _ = srv.accept()
+                    except socket.timeout:
                         continue
-                    peer = int.from_bytes(hello[len(hello_tag):], "little")
-                    if hello[:len(hello_tag)] == hello_tag and 0 < peer < world:
-                        # a peer counts as served once it ACKNOWLEDGES the id: a client that gave this connection up meanwhile
-                        # (it retries on a new one) leaves a dead socket whose sendall may well "succeed" -- answer its retry too
-                        try:
-                            conn.sendall(hello_tag + bytes(uid))
-                            if _recv_exact(conn, 2) == b"OK":
-                                served.add(peer)
-                        except (ConnectionError, socket.timeout, OSError):
-                            continue
+                    except OSError:
+                        return
+                    answer(conn, set())
+
+        import threading
+
+        threading.Thread(target=linger, name="slp-rendezvous-linger", daemon=True).start()
         return bytes(uid)
     deadline = time.monotonic() + timeout
     while True:
@@ -176,7 +206,8 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=300
                     reply = _recv_exact(conn, len(hello_tag) + 128)
                     if reply[:len(hello_tag)] == hello_tag:
                         conn.sendall(b"OK")
-                        return reply[len(hello_tag):]
+                        if _recv_exact(conn, 1) == b"K":   # rank 0 has seen the acknowledgement (else: once more, it keeps answering)
+                            return reply[len(hello_tag):]
             except (ConnectionError, socket.timeout, OSError):
                 pass
         if time.monotonic() > deadline:
@@ -222,6 +253,7 @@ class HostTcpAllreduce:
                     conn.sendall(hello_tag)  # the client checks that it reached ITS job's rank 0
                     if _recv_exact(conn, 2) != b"OK":
                         raise ConnectionError("no acknowledgement")
+                    conn.sendall(b"K")       # the client only keeps a connection whose acknowledgement rank 0 has seen
                 except (ConnectionError, socket.timeout, OSError):
                     conn.close()
                     continue
@@ -244,7 +276,8 @@ class HostTcpAllreduce:
                     conn.sendall(hello_tag + self.rank.to_bytes(4, "little"))
                     if _recv_exact(conn, len(hello_tag)) == hello_tag:
                         conn.sendall(b"OK")
-                        break
+                        if _recv_exact(conn, 1) == b"K":
+                            break
                 except (OSError, ConnectionError, socket.timeout):
                     pass
                 if conn is not None:

@@ -3,6 +3,7 @@
 # (ms per iteration inside collectives, bytes and algbw per collective, max over the ranks) and `compute_ms_per_step` next to
 # `ms_per_step`, so a scaling shortfall can be read off as exchange or as compute without a second run.
 #
+#   0. tools/rccl_preflight.py      (dlopen + symbols, device count, IPC mode, one-rank and N-rank 80 MB all-reduce timing)
 #   1. tests/test_gpu_multi_rccl.py   (N = 2 / 4 / 8 processes, one per GPU, RCCL: replicas identical, x = the one-process run)
 #   2. bench.py --gpus 1 / 2 / 4 / 8 on config 4 (matrix-free ADMM; replicated updates, then SLP_SHARD_UPDATES=1: 6 collectives
 #      per iteration instead of 2) and on config 5 (block-splitting ADMM, 8 / N blocks per rank, per-block all-reduce overlapped
@@ -19,6 +20,9 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 NGPU=$(python -c "from pysparselp_amd import _lib; print(_lib.load().slp_device_count())")
 echo "{\"what\": \"first_8gpu_run\", \"gpus_visible\": $NGPU, \"steps\": $STEPS}" >> "$OUT"
 
+echo "== preflight (librccl symbols, device count, HSA_ENABLE_IPC_MODE_LEGACY, a one-rank and an N-rank 80 MB all-reduce)"
+python tools/rccl_preflight.py --ranks "$NGPU" 2>> "${OUT%.jsonl}.err" | tail -1 | tee -a "$OUT"
+
 echo "== RCCL tests (skip below 2 GPUs)"
 python -m pytest tests/test_gpu_multi_rccl.py -m gpu -q -x 2>&1 | tail -5 | tee -a "${OUT%.jsonl}.tests.log"
 
@@ -30,14 +34,10 @@ run() {   # run <config> <gpus> <shard 0|1>
         echo "{\"config\": \"$cfg\", \"gpus\": $n, \"skipped\": \"only $NGPU GPU(s) visible\"}" >> "$OUT"
         return
     fi
-    if [ "$n" -eq 1 ]; then
-        line=$(SLP_SHARD_UPDATES=$shard python bench.py --config "$cfg" --gpus 1 --steps "$STEPS" --warmup 3 --no-cpu-baseline --no-general \
-               --no-secondary 2>> "${OUT%.jsonl}.err" | grep '^{' | tail -1)
-    else
-        line=$(SLP_SHARD_UPDATES=$shard python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 \
-               --master-port "$port" bench.py --config "$cfg" --gpus "$n" --steps "$STEPS" --warmup 3 --no-cpu-baseline --no-general \
-               --no-secondary 2>> "${OUT%.jsonl}.err" | grep '^{' | tail -1)
-    fi
+    # bench.py starts its own ranks (self_launch: child processes + the TCP id exchange of pysparselp_amd/parallel.py, no torch);
+    # the driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` gives the same line
+    line=$(SLP_SHARD_UPDATES=$shard MASTER_PORT=$port python bench.py --config "$cfg" --gpus "$n" --steps "$STEPS" --warmup 3 --no-cpu-baseline \
+           --no-general --no-secondary 2>> "${OUT%.jsonl}.err" | grep '^{' | tail -1)
     if [ -z "$line" ]; then line="{\"error\": \"no bench line (see ${OUT%.jsonl}.err)\"}"; fi
     echo "{\"config\": \"$cfg\", \"gpus\": $n, \"shard_updates\": $shard, \"line\": $line}" >> "$OUT"
     python - "$line" <<'PY'

@@ -8,6 +8,6 @@ cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export SLP_DEVICE=0 SLP_COMM_TRANSPORT=host
 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-general | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('N=1', d['objective_after_run'], d['value'])"
 for N in 2 4 8; do
-  timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29700 + N * 20)) bench.py --gpus $N --steps 6 --warmup 2 --no-cpu-baseline --no-general 2> gpurun_out/multirank_$N.err | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][0]); print('N=$N', d['objective_after_run'], d['config']['collectives_per_iteration'], d['config']['nnz'], d['device_memory'])"
+  MASTER_PORT=$((29700 + N * 20)) timeout 900 python3 bench.py --gpus $N --steps 6 --warmup 2 --no-cpu-baseline --no-general 2> gpurun_out/multirank_$N.err | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][0]); print('N=$N', d['objective_after_run'], d['config']['collectives_per_iteration'], d['config']['nnz'], d['device_memory'])"
   tail -3 gpurun_out/multirank_$N.err
 done
