@@ -742,7 +742,7 @@ int slp_matrix_release_csr(slp_matrix *m) {
         SLP_REQUIRE(f0 && f1, "slp_matrix_release_csr: the matrix does not run on strip copies in both orientations; its CSR arrays "
                               "are the only copy of the entries");
         SLP_REQUIRE(m->csr_bound == 0, "slp_matrix_release_csr: a solver created on this matrix iterates on its CSR arrays "
-                                       "(Chambolle-Pock in SEQUENTIAL order with equality and inequality rows); destroy it first");
+                                       "(one of its iteration halves has no strip copy to run on); destroy it first");
         SLP_HIP(hipStreamSynchronize(ctx().stream));
         m->a.idx.release(); m->a.val.release();
         m->at.idx.release(); m->at.val.release();

@@ -103,36 +103,39 @@ def test_matrix_guards_raise_clear_errors():
     a.close()
 
 
-def test_release_is_refused_while_a_solver_iterates_on_the_csr_arrays():
-    """Chambolle-Pock in SEQUENTIAL order with equality AND inequality rows keeps the two partial sums of a
-    column apart ((c + s_eq) + s_ineq, ChambollePockPPD.py:206,216), which only the CSR walk gives -- such a solver pins the
-    CSR arrays: the release is refused while it lives, and works (iterates unchanged) for the strip-only orders."""
-    from pysparselp_amd import _lib
+def test_release_with_equality_rows_keeps_the_reference_order():
+    """Chambolle-Pock with equality AND inequality rows keeps the two partial sums of a column apart ((c + s_eq) + s_ineq,
+    ChambollePockPPD.py:206,216).  Rounds 2-5: only the CSR walk gave them, such a solver pinned the CSR arrays and the release
+    was refused.  Round 6: the solver owns strip copies of A_e^T and A_i^T (csrc/slp_cp.hip cp_split_setup), so the release is
+    allowed while it lives and its iterates go on unchanged; a solver created AFTER the release (no CSR to cut the row ranges
+    from) forms the two sums by two masked products over the whole copy -- every form bit for bit the oracle's iterate."""
+    from oracle import oracle
     from pysparselp_amd._lib import ORDER_SEQUENTIAL
     from pysparselp_amd.problems import random_lp_on_device
     from pysparselp_amd.scale import DeviceCP
 
     os.environ["SLP_STRIP_MIN_NNZ"] = "1"
     try:
-        a, xf, c, lb, ub, b = random_lp_on_device(30000, 40000, 0.001, seed=7)
-        b_eq = b.copy()
-        b_eq[:5000] = a.matvec(xf)[:5000]          # the first 5000 rows as equalities through the feasible point
-        seq = DeviceCP(a, b_eq, c, lb, ub, order=ORDER_SEQUENTIAL, m_eq=5000)
+        m_eq = 5000
+        a, xf, c, lb, ub, b_eq = random_lp_on_device(30000, 40000, 0.001, seed=7, m_eq=m_eq)   # the first 5000 rows: a_i x = a_i x_f
+        host = a.download()
+        want, _ = oracle.chambolle_pock_ppd(c, host[:m_eq], b_eq[:m_eq], host[m_eq:], None, b_eq[m_eq:], lb, ub, nb_max_iter=10,
+                                            nb_iter_plot=10 ** 9)
+        seq = DeviceCP(a, b_eq, c, lb, ub, order=ORDER_SEQUENTIAL, m_eq=m_eq)
+        assert seq.split_form() == 1                # copies of the two row ranges, the solver's own
         seq.iterate(5)
         x5 = seq.x()
-        with pytest.raises(_lib.SlpError, match="iterates on its CSR arrays"):
-            a.release_csr()
-        seq.iterate(5)                              # still on intact arrays
+        a.release_csr()                             # allowed: no iteration half walks the CSR arrays
+        seq.iterate(5)
         x10 = seq.x()
         seq.close()
-        auto = DeviceCP(a, b_eq, c, lb, ub, m_eq=5000)
-        auto.iterate(5)
-        a.release_csr()                             # strip-only solver: allowed
-        auto.iterate(5)
-        y10 = auto.x()
-        auto.close()
+        late = DeviceCP(a, b_eq, c, lb, ub, m_eq=m_eq)
+        assert late.split_form() == 2               # no CSR left to cut row ranges from: masked products over the whole copy
+        late.iterate(10)
+        y10 = late.x()
+        late.close()
         assert not np.array_equal(x5, x10)
-        assert np.allclose(x10, y10, rtol=1e-9, atol=1e-12)   # same iteration, one chain instead of two partial sums
+        assert np.array_equal(x10, want) and np.array_equal(y10, want)
         a.close()
     finally:
         del os.environ["SLP_STRIP_MIN_NNZ"]
