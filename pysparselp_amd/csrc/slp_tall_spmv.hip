@@ -49,7 +49,8 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
     constexpr int kPieces = C / 2048 ? C / 2048 : 1;     // 16-byte pieces of a tile per lane
     const int p = threadIdx.x;
     const bool tile_lane = C >= 2048 || p < C / 2;       // (1024 columns: the first 512 lanes carry the tile)
-    const unsigned int wbase = (unsigned int)(p & ~(kWave - 1));
+    // (wave-uniform by construction; told to the compiler, so that tests on it are scalar branches, not EXEC masks)
+    const unsigned int wbase = (unsigned int)__builtin_amdgcn_readfirstlane(p & ~(kWave - 1));
     const int v = blockIdx.x;
     int cur = 0;
     TallWg wg = wgs[v];
@@ -70,12 +71,19 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
     const gptr_t hd = (gptr_t)(unsigned long long)wg.dir + (p & 7);
     const int npk = (int)wg.npk - 2 * kTallDepth;                             // the last 2 x depth packets are prefetch targets only
     // buffer descriptors: lanes without work address past num_records (the load returns 0 without a memory request)
-    const __amdgpu_buffer_rsrc_t rs_pay =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(wg.pay), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x + wg.x0), 0, (int)(wg.ncol * 8), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_val =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : wg.val), 0, 0x7fffffff, 0x00020000);
+
+    // A slot as a buffer of its own: `width` words from word `so` of the payload -- the lanes past the slot's width lie behind the
+    // descriptor's end (the load returns 0, no memory request) with no per-lane predicate: the slot's base and size are wave-uniform,
+    // so the descriptor is a few SCALAR instructions where a compare and a select per load and lane used to be (round 6: 224 of the
+    // ~1200 vector instructions of eight packets)
+    auto slot_pay = [&](unsigned int so, unsigned int width) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(wg.pay) + so, 0, (int)(width * 4u), 0x00020000);
+    };
+    auto slot_val = [&](unsigned int so, unsigned int width) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(DICT ? x : wg.val) + so, 0, (int)(width * 8u), 0x00020000);
+    };
 
     TallRegs<DICT> regs[kDepth];
     unsigned int hw[2 * kDepth];
@@ -105,21 +113,21 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
         const unsigned int xs = (unsigned int)__builtin_amdgcn_readlane((int)h, 1) & 0x7fffffffu;
         unsigned int c[kTallSlots];
         widths(h, c);
-        unsigned int so = off * 4u;
+        unsigned int so = off;   // (words)
         const unsigned int mine = (unsigned int)p * 4u;
 #pragma unroll
         for (int k = 0; k < kTallSlots; ++k) {
-            g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);  // streamed once
+            g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(slot_pay(so, c[k]), mine, 0, 2);  // streamed once
             if (!DICT) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_val, (unsigned)p < c[k] ? 2u * mine : kOob, 2u * so, 2);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(slot_val(so, c[k]), 2u * mine, 0, 2);
                 g.val[k] = __hiloint2double((int)v[1], (int)v[0]);
             }
-            so += c[k] * 4u;
+            so += c[k];
         }
         if (DICT) {
-            g.hi[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[0] ? mine : kOob, so, 2);
-            so += c[0] * 4u;
-            g.hi[DICT ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4] ? mine : kOob, so, 2);
+            g.hi[0] = __builtin_amdgcn_raw_buffer_load_b32(slot_pay(so, c[0]), mine, 0, 2);
+            so += c[0];
+            g.hi[DICT ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b32(slot_pay(so, c[4]), mine, 0, 2);
         }
         // columns past ncol read 0: the displacement of each double is part of the voffset, which the descriptor's range check
         // covers (an soffset is not checked on gfx9 raw buffers)
@@ -137,8 +145,8 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
         unsigned int c[kTallSlots];
         widths(h, c);
         const unsigned int mine = (unsigned int)p * 4u;
-        unsigned int so = off * 4u;
-        if (part == 1) so += (c[0] + c[1] + c[2] + c[3]) * 4u;
+        unsigned int so = off;   // (words)
+        if (part == 1) so += c[0] + c[1] + c[2] + c[3];
         // A packet without a fifth item (lists of <= 4 items: the metric's density, where a cell is one such packet) issues no
         // loads for slots 4-7 and their fifth bytes -- a uniform branch; consume() takes the second group under the same test.  The
         // compiler then counts the loads in flight by the path without them (vmcnt(24-26) instead of 36-41): exact for those
@@ -147,17 +155,17 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
         if (part == 0 || wbase < c[4]) {   // (per wave: the waves past the fifth items' lanes skip them too)
 #pragma unroll
             for (int k = 4 * part; k < 4 * part + 4; ++k) {
-                g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[k] ? mine : kOob, so, 2);
+                g.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(slot_pay(so, c[k]), mine, 0, 2);
                 if (!DICT) {
-                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_val, (unsigned)p < c[k] ? 2u * mine : kOob, 2u * so, 2);
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(slot_val(so, c[k]), 2u * mine, 0, 2);
                     g.val[DICT ? 0 : k] = __hiloint2double((int)v[1], (int)v[0]);
                 }
-                so += c[k] * 4u;
+                so += c[k];
             }
             if (DICT) {
-                if (part == 0) so += (c[4] + c[5] + c[6] + c[7]) * 4u;   // the fifth bytes follow the eight slots: slots 0-3, then slots 4-7
-                else so += c[0] * 4u;
-                g.hi[DICT ? part : 0] = __builtin_amdgcn_raw_buffer_load_b32(rs_pay, (unsigned)p < c[4 * part] ? mine : kOob, so, 2);
+                if (part == 0) so += c[4] + c[5] + c[6] + c[7];   // the fifth bytes follow the eight slots: slots 0-3, then slots 4-7
+                else so += c[0];
+                g.hi[DICT ? part : 0] = __builtin_amdgcn_raw_buffer_load_b32(slot_pay(so, c[4 * part]), mine, 0, 2);
             }
         }
         if (part == 1) {   // the tile of the packet `depth` ahead: behind all of this packet's items
