@@ -152,6 +152,10 @@ int slp_matrix_chunked_append(slp_matrix *chunked, slp_matrix *chunk);
  * 10.4 s of set-up; on quick-malloc boxes it LOST time and it raises the peak footprint by the blocks taken ahead (measured:
  * 279.8 -> 302.9 GB), hence off unless asked for.  Never changes results. */
 int slp_matrix_chunked_expect(slp_matrix *chunked, int64_t chunks);
+/* The same with the row count of the whole matrix: every chunk then brings its exact SHARE of a multiple of the CU
+ * count of tall row blocks (cumulative shares rounded), whatever the chunks' sizes -- e.g. an LP whose equality rows
+ * are cut off into chunks of their own (slp_cp_create_on with 0 < m_eq < m).  rows = 0: as slp_matrix_chunked_expect. */
+int slp_matrix_chunked_expect_rows(slp_matrix *chunked, int64_t chunks, int64_t rows);
 /* Chunks appended so far; 0 for an ordinary matrix, -1 for NULL. */
 int64_t slp_matrix_chunks(const slp_matrix *a);
 /* Product-kernel launches one y = A x (transposed: A^T y) takes: 1 for an ordinary matrix, up to one per row chunk for a

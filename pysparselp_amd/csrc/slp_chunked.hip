@@ -90,7 +90,14 @@ int slp_matrix_chunked_append(slp_matrix *g, slp_matrix *c) {
         // brings 1 / K of a multiple of the CU count of row blocks instead of a whole multiple -- its row blocks stay as tall
         // as the LDS allows however finely the rows are chunked (config 4 in 16 chunks: 128 blocks of 9766 rows each, 2048 in
         // the grid; a whole multiple per chunk would halve the blocks' height and double the per-cell work)
-        if (g->expect_chunks > 1 && !c->tried_fa) {
+        if (g->expect_rows > 0 && g->a.nrow + c->a.nrow <= g->expect_rows && !c->tried_fa) {
+            // the whole matrix's row count is known (slp_matrix_chunked_expect_rows): the chunk brings its share of the row blocks
+            const char *e = getenv("SLP_TALL_FUSE");
+            if (!(e && e[0] == '0')) {
+                c->tall_rows_before = g->a.nrow;
+                c->tall_rows_total = g->expect_rows;
+            }
+        } else if (g->expect_chunks > 1 && !c->tried_fa) {
             const char *e = getenv("SLP_TALL_FUSE");
             if (!(e && e[0] == '0')) {
                 i64 a = ctx().num_cu, b = g->expect_chunks;
@@ -131,6 +138,14 @@ int slp_matrix_chunked_expect(slp_matrix *g, int64_t chunks) {
     SLP_API_INT({
         SLP_REQUIRE(g && g->csr_released && g->a.ptr.p == nullptr && chunks >= 0, "slp_matrix_chunked_expect: bad arguments");
         g->expect_chunks = chunks;
+    })
+}
+
+int slp_matrix_chunked_expect_rows(slp_matrix *g, int64_t chunks, int64_t rows) {
+    SLP_API_INT({
+        SLP_REQUIRE(g && g->csr_released && g->a.ptr.p == nullptr && chunks >= 0 && rows >= 0, "slp_matrix_chunked_expect_rows: bad arguments");
+        g->expect_chunks = chunks;
+        g->expect_rows = rows;
     })
 }
 

@@ -298,7 +298,8 @@ void strip_spmv_abs_pow(const StripJds &f, double pw, const double *x, double *o
 // long rows that are sparse inside every LDS-sized window (slp_tall.hip); transposed: the question / the copy for A^T, taken
 // straight from the CSR of A (no transposed CSR is ever formed)
 bool tall_wanted(i64 nrow, i64 ncol, i64 nnz);
-bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict, i64 block_multiple = 0);
+bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict, i64 block_multiple = 0, i64 rows_before = 0,
+                i64 rows_total = 0);   // rows_total > 0: the chunk's share of the row blocks of a chunked matrix (tall_geometry)
 void tall_spmv(const StripJds &f, const double *x, double *out, int accum);
 bool tall_fuse(StripJds &composite);                                          // one descriptor table over all chunks' copies, if they allow it
 void tall_spmv_fused(const StripJds &composite, const double *x, double *out);  // the whole product of a fused composite in ONE launch
@@ -327,6 +328,8 @@ struct slp_matrix {
     slp::DevBuf<double> rowsq;             // a chunk: [2 * rows] the two sums of squares behind the ADMM row scaling (tools.py:272-290)
     slp::i64 expect_chunks = 0;            // slp_matrix_chunked_expect: chunks to come in all (0: unknown, nothing is reserved ahead)
     slp::i64 tall_block_multiple = 0;      // a chunk about to join a chunked matrix of K chunks: row blocks in multiples of CUs / gcd(CUs, K)
+    slp::i64 tall_rows_before = 0, tall_rows_total = 0;   // ... or, when the chunked matrix knows its row count: the chunk's share of its row blocks
+    slp::i64 expect_rows = 0;              // slp_matrix_chunked_expect_rows: rows of the whole chunked matrix (0: unknown)
     ~slp_matrix();
 };
 

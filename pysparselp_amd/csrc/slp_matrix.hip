@@ -304,8 +304,8 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
         // long rows that are sparse inside every LDS-sized window (the slice of a 1e7-variable LP): tall cells -- for A^T taken
         // straight from the CSR of A, no transposed CSR is formed
         const bool tall = tall_wanted(shape.nrow, shape.ncol, shape.nnz);
-        if (!dict && tall && matrix_dictionary(m) && tall_build(m->a, transposed, f, &m->vdict, m->tall_block_multiple)) return &f;
-        if (!dict && !strip_wanted(shape, 0) && tall && tall_build(m->a, transposed, f, nullptr, m->tall_block_multiple)) return &f;  // arbitrary values: fp64 entries
+        if (!dict && tall && matrix_dictionary(m) && tall_build(m->a, transposed, f, &m->vdict, m->tall_block_multiple, m->tall_rows_before, m->tall_rows_total)) return &f;
+        if (!dict && !strip_wanted(shape, 0) && tall && tall_build(m->a, transposed, f, nullptr, m->tall_block_multiple, m->tall_rows_before, m->tall_rows_total)) return &f;  // arbitrary values: fp64 entries
         if (transposed) build_transpose(m);  // the other copies are converted from the orientation's own CSR
         const CsrDev &a = transposed ? m->at : m->a;
         if (dict) strip_build(a, f, &m->vdict, variant);

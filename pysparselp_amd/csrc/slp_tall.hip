@@ -670,13 +670,31 @@ __global__ void k_tall_dir(i64 ncell, i64 V, i64 T, int S, int cshift, const i64
 // 2e-4 at R = 9766 ran at 1.5 TB/s, 17.5 ms, against 4.2 ms for half the entries at 1e-4).
 // `block_multiple` (0 = the CU count): the row blocks come in multiples of this -- a row chunk that will run in ONE grid with
 // the other chunks of its chunked matrix (tall_fuse) only has to bring its share of a multiple of the CU count.
-static void tall_geometry(i64 nrow, i64 T, double per_cell, i64 block_multiple, int *R_out, int *S_out) {
+// `rows_total` > 0 (round 6): the rows are a chunk of a chunked matrix of `rows_total` rows whose chunks run in ONE grid, `rows_before`
+// of them in the chunks in front -- the chunk brings its SHARE of a multiple of the CU count of row blocks: the blocks of all
+// chunks add up to that multiple exactly whatever the chunks' sizes (the cumulative shares are rounded, not each chunk's), and
+// every chunk's blocks are as tall as the whole matrix's would be.  (The per-chunk multiple of round 5 assumes equal chunks: an LP
+// whose equality rows are cut off into chunks of their own came out with 2112 row blocks for 256 CUs -- a ninth round of the
+// grid a quarter full, A x 14 % slower -- and blocks of 8334 rows.)
+static void tall_geometry(i64 nrow, i64 T, double per_cell, i64 block_multiple, int *R_out, int *S_out, i64 rows_before = 0,
+                          i64 rows_total = 0) {
     const i64 cus = block_multiple > 0 ? std::min<i64>(block_multiple, ctx().num_cu) : ctx().num_cu;
     const double p2 = 1.0 - exp(-per_cell) * (1.0 + per_cell);
     const i64 rcap = std::max<i64>(1024, std::min<i64>(kTallRmax, p2 > 0.0 ? (i64)(900.0 / p2) : kTallRmax));
     const char *es = getenv("SLP_TALL_SPLIT");
     const int want = es ? atoi(es) : 0;
     const char *e = getenv("SLP_TALL_R");
+    if (rows_total > 0 && rows_before >= 0 && rows_before + nrow <= rows_total && want == 0 && !(e && atoi(e) > 0)) {
+        const i64 all = ctx().num_cu;
+        // (a margin of 1.5 % on the height: a chunk's share is a whole number of blocks)
+        const i64 total = std::max<i64>(1, (i64)ceil((double)rows_total / ((double)all * (double)rcap * 0.985))) * all;
+        auto upto = [&](i64 r) { return (i64)llround((double)total * (double)r / (double)rows_total); };
+        const i64 blocks = upto(rows_before + nrow) - upto(rows_before);
+        if (blocks > 0) {
+            const i64 R = (nrow + blocks - 1) / blocks;
+            if (R >= 1024 && R <= rcap && (nrow + R - 1) / R == blocks) { *S_out = 1; *R_out = (int)R; return; }
+        }
+    }
     if (want != 0 && !(e && atoi(e) > 0)) {
         const i64 R = std::min<i64>(rcap, std::max<i64>(nrow, 1)), B = (nrow + R - 1) / R;
         i64 S = want > 0 ? want : std::max<i64>(1, cus / B);
@@ -704,7 +722,7 @@ static i64 tall_pass_nnz() {
 
 // The tall-cell copy of `a` (transposed: of a^T) straight from the CSR of `a`.  Keys are drawn and sorted in passes over ranges
 // of the copy's row blocks (a pass's cells all precede the next pass's: the sorted ranges line up into the sorted whole).
-bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict, i64 block_multiple) {
+bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *dict, i64 block_multiple, i64 rows_before, i64 rows_total) {
     Phase ph(transposed ? "tall_build (A^T from the CSR of A)" : "tall_build");
     hipStream_t st = ctx().stream;
     f = StripJds();
@@ -728,7 +746,7 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
             const i64 Tc = (ncolF + ((i64)1 << cs) - 1) >> cs;
             const double pc = (double)a.nnz / (double)nrowF / (double)Tc;
             int Rc = 0, Sc = 1;
-            tall_geometry(nrowF, Tc, pc, transposed ? 0 : block_multiple, &Rc, &Sc);
+            tall_geometry(nrowF, Tc, pc, transposed ? 0 : block_multiple, &Rc, &Sc, transposed ? 0 : rows_before, transposed ? 0 : rows_total);
             const double n = std::max(1.0, (double)std::min<i64>(Rc, nrowF) * pc), tau = std::ceil(n / kTallT);
             const double bytes = dict ? 4.0 + 4.0 * std::min(n, (double)kTallT) * std::ceil(tau / 4.0) / n : 12.0;
             const double cost = 0.393 * bytes + (0.95 + 0.34 * (double)((i64)1 << cs) / kTallC) * 4000.0 / n;
@@ -739,7 +757,7 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     const i64 Cw = (i64)1 << cshift;
     const i64 T = (ncolF + Cw - 1) / Cw;
     int R = 0, S = 1;
-    tall_geometry(nrowF, T, (double)a.nnz / (double)nrowF / (double)T, transposed ? 0 : block_multiple, &R, &S);
+    tall_geometry(nrowF, T, (double)a.nnz / (double)nrowF / (double)T, transposed ? 0 : block_multiple, &R, &S, transposed ? 0 : rows_before, transposed ? 0 : rows_total);
     const i64 B = (nrowF + R - 1) / R, ncell = B * T, V = B * S;  // V workgroups: (row block, strip range)
     unsigned int cellbits = 1;
     while (((i64)1 << cellbits) < ncell) ++cellbits;

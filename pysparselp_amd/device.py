@@ -167,12 +167,16 @@ class ChunkedDeviceMatrix(DeviceMatrix):
     (``DeviceCP``, ``DeviceADMM``) take it like a ``DeviceMatrix``; ``A^T y`` continues the column sums from chunk to
     chunk, bit for bit the unchunked product."""
 
-    def __init__(self, ncol, expect_chunks=0):
+    def __init__(self, ncol, expect_chunks=0, expect_rows=0):
         """``expect_chunks``: how many chunks will be appended (optional; lets the library take the next chunk's buffers from
-        the driver beside the work on it -- ``slp_matrix_chunked_expect``)."""
+        the driver beside the work on it -- ``slp_matrix_chunked_expect``).  ``expect_rows``: the row count of the whole matrix
+        (optional): every chunk then brings its exact share of a multiple of the CU count of tall row blocks, so that chunks of
+        unequal sizes (equality rows cut off into chunks of their own) fill the one grid of a product as equal chunks do."""
         l = _lib.lib()
         super().__init__(_lib.check_handle(l.slp_matrix_chunked_create(int(ncol))), (0, ncol))
-        if expect_chunks:
+        if expect_rows:
+            _lib.check(l.slp_matrix_chunked_expect_rows(self._h, int(expect_chunks), int(expect_rows)))
+        elif expect_chunks:
             _lib.check(l.slp_matrix_chunked_expect(self._h, int(expect_chunks)))
 
     def append(self, chunk):
@@ -196,7 +200,7 @@ class ChunkedDeviceMatrix(DeviceMatrix):
             head = cls.balanced_cuts(indptr[:cut_at + 1], chunk_entries)
             tail = cls.balanced_cuts(indptr[cut_at:] - indptr[cut_at], chunk_entries)
             cuts = head + [cut_at + c for c in tail[1:]]
-        g = cls(a.shape[1], expect_chunks=len(cuts) - 1)
+        g = cls(a.shape[1], expect_chunks=len(cuts) - 1, expect_rows=a.shape[0])
         for r0, r1 in zip(cuts, cuts[1:]):
             g.append(DeviceMatrix.from_csr(a[r0:r1]))
         return g
@@ -231,29 +235,9 @@ class ChunkedDeviceMatrix(DeviceMatrix):
             assert cut_at % 2 == 0, "every chunk but the last needs an even row count"
             chunks = max(2, chunks)
 
-            def fill(part, k):
-                # how full the tall row blocks of `k` equal chunks of `part` rows come out (csrc/slp_tall.hip tall_geometry: blocks of
-                # at most 9984 rows, in multiples of 256 / gcd(256, chunks) per chunk when the chunks run in one grid)
-                import math
-
-                mult = 256 // math.gcd(256, chunks)
-                per = -(-part // k)
-                blocks = -(-per // (9984 * mult)) * mult
-                return per / (blocks * 9984.0)
-
-            # how many of the chunks the rows in front of the cut get: in proportion, give or take -- a chunk up to twice the even
-            # share is fine in front (the first chunks are converted while the device is still empty) -- whichever split leaves the
-            # row blocks fullest (config 4 with 2e6 equality rows of 2e7 in 16 chunks: 1 + 15 gives blocks of 9616 / 9375 rows,
-            # 2 + 14 blocks of 8929)
-            share = rows / chunks
-            best = None
-            for head in range(1, chunks):
-                if cut_at / head > 2.05 * share or (rows - cut_at) / (chunks - head) > 1.25 * share:
-                    continue
-                score = (cut_at * fill(cut_at, head) + (rows - cut_at) * fill(rows - cut_at, chunks - head)) / rows
-                if best is None or score > best[0] + 1e-12:
-                    best = (score, head)
-            head = best[1] if best else min(chunks - 1, max(1, int(round(chunks * cut_at / rows))))
+            # the chunks in front of the cut and behind it in proportion to the rows (the library gives every chunk its exact share of
+            # the row blocks, slp_matrix_chunked_expect_rows: unequal chunks cost nothing in the products)
+            head = min(chunks - 1, max(1, int(round(chunks * cut_at / rows))))
             return ChunkedDeviceMatrix.cuts(cut_at, head) + [cut_at + c for c in ChunkedDeviceMatrix.cuts(rows - cut_at, chunks - head)[1:]]
         cuts = [(rows * k // chunks) & ~1 for k in range(chunks)] + [rows]
         return [c for i, c in enumerate(cuts) if i == 0 or c > cuts[i - 1]]

@@ -102,7 +102,7 @@ def random_lp_on_device(n, m, density, seed=0, row_offset=0, rows=None, chunks=1
         xf, c, lb, ub, b = a.random_lp_vectors(density, seed, row_offset, columns=columns, m_eq=m_eq)
         return a, xf, c, lb, ub, b
     cuts = ChunkedDeviceMatrix.cuts(rows, max(1, chunks), cut_at=m_eq)
-    a = ChunkedDeviceMatrix(n, expect_chunks=len(cuts) - 1)
+    a = ChunkedDeviceMatrix(n, expect_chunks=len(cuts) - 1, expect_rows=rows)
     for r0, r1 in zip(cuts, cuts[1:]):
         a.append(DeviceMatrix.random(r1 - r0, n, density, seed, row_offset + r0))
     # b_upper = ceil((A x_f + ...) 1000) / 1000 of all rows at once, through the product copies (one launch of the fused product)
