@@ -16,7 +16,7 @@ chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 n, m, p, seed = 10_000_000, 20_000_000, 1e-4, 0
 lib = _lib.lib(0)
 cuts = ChunkedDeviceMatrix.cuts(m, chunks)
-a = ChunkedDeviceMatrix(n, expect_chunks=len(cuts) - 1)
+a = ChunkedDeviceMatrix(n, expect_chunks=len(cuts) - 1, expect_rows=m)
 for r0, r1 in zip(cuts, cuts[1:]):
     a.append(DeviceMatrix.random(r1 - r0, n, p, seed, r0))   # (no LP vectors: nothing but the generator and the conversions runs before)
 out = {"nnz": a.nnz, "chunks": a.chunks}
