@@ -87,7 +87,7 @@ CONFIG_BLOCKS = {"c5": 8}   # row blocks of the whole LP (admm_blocks)
 # (record, launches of the recorded kernel that make ONE product: round 4 ran a launch per row chunk, round 5 runs one per product)
 PMC_FILES_BY_SHAPE = {(10_000_000, 2_500_000, 1e-4): {6: ((("r05_tall_slice_pmc_hbm.json", 1), ("r04_tall_slice_pmc_hbm.json", 1), ("r03_tall_slice_pmc_hbm.json", 1)),
                                                           "slp::k_tall_spmv")},
-                      (10_000_000, 20_000_000, 1e-4): {6: ((("r05_c4_pmc_hbm.json", 1), ("r04_c4_pmc_hbm.json", 8)), "slp::k_tall_spmv")},
+                      (10_000_000, 20_000_000, 1e-4): {6: ((("r06_c4_pmc_hbm.json", 1), ("r05_c4_pmc_hbm.json", 1), ("r04_c4_pmc_hbm.json", 8)), "slp::k_tall_spmv")},
                       (50_000_000, 4_000_000, 1e-4): {6: ((("r05_c5_pmc_hbm.json", 1), ("r04_c5shape_pmc_hbm.json", 1)), "slp::k_tall_spmv")}}
 # A chunk's CSR (12 B per entry) + its conversion temporaries (sorted keys 8 B, pass scratch) sit beside the copies already built:
 # at 1.3e9 entries per chunk (config 4: 16 chunks on one GPU) the set-up peaks at 252 of the 309 GB instead of 280 with 8 chunks.

@@ -357,6 +357,53 @@ def test_rendezvous_rejects_a_rank_of_another_job():
 
 
 @pytest.mark.timeout(120)
+def test_rendezvous_closes_its_handshake_and_answers_retries():
+    """ADVICE r05: the lost-acknowledgement hole.  A client only returns once rank 0's FINAL byte tells it that its ``OK`` arrived;
+    a client that sent ``OK`` but lost the connection before that byte connects again -- and rank 0, which has counted it as served
+    and gone on to the communicator's initialisation, still answers (a background thread keeps the listener for a while)."""
+    import socket
+    import threading
+    import time
+
+    from pysparselp_amd import parallel
+
+    port = _free_port()
+    os.environ["SLP_JOB_TOKEN"] = "job-handshake"
+    uid = bytes(reversed(range(128)))
+    got = {}
+    try:
+        tag = parallel.MAGIC + parallel.job_token(2)
+        th = threading.Thread(target=lambda: got.setdefault("server", parallel.rendezvous_unique_id(0, 2, lambda: uid, addr="127.0.0.1", port=port,
+                                                                                                    timeout=30.0)))
+        th.start()
+
+        def attempt(read_final):
+            for _ in range(100):
+                try:
+                    with socket.create_connection(("127.0.0.1", port), timeout=2.0) as conn:
+                        conn.settimeout(5.0)
+                        conn.sendall(tag + (1).to_bytes(4, "little"))
+                        reply = parallel._recv_exact(conn, len(tag) + 128)
+                        conn.sendall(b"OK")
+                        return reply, (parallel._recv_exact(conn, 1) if read_final else None)
+                except OSError:
+                    time.sleep(0.05)
+            raise AssertionError("rank 0 did not answer")
+
+        # the first connection acknowledges the id and drops before the final byte (as if that byte were lost)
+        reply, _ = attempt(read_final=False)
+        assert reply == tag + uid
+        th.join(timeout=20.0)
+        assert not th.is_alive() and got["server"] == uid        # rank 0 counted the peer as served and went on
+        # the client's retry is still answered, final byte included
+        reply, final = attempt(read_final=True)
+        assert reply == tag + uid and final == b"K"
+        # and the ordinary client path returns the id through the same listener
+        assert parallel.rendezvous_unique_id(1, 2, None, addr="127.0.0.1", port=port, timeout=10.0) == uid
+    finally:
+        del os.environ["SLP_JOB_TOKEN"]
+
+
 def test_host_transport_survives_a_connection_its_client_gave_up():
     """a client abandons a connection after 5 s without the tag echo and reconnects; rank 0, accepting strictly one
     after the other, may later pick up the ABANDONED socket (whose echo can still "succeed").  A connection only counts once

@@ -318,3 +318,48 @@ def test_abs_power_products_and_the_oracle_iterating_over_device_products(tall_r
     for u, v in ((through, want), (got, want), (got, through)):
         assert np.max(np.abs(u - v) / (1 + np.abs(v))) <= 1e-9
     a.close()
+
+
+@pytest.mark.parametrize("eq_frac", [0.0, 0.1])
+def test_oracle_streaming_its_own_products_equals_the_device_solvers(eq_frac):
+    """What tools/c4_streamed_parity.py does at config 4's full size (profiles/r06_c4_streamed_oracle_parity.json), in small:
+    ``oracle.StreamedCsr`` holds the LP one row chunk at a time -- regenerated by the counter-based generator, downloaded, multiplied
+    by the oracle's C kernels, dropped -- so NO device product enters the oracle's iteration.  Chambolle-Pock x bit for bit, matrix-free
+    ADMM <= 1e-9, with and without equality rows in chunks of their own."""
+    from pysparselp_amd.admm_cg import DeviceADMM
+    from pysparselp_amd.device import ChunkedDeviceMatrix, DeviceMatrix
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    sh = TALL
+    m_eq = (int(sh["m"] * eq_frac)) & ~1
+    a, xf, c, lb, ub, b = random_lp_on_device(sh["n"], sh["m"], sh["density"], seed=sh["seed"], chunks=3, m_eq=m_eq)
+    try:
+        cuts = ChunkedDeviceMatrix.cuts(sh["m"], 3, cut_at=m_eq)
+        asked = []
+
+        def source(k):
+            asked.append(k)
+            blk = DeviceMatrix.random(cuts[k + 1] - cuts[k], sh["n"], sh["density"], sh["seed"], cuts[k])
+            host = blk.download()
+            blk.close()
+            return host
+
+        st = oracle.StreamedCsr(sh["n"], cuts, source)
+        ops_eq = st.row_range(0, m_eq) if m_eq else None
+        ops_in = st.row_range(m_eq, sh["m"])
+        beq = b[:m_eq] if m_eq else None
+        want, _ = oracle.chambolle_pock_ppd(c, ops_eq, beq, ops_in, None, b[m_eq:], lb, ub, nb_max_iter=6, nb_iter_plot=10 ** 9)
+        s = DeviceCP(a, b, c, lb, ub, m_eq=m_eq)
+        s.iterate(6)
+        assert np.array_equal(s.x(), want)
+        s.close()
+        want = oracle.lp_admm_cg(c, ops_eq, beq, ops_in, None, b[m_eq:], lb, ub, nb_iter=4, nb_iter_plot=10 ** 9)
+        s = DeviceADMM(a, b, c, lb, ub, m_eq=m_eq)
+        s.iterate(5)
+        got = s.x(sh["n"])
+        s.close()
+        assert float(np.max(np.abs(got - want) / (1 + np.abs(want)))) <= 1e-9
+        assert len(asked) > 3 * 10            # every product streamed the chunks again (nothing cached, nothing from the device copies)
+    finally:
+        a.close()

@@ -81,6 +81,25 @@ def test_shipped_kernels_carry_no_lab_switches():
     assert int(_lib.load().slp_build_flags()) == 0
 
 
+def test_chunk_cuts_respect_the_boundary_between_equality_and_inequality_rows():
+    """``ChunkedDeviceMatrix.cuts(rows, chunks, cut_at)`` / ``from_csr(cut_at=...)``: the equality rows in front of ``cut_at`` and the
+    inequality rows behind it in chunks of their own (what lets Chambolle-Pock form (c + y_eq a_eq) + y_ineq a_ineq from two
+    products over the chunks' copies), every inner boundary even, chunks in proportion to the rows."""
+    from pysparselp_amd.device import ChunkedDeviceMatrix as C
+
+    for rows, chunks, cut in ((20_000_000, 16, 2_000_000), (60_000, 3, 6_000), (60_000, 8, 6_000), (2_000_000, 1, 200_000), (1001, 4, 500),
+                              (10_000, 5, 9_998)):
+        cuts = C.cuts(rows, chunks, cut_at=cut)
+        assert cuts[0] == 0 and cuts[-1] == rows and cut in cuts
+        assert all(a < b for a, b in zip(cuts, cuts[1:])) and all(c % 2 == 0 for c in cuts[1:-1])
+        assert len(cuts) - 1 == max(2, chunks) or rows < 4 * chunks
+        head = cuts.index(cut)
+        assert 1 <= head <= max(2, chunks) - 1 and abs(head - max(2, chunks) * cut / rows) <= 1.0
+    assert C.cuts(1000, 4) == [0, 250, 500, 750, 1000] and C.cuts(1000, 4, cut_at=0) == C.cuts(1000, 4)
+    indptr = np.arange(0, 1001, dtype=np.int64) * 7          # 1000 rows of 7 entries
+    assert C.balanced_cuts(indptr, 2000) == [0, 250, 500, 750, 1000]
+
+
 def test_admm_setup_matches_reference_arrays():
     """tools.py against the reference's precondition/standard-form/M chain (ADMM.py:76-101)."""
     d = load_golden("kernel_kats")
