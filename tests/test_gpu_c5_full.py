@@ -98,7 +98,9 @@ def test_every_block_is_resident_and_multiplies_like_the_oracle(c5):
 
 
 @pytest.mark.timeout(2400)
-def test_block_solver_invariants_on_the_whole_lp(c5):
+def test_block_solver_properties_on_the_whole_lp_not_an_oracle_comparison(c5):
+    """Properties only (projection residuals, determinism, bounds): the solver against the ORACLE at this size is
+    tools/c5_oracle_parity.py (profiles/r06_c5_oracle_parity.json), and on the reduced shape below."""
     grp, xf, c, lb, ub, b = c5
     runs = []
     for rep in range(2):

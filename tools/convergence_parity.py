@@ -9,7 +9,10 @@ Chambolle-Pock (ChambollePockPPD.py:195-343) for 2000 iterations, the matrix-fre
 at iterations 100 / 500 / 1000 / 2000: objective c.x relative to the oracle's, max |dx|, and the worst row violation
 max(A x - b) of both.  Bars: objective 1e-6 relative (CP: the iterates are bit-identical, so 0), violation equal to 1e-6.
 
-Writes gpurun_out/convergence_parity.json (copy to profiles/).  Usage: python tools/convergence_parity.py [--quick]"""
+``--eq-frac 0.1`` (round 6): the 10 %-equality variant of the same LPs (Chambolle-Pock then forms (c + y_eq a_eq) + y_ineq a_ineq
+from two products, csrc/slp_cp.hip cp_split_setup) -- the same bars.
+
+Writes gpurun_out/convergence_parity.json (copy to profiles/).  Usage: python tools/convergence_parity.py [--quick] [--eq-frac 0.1]"""
 import argparse
 import json
 import os
@@ -32,15 +35,19 @@ FORMATS = {"strips": (("dictionary strips", 0, (2, 3)), ("fp64 strips", 1, (1,))
            "tall": (("tall cells, dictionary items", 0, (6,)), ("tall cells, fp64 entries", 1, (7,)))}
 
 
-def run(shape, checkpoints_cp, checkpoints_admm, threads=64, seed=1):
-    """One LP: the oracle once per solver (iterates kept at the checkpoints), every format of the shape on the GPU."""
+def run(shape, checkpoints_cp, checkpoints_admm, threads=64, seed=1, eq_frac=0.0):
+    """One LP: the oracle once per solver (iterates kept at the checkpoints), every format of the shape on the GPU.
+    ``eq_frac`` > 0: SURVEY 8(d)'s equality variant (randomLP.py:62-68): the first eq_frac * m rows are equalities."""
     n, m, p = SHAPES[shape]
+    m_eq = (int(round(eq_frac * m)) & ~1) if eq_frac > 0 else 0
     os.environ["SLP_STRIP_MIN_NNZ"] = "1"
     oracle.set_threads(threads)
-    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=seed)
+    a, xf, c, lb, ub, b = random_lp_on_device(n, m, p, seed=seed, m_eq=m_eq)
     host = a.download()
     a.close()
-    rec = {"n": n, "m": m, "density": p, "stored_entries": int(host.nnz), "objective_at_the_generators_feasible_point": float(c.dot(xf))}
+    a_eq, b_eq, a_in, b_in = (host[:m_eq], b[:m_eq], host[m_eq:], b[m_eq:]) if m_eq else (None, None, host, b)
+    rec = {"n": n, "m": m, "equality_rows": m_eq, "density": p, "stored_entries": int(host.nnz),
+           "objective_at_the_generators_feasible_point": float(c.dot(xf))}
     want = {"cp": {}, "admm": {}}
 
     def keep(store, points):
@@ -50,26 +57,32 @@ def run(shape, checkpoints_cp, checkpoints_admm, threads=64, seed=1):
         return hook
 
     t0 = time.perf_counter()
-    oracle.chambolle_pock_ppd(c, None, None, host, None, b, lb, ub, nb_max_iter=max(checkpoints_cp), nb_iter_plot=10 ** 9,
+    oracle.chambolle_pock_ppd(c, a_eq, b_eq, a_in, None, b_in, lb, ub, nb_max_iter=max(checkpoints_cp), nb_iter_plot=10 ** 9,
                               iterate_hook=keep(want["cp"], set(checkpoints_cp)))
     rec["oracle_cp_seconds"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    oracle.lp_admm_cg(c, None, None, host, None, b, lb, ub, nb_iter=max(checkpoints_admm) - 1, nb_iter_plot=10 ** 9,
+    oracle.lp_admm_cg(c, a_eq, b_eq, a_in, None, b_in, lb, ub, nb_iter=max(checkpoints_admm) - 1, nb_iter_plot=10 ** 9,
                       iterate_hook=keep(want["admm"], set(checkpoints_admm)))
     rec["oracle_admm_seconds"] = time.perf_counter() - t0
+
+    def violation(x):   # inequality rows: a_i x - b_i ; equality rows: |a_i x - b_i|
+        r = host @ x - b
+        r[:m_eq] = np.abs(r[:m_eq])
+        return float(np.max(r))
 
     def compare(x, ref):
         og, oc = float(c.dot(x)), float(c.dot(ref))
         return {"objective_gpu": og, "objective_cpu": oc, "objective_relative_gap": abs(og - oc) / abs(oc),
                 "max_abs_dx": float(np.max(np.abs(x - ref))), "bit_identical": bool(np.array_equal(x, ref)),
-                "max_row_violation_gpu": float(np.max(host @ x - b)), "max_row_violation_cpu": float(np.max(host @ ref - b))}
+                "max_row_violation_gpu": violation(x), "max_row_violation_cpu": violation(ref)}
 
     rec["formats"] = {}
     for name, policy, kernels in FORMATS[shape]:
         out = {"chambolle_pock_ppd": {}, "admm": {}}
         a = random_lp_on_device(n, m, p, seed=seed)[0]
         a.set_format(policy)
-        cp = DeviceCP(a, b, c, lb, ub)
+        cp = DeviceCP(a, b, c, lb, ub, m_eq=m_eq)
+        out["chambolle_pock_split_form"] = cp.split_form()
         assert a.spmv_kernel(False) in kernels, (name, a.spmv_kernel(False))
         done = 0
         for k in sorted(checkpoints_cp):
@@ -77,7 +90,7 @@ def run(shape, checkpoints_cp, checkpoints_admm, threads=64, seed=1):
             done = k
             out["chambolle_pock_ppd"][str(k)] = compare(cp.x(), want["cp"][k])
         cp.close()
-        admm = DeviceADMM(a, b, c, lb, ub)     # (without a dictionary the rows are scaled in place: the matrix is not reused)
+        admm = DeviceADMM(a, b, c, lb, ub, m_eq=m_eq)     # (without a dictionary the rows are scaled in place: the matrix is not reused)
         out["admm_reuse_level"] = admm.reuse
         done = 0
         for k in sorted(checkpoints_admm):
@@ -108,14 +121,15 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--quick", action="store_true", help="200 iterations (the copy that runs inside pytest -m gpu)")
     p.add_argument("--threads", type=int, default=64)
+    p.add_argument("--eq-frac", type=float, default=0.0, help="fraction of the rows turned into equalities (randomLP.py:62-68)")
     p.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "convergence_parity.json"))
     args = p.parse_args()
     _lib.lib(0)
     cps = (50, 200) if args.quick else (100, 500, 1000, 2000)
     ads = (50, 200) if args.quick else (100, 500, 1000)
-    rec = {"checkpoints_cp": cps, "checkpoints_admm": ads, "oracle_threads": args.threads, "shapes": {}}
+    rec = {"checkpoints_cp": cps, "checkpoints_admm": ads, "oracle_threads": args.threads, "eq_frac": args.eq_frac, "shapes": {}}
     for shape in SHAPES:
-        rec["shapes"][shape] = run(shape, cps, ads, threads=args.threads)
+        rec["shapes"][shape] = run(shape, cps, ads, threads=args.threads, eq_frac=args.eq_frac)
     obj, vio = verdict(rec)
     rec["worst_objective_relative_gap"], rec["worst_violation_difference"] = obj, vio
     rec["bars"] = {"objective_relative": 1e-6, "violation_difference": 1e-6}
