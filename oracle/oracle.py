@@ -898,15 +898,18 @@ def lp_admm_blocks_cg(c, blocks, lb, ub, gamma=0.7, alpha=1.95, nb_iter=10, cg_t
     n = c.size
     st = []
     copies = np.zeros(n)
-    for a, bl, bu in blocks:
-        a = as_csr(a)
+    for a_given, bl, bu in blocks:
+        # a block may be handed over as a CALLABLE that returns its rows: it is then loaded for this set-up pass and again for each
+        # of its updates, and dropped in between -- eight 5e5 x 5e7 blocks (BASELINE config 5: 240 GB of CSR, twice that with the
+        # column-major copies the threaded products keep) never sit in host memory together (tools/c5_oracle_parity.py)
+        a = as_csr(a_given() if callable(a_given) else a_given)
         m = a.shape[0]
         bu = _f64(bu)
         bl = np.full(m, -np.inf) if bl is None else _f64(bl)
         used = np.zeros(n, dtype=bool)
         used[a.indices] = True   # a copy exists only for the variables the block uses (:183-185)
         copies += used
-        st.append({"a": a, "m": m, "slo": bl, "shi": bu, "used": used, "lam": np.zeros(n), "nu": np.zeros(m), "xsol": np.zeros(n),
+        st.append({"a": a_given if callable(a_given) else a, "m": m, "slo": bl, "shi": bu, "used": used, "lam": np.zeros(n), "nu": np.zeros(m), "xsol": np.zeros(n),
                    "xps": np.minimum(np.maximum(0.0, bl), bu), "lams": np.zeros(m),
                    "primal": (m >= n and m > 0) if primal is None else bool(primal)})
     xp = np.minimum(np.maximum(0.0, lb), ub)   # :84-86 with x0 = 0
@@ -939,6 +942,8 @@ def lp_admm_blocks_cg(c, blocks, lb, ub, gamma=0.7, alpha=1.95, nb_iter=10, cg_t
         xs_all = []
         for k, s in enumerate(st):
             a, m = s["a"], s["m"]
+            if callable(a):
+                a = as_csr(a())
             v = xp - s["lam"] / gamma
             vs = s["xps"] - s["lams"] / gamma
             if s["primal"]:
@@ -965,6 +970,7 @@ def lp_admm_blocks_cg(c, blocks, lb, ub, gamma=0.7, alpha=1.95, nb_iter=10, cg_t
             t = np.minimum(np.maximum(xs + s["lams"] / gamma, s["slo"]), s["shi"])
             s["lams"] = s["lams"] + gamma * (xs - t)
             s["xps"] = t
+            a = None   # (a streamed block goes again)
         t = np.where(copies > 0, total, xp) - c / gamma
         t = t / np.maximum(copies, 1.0)
         xp = np.minimum(np.maximum(t, lb), ub)

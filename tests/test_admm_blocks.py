@@ -232,3 +232,27 @@ def test_several_row_blocks_on_one_rank_match_the_reference_block_decomposition(
     one.close()
     single.close()
     a.close()
+
+
+def test_blocks_handed_over_as_callables_are_loaded_per_update():
+    """``oracle.lp_admm_blocks_cg`` with blocks given as callables (how tools/c5_oracle_parity.py --stream-blocks keeps one 30 GB block
+    of BASELINE config 5 in host memory at a time): the same iterates and conjugate-gradient step counts as with resident blocks, bit
+    for bit; every block loaded once for the set-up and once per iteration."""
+    import scipy.sparse
+
+    from oracle import oracle
+
+    rng = np.random.RandomState(0)
+    n, blocks = 300, []
+    for g in range(3):
+        a = scipy.sparse.random(80, n, 0.05, format="csr", random_state=rng)
+        a.sort_indices()
+        a.data = np.round(a.data * 10) / 10 + 0.05
+        blocks.append((a, None, a @ rng.rand(n) + 0.5))
+    c, lb, ub = rng.randn(n), -np.ones(n), np.ones(n)
+    want, steps = oracle.lp_admm_blocks_cg(c, blocks, lb, ub, nb_iter=4)
+    loads = []
+    lazy = [((lambda a=a, g=g: (loads.append(g), a)[1]), bl, bu) for g, (a, bl, bu) in enumerate(blocks)]
+    got, steps2 = oracle.lp_admm_blocks_cg(c, lazy, lb, ub, nb_iter=4)
+    assert np.array_equal(got, want) and steps == steps2
+    assert loads == [0, 1, 2] * 5
