@@ -156,11 +156,6 @@ int slp_matrix_chunked_expect(slp_matrix *chunked, int64_t chunks);
  * count of tall row blocks (cumulative shares rounded), whatever the chunks' sizes -- e.g. an LP whose equality rows
  * are cut off into chunks of their own (slp_cp_create_on with 0 < m_eq < m).  rows = 0: as slp_matrix_chunked_expect. */
 int slp_matrix_chunked_expect_rows(slp_matrix *chunked, int64_t chunks, int64_t rows);
-/* > 0: the tall-cell copy of this orientation runs on an ARITHMETIC value dictionary -- every stored value is k / q for an
- * integer |k| <= 1023 and this q (rounded coefficients: randomLP.py:21 draws k / 100), verified bit for bit at build time --
- * and the product kernel computes a value from its 11-bit code instead of gathering it from a table in LDS.  0: a table
- * (or no tall-cell copy); -1: error.  SLP_TALL_ARITH=0 turns the tier off.  Results do not change by a bit either way. */
-double slp_matrix_tall_arith(slp_matrix *a, int transposed);
 /* Chunks appended so far; 0 for an ordinary matrix, -1 for NULL. */
 int64_t slp_matrix_chunks(const slp_matrix *a);
 /* Product-kernel launches one y = A x (transposed: A^T y) takes: 1 for an ordinary matrix, up to one per row chunk for a

@@ -62,7 +62,6 @@ _SIGNATURES = {
     "slp_matrix_strip_width": (c_i64, [c_vp, c_int]),
     "slp_matrix_chunked_expect": (c_int, [c_vp, c_i64]),
     "slp_matrix_chunked_expect_rows": (c_int, [c_vp, c_i64, c_i64]),
-    "slp_matrix_tall_arith": (c_dbl, [c_vp, c_int]),
     "slp_cp_create": (c_vp, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_cp_create_on": (c_vp, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "slp_cp_destroy": (None, [c_vp]),

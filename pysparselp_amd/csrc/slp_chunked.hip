@@ -164,19 +164,6 @@ int64_t slp_matrix_strip_width(slp_matrix *m, int transposed) {
     return rc == 0 ? c : -1;
 }
 
-double slp_matrix_tall_arith(slp_matrix *m, int transposed) {
-    if (!m) return -1.0;
-    double q = 0.0;
-    const int rc = [&]() -> int {
-        SLP_API_INT({
-            const StripJds *f = fast_format(m, transposed != 0);
-            if (f && !m->chunks.empty() && !f->parts.empty() && !f->fused) f = f->parts[0];
-            q = (f && f->ok && f->tall) ? f->arith_q : 0.0;
-        })
-    }();
-    return rc == 0 ? q : -1.0;
-}
-
 int64_t slp_matrix_product_launches(const slp_matrix *g, int transposed) {
     if (!g) return -1;
     if (g->chunks.empty()) return 1;

@@ -254,8 +254,6 @@ struct StripJds {
     DevBuf<unsigned short> col;   // [nnz] column inside the strip
     // value-dictionary variant (matrices with few distinct stored values): an entry is (uint16 value id,
     // uint16 column) = 4 B; pairs of entries are packed as {id0, id1, col0, col1}; the D values sit in LDS
-    double arith_q = 0.0;         // tall cells over an arithmetic dictionary (ValueDict::arith_q): `dict` is its 2048-entry table
-    const double *arith_table = nullptr;   // ... that table (a launch whose `dict` is another table -- |v|^p -- gathers as usual)
     int C = 0;                    // columns per strip of this copy
     int D = 0;                    // 0: fp64 values in `val`; > 0: `ent` + `dict`
     bool wide = false;            // strips of 131072 columns, x gathered from L2 instead of an LDS tile (32-bit columns)
@@ -283,14 +281,8 @@ struct ValueDict {
     int D = 0;
     DevBuf<double> values;                // [D] ascending (total order on the bit patterns: -0.0 < +0.0)
     DevBuf<unsigned long long> keys;      // [D] order-preserving integer image of `values`
-    // > 0: an ARITHMETIC dictionary -- entry `code` is the quotient (code - 1024) / arith_q as tall_quotient() (slp_kernels.h)
-    // forms it, for all 2048 codes: the tall-cell product kernel computes a value from its code (three fp64 operations)
-    // instead of gathering it from a table in LDS (value_dictionary_arith)
-    double arith_q = 0.0;
 };
 bool value_dictionary(const CsrDev &a, ValueDict &d);
-// The arithmetic dictionary that contains every value of `d` (rounded coefficients k / q: randomLP.py:21 draws k / 100), or false
-bool value_dictionary_arith(const ValueDict &d, ValueDict &arith);
 bool strip_wanted(const CsrDev &a, int variant);   // variant: 0 fp64 entries, 1 dictionary pairs, 2 dictionary quads, 3 wide strips
 bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int variant);
 void strip_spmv(const StripJds &f, const double *x, double *out);
@@ -323,7 +315,6 @@ struct slp_matrix {
     slp::StripJds fa, fat;            // LDS-tiled copies of a / at, built on first use when they pay
     bool tried_fa = false, tried_fat = false;
     slp::ValueDict vdict;             // shared by both orientations
-    slp::ValueDict vdict_arith;       // its arithmetic superset for the tall-cell copies, where one exists (state 0: none)
     slp::DevBuf<double> vx, vy;  // scratch vectors for the host-vector entry points
     int format_policy = 0;       // slp_matrix_set_format: 0 auto, 1 no value dictionary (fp64 entries), 2 CSR kernels only
     bool scaled = false;         // the stored values were row-normalised in place by an ADMM setup (not idempotent)

@@ -169,15 +169,4 @@ __device__ __forceinline__ void row_dot_split(const i64 *__restrict__ ptr, const
         default: { constexpr int L = 64; CALL; } break;   \
     }
 
-// (code - 1024) / q, correctly rounded in all the cases the build verifies (every code of an arithmetic dictionary is generated by
-// THIS function on the device and the matrix's values are required to be among them, value_dictionary_arith): the integer goes
-// into a double through the 2^52 trick, q0 = k rq is within an ulp of the quotient, the fma's remainder k - q0 q is exact, the last
-// fma rounds the corrected quotient.  rq = 1.0 / q.  -ffp-contract=off: the fmas are the written ones.
-__device__ inline double tall_quotient(unsigned int code, double q, double rq) {
-    const double kd = __hiloint2double(0x43300000, (int)code) - (4503599627370496.0 + 1024.0);
-    const double q0 = kd * rq;
-    const double rem = __builtin_fma(-q0, q, kd);
-    return __builtin_fma(rem, rq, q0);
-}
-
 }  // namespace slp

@@ -304,11 +304,7 @@ const StripJds *fast_format(slp_matrix *m, bool transposed) {
         // long rows that are sparse inside every LDS-sized window (the slice of a 1e7-variable LP): tall cells -- for A^T taken
         // straight from the CSR of A, no transposed CSR is formed
         const bool tall = tall_wanted(shape.nrow, shape.ncol, shape.nnz);
-        if (!dict && tall && matrix_dictionary(m)) {
-            // rounded coefficients (k / q): the copy's items carry the code of the ARITHMETIC dictionary, whose values the kernel computes
-            const ValueDict *vd = value_dictionary_arith(m->vdict, m->vdict_arith) ? &m->vdict_arith : &m->vdict;
-            if (tall_build(m->a, transposed, f, vd, m->tall_block_multiple, m->tall_rows_before, m->tall_rows_total)) return &f;
-        }
+        if (!dict && tall && matrix_dictionary(m) && tall_build(m->a, transposed, f, &m->vdict, m->tall_block_multiple, m->tall_rows_before, m->tall_rows_total)) return &f;
         if (!dict && !strip_wanted(shape, 0) && tall && tall_build(m->a, transposed, f, nullptr, m->tall_block_multiple, m->tall_rows_before, m->tall_rows_total)) return &f;  // arbitrary values: fp64 entries
         if (transposed) build_transpose(m);  // the other copies are converted from the orientation's own CSR
         const CsrDev &a = transposed ? m->at : m->a;
@@ -374,7 +370,6 @@ void invalidate_derived(slp_matrix *m) {
     m->fat = StripJds();
     m->tried_fa = m->tried_fat = false;
     m->vdict = ValueDict();
-    m->vdict_arith = ValueDict();
 }
 
 void finish_stats(CsrDev &a) {  // fills a.max_row_len (kernel choices depend on it: every constructor must call this)

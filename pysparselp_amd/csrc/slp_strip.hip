@@ -1043,57 +1043,6 @@ bool value_dictionary(const CsrDev &a, ValueDict &d) {
     return true;
 }
 
-__global__ void k_arith_table(double q, double *__restrict__ values, unsigned long long *__restrict__ keys) {
-    const unsigned int code = blockIdx.x * blockDim.x + threadIdx.x;
-    if (code < 2048u) {
-        const double v = tall_quotient(code, q, 1.0 / q);
-        values[code] = v;
-        keys[code] = value_key((unsigned long long)__double_as_longlong(v));
-    }
-}
-
-// Rounded coefficients -- randomLP.py:21 draws round(100 N(0,1)) / 100; +-1 patterns; decimals of netlib-style data -- are k / q
-// with a small integer k: every value of `d` is looked for among the 2048 quotients (code - 1024) / q, q from a short list, AS THE
-// DEVICE FORMS THEM (the table comes from tall_quotient on the device; a value must equal its entry bit for bit, so -0.0, a value
-// a last bit off k / q, or |k| > 1023 all fall back to the table in LDS).  SLP_TALL_ARITH=0 turns the tier off.
-bool value_dictionary_arith(const ValueDict &d, ValueDict &arith) {
-    if (arith.state >= 0) return arith.state == 1;
-    arith.state = 0;
-    const char *e = getenv("SLP_TALL_ARITH");
-    if ((e && e[0] == '0') || d.state != 1 || d.D <= 0) return false;
-    std::vector<double> vals((size_t)d.D);
-    d.values.download(vals.data(), vals.size());
-    static const double qs[] = {1, 2, 4, 5, 8, 10, 16, 20, 25, 32, 40, 50, 64, 100, 125, 128, 200, 250, 256, 400, 500, 1000};
-    for (double q : qs) {
-        bool fits = true;
-        for (double v : vals) {
-            const double k = std::nearbyint(v * q);
-            if (!(std::fabs(k) <= 1023.0) || k / q != v) { fits = false; break; }
-        }
-        if (!fits) continue;
-        DevBuf<double> tv(2048);
-        DevBuf<unsigned long long> tk(2048);
-        hipLaunchKernelGGL(k_arith_table, dim3(8), dim3(256), 0, ctx().stream, q, tv.p, tk.p);
-        SLP_HIP(hipGetLastError());
-        std::vector<double> table(2048);
-        tv.download(table.data(), table.size());
-        bool ok = true;
-        for (size_t i = 1; i < table.size() && ok; ++i) ok = table[i - 1] < table[i];
-        for (size_t i = 0; i < vals.size() && ok; ++i) {
-            const long long k = (long long)std::nearbyint(vals[i] * q);
-            ok = std::memcmp(&table[(size_t)(k + 1024)], &vals[i], sizeof(double)) == 0;
-        }
-        if (!ok) continue;
-        arith.values = std::move(tv);
-        arith.keys = std::move(tk);
-        arith.D = 2048;
-        arith.arith_q = q;
-        arith.state = 1;
-        return true;
-    }
-    return false;
-}
-
 // Builds the strip format of `a` (rows sorted by column).  Returns false (and leaves f.ok == false)
 // when the matrix does not qualify: unsorted rows, or a row with >= 256 entries inside one strip.
 // dict != NULL: the value-dictionary variant (narrower strips, 4-byte entries).

@@ -947,8 +947,6 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
     f.nrow = nrowF; f.ncol = ncolF; f.nnz = a.nnz; f.T = T; f.B = B; f.C = (int)Cw; f.rpl = 1;
     f.D = dict ? dict->D : 0;
     f.dict = dict ? dict->values.p : nullptr;
-    f.arith_q = dict ? dict->arith_q : 0.0;   // an arithmetic dictionary: the product kernel computes the value from the item's code
-    f.arith_table = f.arith_q > 0.0 ? f.dict : nullptr;
     f.tall = true;
     f.tall_R = R;
     f.S = S;

@@ -35,21 +35,15 @@ struct TallRegs {
 // C: columns per strip = doubles of an x-tile (4096, 2048 or 1024: the build halves the strips of denser matrices until a cell
 // holds ~0.3-0.6 entries per row -- the regime the dealing of a cell's rows to the lanes is made for; items keep their 12-bit
 // column field).
-// ARITH (DICT only): the copy's dictionary is an arithmetic one (ValueDict::arith_q = `pw` here): the value of an item is COMPUTED from
-// its 11-bit code, (code - 1024) / q by tall_quotient() -- three fp64 operations -- instead of gathered from the table in LDS: one of
-// the two bank-conflict-ridden gathers of an item gone (round 6: -2.4 % at config 4; every table entry is generated by the same
-// function at build time and the matrix's values are required to be among them, so the product is the same bit for bit).
-template <bool DICT, bool ACC, bool POW = false, int C = kTallC, bool ARITH = false>
+template <bool DICT, bool ACC, bool POW = false, int C = kTallC>
 __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__restrict__ wgs, const double *__restrict__ dict_arg,
                                                       const double *__restrict__ x, double *__restrict__ out, double pw) {
-    static_assert(!ARITH || (DICT && !POW), "arithmetic dictionaries: dictionary items only");
     constexpr int kDepth = DICT ? kTallDepth : 2;
     // acc[0] is a scratch cell: the row field of an item is its local row + 1, and whatever is not a lane's item -- a slot
     // beyond its list (the load past the buffer descriptor returns 0), a skip item -- decodes to row 0, value id 0, column 0
     // and adds into the scratch cell: no predicate on the stores, none on the sums
     __shared__ double acc[kTallRmax + 1];
-    __shared__ double dv[ARITH ? 1 : kTallDictMax];
-    const double aq = pw, arq = 1.0 / pw;   // (ARITH: the dictionary's divisor and its reciprocal, as k_arith_table forms it)
+    __shared__ double dv[kTallDictMax];
     static_assert(C == 4096 || C == 2048 || C == 1024, "tall cells: strip width");
     __shared__ double xt[2][C];
     constexpr int kPieces = C / 2048 ? C / 2048 : 1;     // 16-byte pieces of a tile per lane
@@ -67,7 +61,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
     for (int r = p; r <= wg.nrows; r += kTallT) acc[r] = (ACC && r > 0) ? out[wg.row0 + r - 1] : 0.0;
   for (int seg = 0; seg < nseg; ++seg) {
     if (seg > 0) wg = wgs[(i64)seg * gridDim.x + v];
-    if (DICT && !ARITH) {
+    if (DICT) {
         const double *__restrict__ dsrc = dict_arg ? dict_arg : wg.dict;
         for (int q = p; q < wg.D; q += kTallT) dv[q] = dsrc[q];
     }
@@ -241,8 +235,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
                     pr[k] = __builtin_fma(rem, 0.01, q0) * tile[(w[k] >> kTallIdBits) & (kTallC - 1)];
                 } else
 #endif
-                pr[k] = DICT ? (ARITH ? tall_quotient(w[k] & ((1u << kTallIdBits) - 1), aq, arq) : dv[w[k] & ((1u << kTallIdBits) - 1)]) *
-                                   tile[(w[k] >> kTallIdBits) & (kTallC - 1)]
+                pr[k] = DICT ? dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)]
                              : (POW ? abs_pow(g.val[DICT ? 0 : k0 + k], pw) * 1.0 : g.val[DICT ? 0 : k0 + k]) * tile[w[k] & (kTallC - 1)];
             }
 #ifdef SLP_TALL_LAB_ATOMIC
@@ -296,12 +289,12 @@ __global__ void k_tall_combine(i64 nrow, int S, const double *__restrict__ part,
 }
 
 // the instantiation for the copy's strip width
-template <bool DICT, bool ACC, bool POW, bool ARITH = false>
+template <bool DICT, bool ACC, bool POW>
 static void tall_launch(int C, unsigned grid, int nseg, const TallWg *wgs, const double *dict, const double *x, double *out, double pw) {
     switch (C) {
-    case 4096: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 4096, ARITH>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
-    case 2048: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 2048, ARITH>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
-    case 1024: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 1024, ARITH>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
+    case 4096: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 4096>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
+    case 2048: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 2048>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
+    case 1024: hipLaunchKernelGGL((k_tall_spmv<DICT, ACC, POW, 1024>), dim3(grid), dim3(kTallT), 0, ctx().stream, nseg, wgs, dict, x, out, pw); break;
     default: SLP_REQUIRE(false, "tall cells: strip width");
     }
 }
@@ -311,10 +304,7 @@ void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
     const unsigned grid = (unsigned)(f.B * f.S);
     const bool acc = accum && f.S == 1;
     const double *none = nullptr;
-    // (an arithmetic dictionary whose own table is the launch's: values computed; another table behind the codes -- |v|^p -- gathered)
-    const bool arith = f.D > 0 && f.arith_q > 0.0 && f.dict == f.arith_table;
-    if (arith) { if (acc) tall_launch<true, true, false, true>((int)f.C, grid, 1, f.tall_wg.p, f.dict, x, dst, f.arith_q); else tall_launch<true, false, false, true>((int)f.C, grid, 1, f.tall_wg.p, f.dict, x, dst, f.arith_q); }
-    else if (f.D > 0) { if (acc) tall_launch<true, true, false>((int)f.C, grid, 1, f.tall_wg.p, f.dict, x, dst, 0.0); else tall_launch<true, false, false>((int)f.C, grid, 1, f.tall_wg.p, f.dict, x, dst, 0.0); }
+    if (f.D > 0) { if (acc) tall_launch<true, true, false>((int)f.C, grid, 1, f.tall_wg.p, f.dict, x, dst, 0.0); else tall_launch<true, false, false>((int)f.C, grid, 1, f.tall_wg.p, f.dict, x, dst, 0.0); }
     else { if (acc) tall_launch<false, true, false>((int)f.C, grid, 1, f.tall_wg.p, none, x, dst, 0.0); else tall_launch<false, false, false>((int)f.C, grid, 1, f.tall_wg.p, none, x, dst, 0.0); }
     if (f.S > 1)
         hipLaunchKernelGGL(k_tall_combine, dim3(grid_for(f.nrow, kBlock)), dim3(kBlock), 0, ctx().stream, f.nrow, f.S, f.part.p, out, accum);
@@ -328,8 +318,7 @@ void tall_spmv(const StripJds &f, const double *x, double *out, int accum) {
 void tall_spmv_fused(const StripJds &f, const double *x, double *out) {
     const int nseg = f.parts_cols ? (int)f.parts.size() : 1;
     const unsigned grid = (unsigned)(f.tall_wg.n / (size_t)nseg);
-    if (f.D > 0 && f.arith_q > 0.0) tall_launch<true, false, false, true>((int)f.C, grid, nseg, f.tall_wg.p, nullptr, x, out, f.arith_q);   // (every chunk on the same divisor: tall_fuse)
-    else if (f.D > 0) tall_launch<true, false, false>((int)f.C, grid, nseg, f.tall_wg.p, nullptr, x, out, 0.0);
+    if (f.D > 0) tall_launch<true, false, false>((int)f.C, grid, nseg, f.tall_wg.p, nullptr, x, out, 0.0);
     else tall_launch<false, false, false>((int)f.C, grid, nseg, f.tall_wg.p, nullptr, x, out, 0.0);
     SLP_HIP(hipGetLastError());
 }
@@ -360,11 +349,6 @@ bool tall_fuse(StripJds &f) {
     }
     f.tall_wg.upload(all.data(), all.size());
     f.C = f0.C;
-    // values computed from their codes only when every chunk's dictionary is arithmetic with ONE divisor (else every chunk's table --
-    // an arithmetic dictionary is a table too -- is gathered from)
-    f.arith_q = f0.arith_q;
-    for (const StripJds *g : f.parts)
-        if (g->arith_q != f0.arith_q) f.arith_q = 0.0;
     return true;
 }
 

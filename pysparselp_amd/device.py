@@ -139,11 +139,6 @@ class DeviceMatrix:
         """0: best available copy; 1: no value dictionary (fp64 strip entries); 2: CSR kernels only."""
         _lib.check(self._l.slp_matrix_set_format(self._h, int(policy)))
 
-    def tall_arith(self, transposed=False):
-        """The divisor q of the arithmetic value dictionary the tall-cell copy of this orientation runs on (every stored value k / q,
-        computed from its code in the product kernel), or 0.0 when its values are gathered from a table (or it has no tall cells)."""
-        return float(self._l.slp_matrix_tall_arith(self._h, int(bool(transposed))))
-
     def spmv_kernel(self, transposed=False):
         return int(self._l.slp_matrix_spmv_kernel(self._h, int(transposed)))
 

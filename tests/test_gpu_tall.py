@@ -297,46 +297,3 @@ def test_strip_width_follows_the_cost_model():
     finally:
         del os.environ["SLP_TALL_C"]
 
-
-
-def test_arithmetic_dictionary_computes_the_same_values_it_would_gather():
-    """Round 6: rounded coefficients (k / q -- randomLP.py:21 draws round(100 N(0,1)) / 100) make an ARITHMETIC dictionary: the product
-    kernel computes a value from its 11-bit code ((code - 1024) / q by three fp64 operations, every table entry generated by the same
-    device function and the matrix's values required to be among them) instead of gathering it from LDS.  Bit for bit the oracle's
-    products with the tier on (q = 100 detected) and off (SLP_TALL_ARITH=0); values that are NOT k / q (multiples of sqrt(2)), a
-    -0.0 or a k beyond the code range fall back to the table -- and are the oracle's too."""
-    from pysparselp_amd.device import DeviceMatrix
-
-    rng = np.random.RandomState(21)
-    base = _random(20000, 50001, 1e-4, 11)                       # values round(randn, 2): k / 100
-    irrational = base.copy()
-    irrational.data = np.sqrt(2.0) * np.round(rng.randn(base.nnz) * 3)      # few distinct values, none of them k / q
-    irrational.data[irrational.data == 0] = np.sqrt(2.0)
-    wide = base.copy()
-    wide.data = np.round(rng.randn(base.nnz) * 100) / 100
-    wide.data[wide.data == 0] = 0.5
-    wide.data[:3] = [12.34, -11.0, 10.5]                         # |k| > 1023 at q = 100; 10.5 = 21 / 2 does not save it
-    quarters = base.copy()
-    quarters.data = np.round(rng.randn(base.nnz) * 8) / 4 + 0.25  # k / 4
-    x, y = rng.randn(base.shape[1]), rng.randn(base.shape[0])
-    for name, mat, want_q in (("hundredths", base, 100.0), ("irrational", irrational, 0.0), ("beyond the codes", wide, 0.0),
-                              ("quarters", quarters, 4.0)):
-        ax, aty = oracle.matvec(oracle.as_csr(mat), x), oracle.rmatvec(oracle.as_csr(mat), y)
-        for env, q in ((None, want_q), ("0", 0.0)):
-            if env is None:
-                os.environ.pop("SLP_TALL_ARITH", None)
-            else:
-                os.environ["SLP_TALL_ARITH"] = env
-            a = DeviceMatrix.from_csr(mat)
-            try:
-                assert a.spmv_kernel(False) == 6 and a.tall_arith(False) == q, (name, env, a.tall_arith(False))
-                assert np.array_equal(a.matvec(x), ax), (name, env)
-                if a.spmv_kernel(True) == 6:
-                    assert a.tall_arith(True) == q
-                assert np.array_equal(a.rmatvec(y), aty), (name, env)
-                for p in (1.0, 2.0):      # another table behind the same codes: gathered, whatever the dictionary
-                    powered = oracle.Csr(mat.indptr, mat.indices, np.abs(mat.data) ** p, mat.shape)
-                    assert np.array_equal(a.abs_pow_matvec(x, p), oracle.matvec(powered, x)), (name, env, p)
-            finally:
-                a.close()
-    os.environ.pop("SLP_TALL_ARITH", None)
