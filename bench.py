@@ -32,7 +32,14 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
                   SpMV in both orientations, one Chambolle-Pock and one ADMM (reuse level 4) step rate.
 ``cpu_baseline``  the oracle (CPU restatement of the reference algorithm, single thread like the reference) on a bounded
                   sample of the same workload: the first rows of the same LP (all n columns, so the gathers hit a vector
-                  of the full size), ITERATIONS ONLY (setup excluded), scaled by the row ratio; ``extrapolated: true``.
+                  of the full size), ITERATIONS ONLY (setup excluded), scaled by the row ratio; ``extrapolated: true``;
+                  ``matrix_products_per_iteration`` = the products of the reference's form of the iteration that it times
+                  (ADMM 10, Chambolle-Pock 2; the device spends ``config.matrix_passes_per_iteration`` = 4 / 2 on the same iterates).
+``chambolle_pock`` / ``cpu_baseline.chambolle_pock``  (default line) the Chambolle-Pock rate on the same resident LP and the oracle's on
+                  the same sample: the method where both sides do the SAME two products per iteration.
+``--eq-frac 0.1``  SURVEY 8(d)'s second workload: the first tenth of the rows are equalities a_i x = a_i x_feasible
+                  (randomLP.py:62-68); a chunked block is cut at the boundary, Chambolle-Pock keeps the reference's
+                  (c + y_eq a_eq) + y_ineq a_ineq bit for bit (csrc/slp_cp.hip cp_split_setup).
 """
 import argparse
 import json
