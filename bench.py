@@ -468,6 +468,9 @@ def self_launch(args):
         else:
             raise SystemExit("bench.py: no free block of 10 ports on 127.0.0.1 for the ranks' rendezvous")
     token = os.environ.get("SLP_JOB_TOKEN") or secrets.token_hex(8)
+    import signal
+
+    signal.signal(signal.SIGTERM, lambda *_: sys.exit(143))   # (a `timeout` around the launcher ends the ranks too)
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
@@ -475,12 +478,7 @@ def self_launch(args):
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
                                       stdout=None if r == 0 else sys.stderr))   # rank 0 prints the line; the others print nothing
-    failed = None
-    while failed is None and any(p.poll() is None for p in procs):
-        time.sleep(0.2)
-        failed = next((p for p in procs if p.poll() not in (None, 0)), None)
-    if failed is not None:   # a rank died: the others sit in a collective (or its initialisation) for ever -- end them, by PID
-        time.sleep(2.0)
+    def end_ranks():   # by PID, never by pattern
         for p in procs:
             if p.poll() is None:
                 p.terminate()
@@ -489,6 +487,18 @@ def self_launch(args):
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
                 p.kill()
+
+    failed = None
+    try:
+        while failed is None and any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+    except BaseException:   # the launcher itself is being ended (Ctrl-C, a timeout's SIGTERM as KeyboardInterrupt / SystemExit): no orphans
+        end_ranks()
+        raise
+    if failed is not None:   # a rank died: the others sit in a collective (or its initialisation) for ever -- end them
+        time.sleep(2.0)
+        end_ranks()
         print(f"bench.py: rank {procs.index(failed)} exited with code {failed.returncode}; job ended", file=sys.stderr, flush=True)
         raise SystemExit(failed.returncode if failed.returncode and failed.returncode > 0 else 1)
     raise SystemExit(0)
