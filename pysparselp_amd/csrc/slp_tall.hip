@@ -939,6 +939,23 @@ bool tall_build(const CsrDev &a, bool transposed, StripJds &f, const ValueDict *
         wg[(size_t)v].nrows = (int)std::min<i64>(R, nrowF - b * (i64)R);
         wg[(size_t)v].D = dict ? dict->D : 0;
     }
+    if (S > 1 && V > 8) {
+        // Strip-range split (a block of BASELINE config 5: 51 row blocks x 5 ranges): the workgroups of ONE range read the same fifth
+        // of x (80 MB of 400), so they belong on one XCD's L2 -- workgroups whose index is equal mod 8 share an XCD
+        // (cdna_hip_programming.md T1; a placement hint, never a correctness matter: the ranges' partial sums are combined in range
+        // order by k_tall_combine whatever ran where).  The table is laid out so that XCD label l walks a contiguous stretch of the
+        // range-major order (bijective for any V): every XCD then pulls at most two ranges' x instead of all five (round 5's PMC:
+        // 16.8 GB per product for a 12.9 GB copy, the 400 MB x fetched by every XCD).
+        const i64 q = V / 8, r = V % 8;
+        std::vector<TallWg> placed((size_t)V);
+        for (i64 orig = 0; orig < V; ++orig) {
+            const i64 xcd = orig % 8;
+            const i64 pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;   // position in the range-major order
+            const i64 sr = pos / B, b = pos % B;
+            placed[(size_t)orig] = wg[(size_t)(b * S + sr)];
+        }
+        wg.swap(placed);
+    }
     f.tall_wg.upload(wg.data(), wg.size());
     SLP_HIP(hipStreamSynchronize(st));
     // (what a product streams: the words written, not the buffer's margin)
