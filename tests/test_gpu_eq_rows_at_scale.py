@@ -181,3 +181,26 @@ def test_b_upper_does_not_depend_on_the_strip_range_split():
             assert np.array_equal(got[0].matvec(x, order=1), seq)     # SLP_ORDER_SEQUENTIAL: the single chain
         got[0].close()
     assert np.array_equal(np.concatenate(parts), b_whole)
+
+
+@pytest.mark.parametrize("name, m_eq, form", [("tall", 6001, 2), ("tall", 2, 2), ("tall", 59_998, 2), ("strips", 3001, 2), ("strips", 2, 2),
+                                               ("strips", 29_000, 1)])
+def test_awkward_numbers_of_equality_rows(name, m_eq, form):
+    """Edge cases of the split: an ODD number of equality rows (the strip kernels stage y + m_eq by 16-byte loads: no row-range copies),
+    two equality rows or nearly all rows equalities (a row range too small for a strip copy of its own) -- the two masked products over
+    the whole copy take over, bit for bit the oracle's iterate like every other form."""
+    from pysparselp_amd.problems import random_lp_on_device
+    from pysparselp_amd.scale import DeviceCP
+
+    shape = SHAPES[name]
+    a, xf, c, lb, ub, b = random_lp_on_device(shape["n"], shape["m"], shape["density"], seed=shape["seed"], m_eq=m_eq)
+    try:
+        host = a.download()
+        want, _ = oracle.chambolle_pock_ppd(c, host[:m_eq], b[:m_eq], host[m_eq:], None, b[m_eq:], lb, ub, nb_max_iter=8, nb_iter_plot=10 ** 9)
+        s = DeviceCP(a, b, c, lb, ub, m_eq=m_eq)
+        assert s.split_form() == form, s.split_form()
+        s.iterate(8)
+        assert np.array_equal(s.x(), want)
+        s.close()
+    finally:
+        a.close()
