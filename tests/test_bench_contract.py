@@ -189,6 +189,26 @@ def test_self_launched_two_ranks_equal_the_launcher_run():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["chambolle_pock_ppd", "admm"])
+def test_two_ranks_with_equality_rows_match_one_rank(method):
+    """SURVEY 8(d)'s equality variant under a row partition (``--eq-frac 0.1 --gpus 2``, self-launched, host transport on one GPU): the
+    first rank's block holds the equality rows and some inequality rows, the second only inequalities; every rank is told ITS number of
+    equality rows.  Same LP (stored entries), same objective as the one-process run to the summation-order tolerance of a partition."""
+    env = {"SLP_DEVICE": "0", "SLP_COMM_TRANSPORT": "host", "SLP_STRIP_MIN_NNZ": "1"}
+    more = ("--eq-frac", "0.1", "--method", method)
+    r2 = _self_launch(2, env, more=more)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    two = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][0])
+    check_line(two, need_cpu_baseline=False)
+    r1 = _self_launch(1, {"SLP_STRIP_MIN_NNZ": "1"}, more=more)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    one = json.loads([l for l in r1.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["config"]["equality_rows"] == one["config"]["equality_rows"] == 4000
+    assert two["config"]["nnz"] == one["config"]["nnz"]
+    assert abs(two["objective_after_run"] - one["objective_after_run"]) <= 1e-9 * (1 + abs(one["objective_after_run"]))
+
+
+@pytest.mark.gpu
 def test_bench_under_the_launcher_one_rank_rccl():
     """The driver's launch line with N = 1 and the N > 1 plumbing forced on: launcher env, TCP id exchange, a one-rank
     RCCL communicator, the packed exchange (2 collectives per ADMM iteration)."""
