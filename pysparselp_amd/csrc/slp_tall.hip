@@ -140,15 +140,43 @@ __global__ void k_tall_cellptr(i64 nnz, i64 ncell, const unsigned long long *__r
 }
 
 // ---- build, step 2: packets -------------------------------------------------------------------------------------------
-// block-wide exclusive scan of one 64-bit word per thread (three 21-bit counters packed); total in *tot
+// REGISTERS (round 6).  Everything derived from the thread index -- LDS addresses of ten arrays, the masks of ~80 comparisons
+// `i < p / 32`, `i < wave` of the unrolled scans -- is invariant over the cells a workgroup takes; the compiler computed all of it
+// once in front of the cell loop and then could not keep it: 42 vector registers spilled to scratch (164 bytes per lane, stored in
+// the prologue, re-read in every cell: 160 KB per cell against the cell's 32 KB of keys -- more than the L2 share of a workgroup)
+// and 130 scalar ones.  SLP_OPAQUE(v) is an empty asm statement that claims to rewrite v: what is derived from v
+// after it cannot be hoisted in front of it.  The thread index is made opaque once per cell, the row of the 32 x 32 scans once per
+// scan, and the scans are unrolled by 8 (not 32: 32 64-bit LDS reads in flight were 64 registers by themselves): 125 / 128 vector
+// registers, NO scratch, 42 scalar spills left (kernel arguments parked in lanes of one vector register -- no memory behind them).
+#define SLP_OPAQUE(v) asm volatile("" : "+v"(v))
+// Sums along the lanes of a wave by DPP moves (vector ALU; `__shfl_up` is a ds_bpermute: the LDS pipe and its latency, six times
+// per scan).  dpp<CTRL, ROWS>(x): x of the lane CTRL names, 0 where there is none; lanes of the 16-lane rows not in ROWS get 0.
+// row_shr:n = 0x110 + n (n lanes to the left inside the row), row_bcast:15 = 0x142 (lane 15 of a row to every lane of the next row),
+// row_bcast:31 = 0x143 (lane 31 to the upper half).
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ unsigned int tall_dpp(unsigned int x) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xf, true);
+}
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ unsigned long long tall_dpp(unsigned long long x) {
+    return (unsigned long long)tall_dpp<CTRL, ROWS>((unsigned int)(x >> 32)) << 32 | tall_dpp<CTRL, ROWS>((unsigned int)x);
+}
+// inclusive sums over the lanes of a wave (SEG = 64) or of each half of it (SEG = 32)
+template <int SEG, typename U>
+__device__ __forceinline__ U tall_lane_sums(U x) {
+    x += tall_dpp<0x111>(x);
+    x += tall_dpp<0x112>(x);
+    x += tall_dpp<0x114>(x);
+    x += tall_dpp<0x118>(x);
+    x += tall_dpp<0x142, 0xa>(x);
+    if (SEG == 64) x += tall_dpp<0x143, 0xc>(x);
+    return x;
+}
+// block-wide exclusive scan of one word per thread; total in *tot
 __device__ __forceinline__ unsigned long long tall_block_scan(unsigned long long v, unsigned long long *wtot, unsigned long long *tot) {
-    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    unsigned long long inc = v;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const unsigned long long o = __shfl_up(inc, off, kWave);
-        if (lane >= off) inc += o;
-    }
+    int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    SLP_OPAQUE(w);  // (the sixteen `i < w` below are compared here, not once per kernel and kept in 32 scalar registers)
+    const unsigned long long inc = tall_lane_sums<kWave>(v);
     if (lane == kWave - 1) wtot[w] = inc;
     __syncthreads();
     unsigned long long base = 0, all = 0;
@@ -190,11 +218,10 @@ __device__ __forceinline__ void tall_scan_put(const TallScan &sc, i64 c, unsigne
     __hip_atomic_store(&sc.p[c], (level << 62) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned int tall_scan_get(const TallScan &sc, i64 c, unsigned long long *w, unsigned long long *k) {
-    for (;;) {
+    for (;;) {   // both words in flight together (each level of a cell is written once: equal levels = one writer's pair)
         const unsigned long long a = __hip_atomic_load(&sc.w[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!(a >> 62)) continue;
         const unsigned long long b = __hip_atomic_load(&sc.p[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((a >> 62) != (b >> 62)) continue;
+        if (!(a >> 62) || (a >> 62) != (b >> 62)) continue;
         *w = a & kScanMask;
         *k = b & kScanMask;
         return (unsigned int)(a >> 62);
@@ -221,14 +248,19 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
     __shared__ unsigned long long wtot[kTallT / kWave];
     __shared__ unsigned int width[kTallSlots];
     __shared__ unsigned int bcnt[kTallBuckets * 32], bstart[kTallBuckets * 32 + 1];  // (count, bank class) buckets
-    __shared__ unsigned long long cbuf[kTallT];  // scans over the 32 threads of a bank class
-    __shared__ unsigned int ccls[kTallT];   // demands of the 32 lanes of every bank class
-    __shared__ unsigned int spare1[32];     // one-entry rows of a bank class that no lane of the class takes
+    __shared__ unsigned long long cbuf[2 * 32 * 33], ctot[2 * 32];  // scans over the 32 threads of a bank class (two words per thread)
+    __shared__ unsigned int ccls[32 * 33], call[32];   // demands of the 32 lanes of every bank class
+    // one-entry rows of a bank class that no lane of the class takes, as sums: spare1x[r] = those of the classes before r, [32] = all
+    __shared__ unsigned int spare1x[33];
+    // rows of two or more entries, per count class k (counts 6 .. 2) and bank class r: lanes of the class without a row of their own
+    // in the classes before r (lackx), rows without a lane in the classes before r (sparex; [33 k + 32] = all)
+    __shared__ unsigned int lackx[(kTallBuckets - 1) * 32], sparex[(kTallBuckets - 1) * 33];
     __shared__ i64 s_cell;
     __shared__ unsigned long long s_before_w, s_before_p;
-    const int p = threadIdx.x;
     auto tile_of = [&](i64 t) -> unsigned int { return t >= 0 ? (unsigned int)(t << cshift) : kNoTile; };
     for (;;) {
+        int p = threadIdx.x;
+        SLP_OPAQUE(p);   // per cell: see REGISTERS above
         if (p == 0) {
             i64 c;
             for (;;) {  // the next cell with entries; a cell without takes part in the scan with sizes of zero
@@ -254,11 +286,24 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
         for (int r = p; r < R; r += kTallT) cnt[r] = 0;
         __syncthreads();
         SLP_TB_PROF(1);
-        for (int i = p; i < n; i += kTallT) {
-            const unsigned int r = (unsigned int)(keys[c0 + i] >> (kTallIdBits + kTallColBits)) & ((1u << kTallRowBits) - 1);
-            const unsigned int rp = i > 0 ? (unsigned int)(keys[c0 + i - 1] >> (kTallIdBits + kTallColBits)) & ((1u << kTallRowBits) - 1) : ~0u;
-            if (r != rp) rstart[r] = (unsigned int)i;
-            atomicAdd(&cnt[r], 1u);
+        for (int i0 = p; i0 < n; i0 += 4 * kTallT) {   // four rounds' keys in flight together (index clamped, use predicated)
+            unsigned long long ka[4], kb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * kTallT < n ? i0 + j * kTallT : n - 1;
+                ka[j] = keys[c0 + i];
+                kb[j] = keys[c0 + (i > 0 ? i - 1 : 0)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * kTallT;
+                if (i < n) {
+                    const unsigned int r = (unsigned int)(ka[j] >> (kTallIdBits + kTallColBits)) & ((1u << kTallRowBits) - 1);
+                    const unsigned int rp = i > 0 ? (unsigned int)(kb[j] >> (kTallIdBits + kTallColBits)) & ((1u << kTallRowBits) - 1) : ~0u;
+                    if (r != rp) rstart[r] = (unsigned int)i;
+                    atomicAdd(&cnt[r], 1u);
+                }
+            }
         }
         __syncthreads();
         SLP_TB_PROF(2);
@@ -270,18 +315,26 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
         const int crows = R > (int)(p & 31) ? (R - (int)(p & 31) + 31) / 32 : 0;  // rows of the class: rho + 32 m, m < crows
         const int mpl = ((R + 31) / 32 + 31) / 32;                                // consecutive m per thread
         const int m0 = (p >> 5) * mpl < crows ? (p >> 5) * mpl : crows, m1 = m0 + mpl < crows ? m0 + mpl : crows;
-        auto class_scan = [&](unsigned long long v, unsigned long long *tot) -> unsigned long long {
-            cbuf[(p >> 5) * 32 + (p & 31)] = v;
+        // both words of a thread in one scan (v[0], v[1] -> exclusive sums; tot[0], tot[1] the class's totals)
+        // Through LDS TRANSPOSED (pairs at (class, thread of the class), rows of 33 pairs): thread p picks up the pair of thread
+        // p % 32 of class p / 32, so the 32 threads of a class sit in the 32 lanes of half a wave and the scan is lane sums; the
+        // exclusive sums go back the same way.  (Rounds 3-6a: every thread read all 32 pairs of its class -- 512 KB through the LDS
+        // pipe per scan, 1.7 of a cell's 24 us.)
+        auto class_scan2 = [&](unsigned long long *v, unsigned long long *tot) {
+            const int mine = 2 * ((p & 31) * 33 + (p >> 5)), theirs = 2 * ((p >> 5) * 33 + (p & 31));
+            cbuf[mine] = v[0];
+            cbuf[mine + 1] = v[1];
             __syncthreads();
-            unsigned long long ex = 0, all = 0;
-            for (int i = 0; i < 32; ++i) {
-                const unsigned long long u = cbuf[i * 32 + (p & 31)];
-                if (i < (p >> 5)) ex += u;
-                all += u;
-            }
+            const unsigned long long u0 = cbuf[theirs], u1 = cbuf[theirs + 1];
+            const unsigned long long s0 = tall_lane_sums<32>(u0), s1 = tall_lane_sums<32>(u1);
+            cbuf[theirs] = s0 - u0;
+            cbuf[theirs + 1] = s1 - u1;
+            if ((p & 31) == 31) { ctot[2 * (p >> 5)] = s0; ctot[2 * (p >> 5) + 1] = s1; }
             __syncthreads();
-            *tot = all;
-            return ex;
+            v[0] = cbuf[mine];
+            v[1] = cbuf[mine + 1];
+            tot[0] = ctot[2 * (p & 31)];
+            tot[1] = ctot[2 * (p & 31) + 1];
         };
         unsigned long long ha = 0, hb = 0;  // counters of the counts 6,5,4 (21 bits each) / 3,2,1
         for (int m = m0; m < m1; ++m) {
@@ -292,8 +345,10 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
                 else hb += 1ull << (21 * (3 - cl));
             }
         }
-        unsigned long long ta, tb;
-        unsigned long long ea = class_scan(ha, &ta), eb = class_scan(hb, &tb);
+        unsigned long long hv[2] = {ha, hb}, tv[2];
+        class_scan2(hv, tv);
+        unsigned long long ea = hv[0], eb = hv[1];
+        const unsigned long long ta = tv[0], tb = tv[1];
         if (p < 32)
             for (int cl = kTallBuckets; cl >= 1; --cl)
                 bcnt[(kTallBuckets - cl) * 32 + p] = (unsigned int)(((cl > 3 ? ta : tb) >> (21 * ((cl > 3 ? kTallBuckets : 3) - cl))) & 0x1fffffu);
@@ -315,6 +370,20 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
         }
         __syncthreads();
         SLP_TB_PROF(4);
+        // Lanes [S, E) of a count class take its rows: a lane one of its own bank class as far as those last.  Which rows the lanes
+        // without one get is settled by two sums over the bank classes (lane sums inside the 32 lanes of a count class) instead of
+        // every such lane walking the 32 classes twice (64 dependent LDS reads a wave: 4 of the 31 us a cell took).
+        if (p < (kTallBuckets - 1) * 32) {
+            const unsigned int k = (unsigned)p >> 5, r = (unsigned)p & 31u;
+            const unsigned int S = bstart[k * 32], E = bstart[k * 32 + 32];
+            const unsigned int first = S + ((r + 32u - (S & 31u)) & 31u), nl = first < E ? (E - first + 31u) / 32u : 0u;
+            const unsigned int rr = bstart[k * 32 + r + 1] - bstart[k * 32 + r];
+            const unsigned int lack = nl > rr ? nl - rr : 0u, spare = rr > nl ? rr - nl : 0u;
+            const unsigned int il = tall_lane_sums<32>(lack), is = tall_lane_sums<32>(spare);
+            lackx[k * 32 + r] = il - lack;
+            sparex[k * 33 + r] = is - spare;
+            if (r == 31u) sparex[k * 33 + 32] = is;
+        }
         for (int m = m0; m < m1; ++m) {
             const unsigned int r = (unsigned int)((p & 31) + 32 * m), c = cnt[r];
             if (c) {
@@ -354,14 +423,14 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
                 if (i < nr) {
                     pos0 = bs[rho] + i;  // a row of the lane's own bank class
                 } else {                 // the u-th lane without one takes the u-th row without a lane
-                    unsigned int u = i - nr;
-                    #pragma nounroll
-                    for (unsigned int r = 0; r < rho; ++r) { const unsigned int nl = lanes_of(r), rr = bs[r + 1] - bs[r]; u += nl > rr ? nl - rr : 0u; }
-                    #pragma nounroll
-                    for (unsigned int r = 0; r < 32u; ++r) {
-                        const unsigned int nl = lanes_of(r), rr = bs[r + 1] - bs[r], spare = rr > nl ? rr - nl : 0u;
-                        if (u < spare) { pos0 = bs[r] + nl + u; break; }
-                        u -= spare;
+                    const unsigned int k = (unsigned)(kTallBuckets - cl);
+                    const unsigned int u = i - nr + lackx[k * 32 + rho];
+                    const unsigned int *sx = sparex + k * 33;
+                    if (u < sx[32]) {
+                        unsigned int lo = 0, hi = 32;   // the class r with sx[r] <= u < sx[r + 1]
+#pragma unroll
+                        for (int it = 0; it < 5; ++it) { const unsigned int mid = (lo + hi) >> 1; if (sx[mid] <= u) lo = mid; else hi = mid; }
+                        pos0 = bs[lo] + lanes_of(lo) + (u - sx[lo]);
                     }
                 }
                 c0p = cnt[posrow[pos0]];
@@ -382,21 +451,31 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
             // from 3983 items), 20 % where lists are 5 long.
             const unsigned int tau = (unsigned)n / kTallT + ((unsigned)p < (unsigned)n % kTallT ? 1u : 0u);
             const unsigned int want = (fill && c0p < tau) ? tau - c0p : 0u;
-            ccls[(p >> 5) * 32 + rho] = want;
+            ccls[rho * 33 + (p >> 5)] = want;   // (transposed as in class_scan2: the class's 32 demands in the lanes of half a wave)
             __syncthreads();
-            unsigned int before = 0, all = 0;
-            for (int i = 0; i < 32; ++i) { const unsigned int v = ccls[i * 32 + rho]; if (i < (p >> 5)) before += v; all += v; }
+            {
+                const int theirs = (p >> 5) * 33 + (int)rho;
+                const unsigned int u = ccls[theirs], su = tall_lane_sums<32>(u);
+                ccls[theirs] = su - u;
+                if (rho == 31u) call[p >> 5] = su;
+            }
+            __syncthreads();
+            const unsigned int before = ccls[rho * 33 + (p >> 5)], all = call[rho];
             const unsigned int n1 = b1[rho + 1] - b1[rho];
             own0 = b1[rho] + before;
             nown = before >= n1 ? 0u : (want < n1 - before ? want : n1 - before);
-            if (p < 32) spare1[p] = n1 > all ? n1 - all : 0u;  // rows of the class nobody of the class takes
+            if (p < 32) {   // rows of the class nobody of the class takes, summed over the classes before it
+                const unsigned int sp = n1 > all ? n1 - all : 0u;
+                const unsigned int is = tall_lane_sums<32>(sp);
+                spare1x[p] = is - sp;
+                if (p == 31) spare1x[32] = is;
+            }
             __syncthreads();
             SLP_TB_PROF(6);
             // ... then, for what is still missing, the rows left over in other classes: in lane order
             unsigned long long total;
             left0 = (unsigned int)tall_block_scan(want - nown, wtot, &total);
-            unsigned int nspare = 0;
-            for (int r = 0; r < 32; ++r) nspare += spare1[r];
+            const unsigned int nspare = spare1x[32];
             nleft = left0 >= nspare ? 0u : (want - nown < nspare - left0 ? want - nown : nspare - left0);
             if (fill) mine += nown + nleft;
             else for (unsigned int pos = p + kTallT; pos < npos; pos += kTallT) mine += cnt[posrow[pos]];
@@ -409,13 +488,11 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
             q -= nown;
             if (q >= nleft) return npos;
             const unsigned int *b1 = bstart + (kTallBuckets - 1) * 32;
-            unsigned int u = left0 + q;
-            #pragma nounroll
-            for (unsigned int r = 0; r < 32u; ++r) {
-                if (u < spare1[r]) return b1[r + 1] - spare1[r] + u;
-                u -= spare1[r];
-            }
-            return npos;
+            const unsigned int u = left0 + q;   // (< spare1x[32]: q < nleft)
+            unsigned int lo = 0, hi = 32;       // the class r with spare1x[r] <= u < spare1x[r + 1]
+#pragma unroll
+            for (int it = 0; it < 5; ++it) { const unsigned int mid = (lo + hi) >> 1; if (spare1x[mid] <= u) lo = mid; else hi = mid; }
+            return b1[lo + 1] - (spare1x[lo + 1] - spare1x[lo]) + (u - spare1x[lo]);
         };
         // List lengths are non-increasing in p up to a few exceptions (rows with >= 6 entries in bucket order; the lanes
         // that find no one-entry row left).  Slot widths therefore come from the non-increasing envelope cover[p] = max over
@@ -438,18 +515,22 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
             __syncthreads();
         }
         nlane[p] = cover;
-        __syncthreads();
-        SLP_TB_PROF(7);
-        const unsigned int longest = nlane[0];
         // The cell's sizes from the envelope alone: slot k is as wide as the lanes whose envelope exceeds k, so the slots of all
         // packets hold sum_p cover[p] words; the fifth bytes take a word per lane of slot 8 g and of slot 8 g + 4 of every packet g.
-        // A cell's payload is rounded up to 16 bytes (every stream then starts 16-byte aligned).
-        unsigned long long cw;
+        // A cell's payload is rounded up to 16 bytes (every stream then starts 16-byte aligned).  (The waves' sums cross the same
+        // barrier as the envelope itself.)
+        unsigned long long cw = 0;
         {
             unsigned long long w = cover;
             if (DICT) w += (cover + 7u) / 8u + (cover > 4u ? (cover - 4u + 7u) / 8u : 0u);
-            (void)tall_block_scan(w, wtot, &cw);
+            w = tall_lane_sums<kWave>(w);
+            if ((p & (kWave - 1)) == kWave - 1) wtot[p / kWave] = w;
         }
+        __syncthreads();
+        SLP_TB_PROF(7);
+        const unsigned int longest = nlane[0];
+        const unsigned int nxt = p + 1 < kTallT ? nlane[p + 1] : 0u;   // the envelope of the lane to the right
+        for (int i = 0; i < kTallT / kWave; ++i) cw += wtot[i];
         const unsigned long long cell_w = (cw + 3ull) & ~3ull, cell_p = longest ? (longest + kTallSlots - 1) / kTallSlots : 1u;
         if (p == 0) tall_scan_put(sc, cell, 1ull, cell_w, cell_p);  // the cell's sizes stand: later cells need not wait for more
         bool fits = true;
@@ -461,16 +542,14 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
         unsigned int q = 0, s = 0, mypos = rowpos(0);
         unsigned int myrow = mypos < npos ? posrow[mypos] : 0u, mycnt = mypos < npos ? cnt[myrow] : 0u;
         for (unsigned int g = 0; g * kTallSlots < longest || g == 0; ++g) {
-            // slot widths of this packet: width[j] = first lane whose envelope is <= 8 g + j (binary search, lanes 0..7)
-            if (p < kTallSlots) {
-                const unsigned int k = g * kTallSlots + p;
-                int lo = 0, hi = kTallT;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (nlane[mid] > k) lo = mid + 1;
-                    else hi = mid;
-                }
-                width[p] = (unsigned int)lo;
+            // slot widths of this packet: width[j] = first lane whose envelope is <= 8 g + j = the lanes whose envelope exceeds it
+            // (non-increasing).  Written by the lane at the step: the last one above 8 g + j -- or by lane 0 when there is none.
+            // (Rounds 3-5: a binary search over nlane[] by lanes 0..7, ten dependent LDS reads with 1016 lanes waiting.)
+#pragma unroll
+            for (int j = 0; j < kTallSlots; ++j) {
+                const unsigned int k = g * kTallSlots + j;
+                if (nxt <= k && k < cover) width[j] = (unsigned int)p + 1u;
+                if (p == 0 && cover <= k) width[j] = 0u;
             }
             __syncthreads();
             SLP_TB_PROF(8);
