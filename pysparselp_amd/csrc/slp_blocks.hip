@@ -341,6 +341,10 @@ struct slp_blocks {
     DevBuf<double> xsol, zero_m;
     bool precond = false;     // Jacobi-preconditioned CG (slp_blocks_set_precond); dinv = 1 / diag(S), z = preconditioned residual
     DevBuf<double> dinv, z;
+    // the conjugate-gradient loop as begin / rounds (blk_cg_begin, blk_cg_round): the blocks of a group take their rounds in turn,
+    // each on a stream of its own (slp_blocks_group_iterate)
+    struct { i64 m = 0; double *sol = nullptr; bool pc = false; int it = 0; } cg;
+    bool warmed = false;      // has run a projection on the library's stream (slp_blocks_group_iterate)
 };
 
 namespace slp {
@@ -358,9 +362,10 @@ static void blk_apply(slp_blocks *s, const double *dir, double *q) {
     matrix_spmv(s->a, false, s->u.p, q, SLP_ORDER_AUTO);
 }
 
-// the conjugate-gradient loop shared by both layouts; `apply(dir, q)` computes q = S dir
-template <class Apply>
-static void blk_cg(slp_blocks *s, Apply apply, i64 len = -1, double *sol = nullptr) {
+// the conjugate-gradient loop shared by both layouts; `apply(dir, q)` computes q = S dir.  In two pieces: blk_cg_begin (the first
+// inner products) and blk_cg_round (the stopping test on the scalars of the steps so far -- one 64-byte read -- then `check_every`
+// more steps enqueued; true once the test says stop or the step limit is reached).  blk_cg runs them to the end.
+static void blk_cg_begin(slp_blocks *s, i64 len = -1, double *sol = nullptr) {
     hipStream_t st = ctx().stream;
     const i64 m = len < 0 ? s->m : len;   // length of the system (rows: dual form; original variables: primal form)
     if (!sol) sol = s->nu.p;
@@ -375,57 +380,100 @@ static void blk_cg(slp_blocks *s, Apply apply, i64 len = -1, double *sol = nullp
     } else {
         blk_dot(s, m, s->r.p, s->r.p, B_RS, 0);
     }
+    s->cg.m = m; s->cg.sol = sol; s->cg.pc = pc; s->cg.it = 0;
+}
+
+template <class Apply>
+static bool blk_cg_round(slp_blocks *s, Apply apply, bool may_capture = true) {
+    hipStream_t st = ctx().stream;
+    const i64 m = s->cg.m;
+    double *sol = s->cg.sol;
+    const bool pc = s->cg.pc;
+    const int gm = grid_for(m, kBlock);
+    if (s->cg.it >= s->max_cg) return true;
     double h[B_COUNT];
-    for (int it = 0; it < s->max_cg;) {
-        s->scal.download(h, B_COUNT);  // one 64-byte read every `check_every` steps
-        if (!(h[pc ? B_RR : B_RS] > s->tol * s->tol * h[B_RHS2])) break;
-        auto step = [&]() {
-            apply(s->dir.p, s->q.p);
-            blk_dot(s, m, s->dir.p, s->q.p, B_PQ, 1);
-            hipLaunchKernelGGL(k_blk_step, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->dir.p, s->q.p, sol, s->r.p);
-            if (pc) {
-                hipLaunchKernelGGL(k_blk_precond, dim3(gm), dim3(kBlock), 0, st, m, s->dinv.p, s->r.p, s->z.p);
-                blk_dot(s, m, s->r.p, s->z.p, B_RSNEW, 2);
-                blk_dot(s, m, s->r.p, s->r.p, B_RR, 0);
-                hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->z.p, s->dir.p);
-            } else {
-                blk_dot(s, m, s->r.p, s->r.p, B_RSNEW, 2);
-                hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->r.p, s->dir.p);
-            }
-        };
-        const int chunk = std::min(s->check_every, s->max_cg - it);
-        // all kernel arguments are fixed pointers.  Not while an asynchronous RCCL all-reduce of the previous block is in flight: what
-        // the library's own threads call meanwhile is not ours to order against an open capture (see capture_mutex, slp_common.h)
-        if (s->a->a.nnz <= 20000000 && !comm_library_collective_pending()) s->cg_graph.run(chunk, s->check_every, step);
-        else for (int k = 0; k < chunk; ++k) step();
-        it += chunk;
-        s->cg_steps += chunk;
-    }
+    s->scal.download(h, B_COUNT);  // one 64-byte read every `check_every` steps
+    if (!(h[pc ? B_RR : B_RS] > s->tol * s->tol * h[B_RHS2])) return true;
+    auto step = [&]() {
+        apply(s->dir.p, s->q.p);
+        blk_dot(s, m, s->dir.p, s->q.p, B_PQ, 1);
+        hipLaunchKernelGGL(k_blk_step, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->dir.p, s->q.p, sol, s->r.p);
+        if (pc) {
+            hipLaunchKernelGGL(k_blk_precond, dim3(gm), dim3(kBlock), 0, st, m, s->dinv.p, s->r.p, s->z.p);
+            blk_dot(s, m, s->r.p, s->z.p, B_RSNEW, 2);
+            blk_dot(s, m, s->r.p, s->r.p, B_RR, 0);
+            hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->z.p, s->dir.p);
+        } else {
+            blk_dot(s, m, s->r.p, s->r.p, B_RSNEW, 2);
+            hipLaunchKernelGGL(k_blk_dir, dim3(gm), dim3(kBlock), 0, st, m, s->scal.p, s->r.p, s->dir.p);
+        }
+    };
+    const int chunk = std::min(s->check_every, s->max_cg - s->cg.it);
+    // all kernel arguments are fixed pointers.  Not while an asynchronous RCCL all-reduce of the previous block is in flight: what
+    // the library's own threads call meanwhile is not ours to order against an open capture (see capture_mutex, slp_common.h);
+    // not on a group's side streams either (the graph was captured on the library's stream)
+    if (may_capture && s->a->a.nnz <= 20000000 && !comm_library_collective_pending()) s->cg_graph.run(chunk, s->check_every, step);
+    else for (int k = 0; k < chunk; ++k) step();
+    s->cg.it += chunk;
+    s->cg_steps += chunk;
+    return false;
+}
+
+template <class Apply>
+static void blk_cg(slp_blocks *s, Apply apply, i64 len = -1, double *sol = nullptr) {
+    blk_cg_begin(s, len, sol);
+    while (!blk_cg_round(s, apply)) {}
 }
 
 // One block's share of an iteration up to the exchange: its projection (matrix-free CG, no exchange inside), the
 // over-relaxed x, the slack update and the consensus summand acc_j = used_j ? x_j + lambda_j / gamma : 0.
-static void rb_project(slp_blocks *s) {
+// In three pieces (begin / rounds of conjugate-gradient steps / end) so that the blocks of a group can take their rounds in turn
+// on streams of their own; rb_project runs them back to back on the library's stream.
+static void rb_apply_dual(slp_blocks *s, const double *dir, double *q) {   // q = (A A^T + [0; I]) dir
+    blk_apply(s, dir, q);
+    if (s->m > s->m_eq)
+        hipLaunchKernelGGL(k_rb_add_identity, dim3(grid_for(s->m - s->m_eq, kBlock)), dim3(kBlock), 0, ctx().stream, s->m, s->m_eq, dir, q);
+}
+static void rb_apply_primal(slp_blocks *s, const double *dir, double *q) {  // q = dir + A^T (A dir)
+    matrix_spmv(s->a, false, dir, s->w.p, SLP_ORDER_AUTO);
+    matrix_spmv(s->a, true, s->w.p, q, SLP_ORDER_AUTO);
+    hipLaunchKernelGGL(k_rb_add_vec, dim3(grid_for(s->N, kBlock)), dim3(kBlock), 0, ctx().stream, s->N, dir, q);
+}
+
+static void rb_project_begin(slp_blocks *s) {
     hipStream_t st = ctx().stream;
     const i64 n = s->N, m = s->m, me = s->m_eq;
     const int gn = grid_for(n, kBlock), gm = grid_for(m, kBlock);
-    auto apply = [&](const double *dir, double *q) {
-        blk_apply(s, dir, q);
-        if (m > me) hipLaunchKernelGGL(k_rb_add_identity, dim3(grid_for(m - me, kBlock)), dim3(kBlock), 0, st, m, me, dir, q);
-    };
     hipLaunchKernelGGL(k_rb_v, dim3(gn), dim3(kBlock), 0, st, n, s->xp.p, s->lam.p, s->gamma, s->v.p);
     if (s->primal) {
-        auto apply_p = [&](const double *dir, double *q) {  // q = dir + A^T (A dir)
-            matrix_spmv(s->a, false, dir, s->w.p, SLP_ORDER_AUTO);
-            matrix_spmv(s->a, true, s->w.p, q, SLP_ORDER_AUTO);
-            hipLaunchKernelGGL(k_rb_add_vec, dim3(gn), dim3(kBlock), 0, st, n, dir, q);
-        };
         hipLaunchKernelGGL(k_rb_vs, dim3(gm), dim3(kBlock), 0, st, m, s->xps.p, s->lams.p, s->gamma, s->vs.p);
         matrix_spmv(s->a, true, s->vs.p, s->u.p, SLP_ORDER_AUTO);
         matrix_spmv(s->a, false, s->xsol.p, s->w.p, SLP_ORDER_AUTO);
         matrix_spmv(s->a, true, s->w.p, s->q.p, SLP_ORDER_AUTO);
         hipLaunchKernelGGL(k_rb_resid0_primal, dim3(gn), dim3(kBlock), 0, st, n, s->v.p, s->u.p, s->xsol.p, s->q.p, s->r.p, s->dir.p, s->rhs.p);
-        blk_cg(s, apply_p, n, s->xsol.p);
+        blk_cg_begin(s, n, s->xsol.p);
+    } else if (m > 0) {
+        matrix_spmv(s->a, false, s->v.p, s->w.p, SLP_ORDER_AUTO);
+        blk_apply(s, s->nu.p, s->q.p);
+        hipLaunchKernelGGL(k_rb_resid0, dim3(gm), dim3(kBlock), 0, st, m, me, s->w.p, s->b.p, s->q.p, s->nu.p, s->xps.p, s->lams.p, s->gamma,
+                           s->vs.p, s->r.p, s->dir.p, s->rhs.p);
+        blk_cg_begin(s);
+    }
+    SLP_HIP(hipGetLastError());
+}
+
+// the next `check_every` conjugate-gradient steps of the block's projection; true when it has none left
+static bool rb_project_round(slp_blocks *s, bool may_capture = true) {
+    if (s->primal) return blk_cg_round(s, [&](const double *dir, double *q) { rb_apply_primal(s, dir, q); }, may_capture);
+    if (s->m > 0) return blk_cg_round(s, [&](const double *dir, double *q) { rb_apply_dual(s, dir, q); }, may_capture);
+    return true;
+}
+
+static void rb_project_end(slp_blocks *s) {
+    hipStream_t st = ctx().stream;
+    const i64 n = s->N, m = s->m, me = s->m_eq;
+    const int gn = grid_for(n, kBlock), gm = grid_for(m, kBlock);
+    if (s->primal) {
         matrix_spmv(s->a, false, s->xsol.p, s->w.p, SLP_ORDER_AUTO);  // the projected slacks s = A x
         hipLaunchKernelGGL(k_rb_x_primal, dim3(gn), dim3(kBlock), 0, st, n, s->used.p, s->xp.p, s->xsol.p, s->lam.p, s->alpha, 1.0 - s->alpha,
                            s->gamma, s->x.p, s->acc.p);
@@ -434,22 +482,20 @@ static void rb_project(slp_blocks *s) {
         SLP_HIP(hipGetLastError());
         return;
     }
-    if (m > 0) {
-        matrix_spmv(s->a, false, s->v.p, s->w.p, SLP_ORDER_AUTO);
-        blk_apply(s, s->nu.p, s->q.p);
-        hipLaunchKernelGGL(k_rb_resid0, dim3(gm), dim3(kBlock), 0, st, m, me, s->w.p, s->b.p, s->q.p, s->nu.p, s->xps.p, s->lams.p, s->gamma,
-                           s->vs.p, s->r.p, s->dir.p, s->rhs.p);
-        blk_cg(s, apply);
-        matrix_spmv(s->a, true, s->nu.p, s->u.p, SLP_ORDER_AUTO);
-    } else {
-        s->u.zero();
-    }
+    if (m > 0) matrix_spmv(s->a, true, s->nu.p, s->u.p, SLP_ORDER_AUTO);
+    else s->u.zero();
     hipLaunchKernelGGL(k_rb_x, dim3(gn), dim3(kBlock), 0, st, n, s->used.p, s->xp.p, s->v.p, s->u.p, s->lam.p, s->alpha, 1.0 - s->alpha,
                        s->gamma, s->x.p, s->acc.p);
     if (m > me)
         hipLaunchKernelGGL(k_rb_slack, dim3(grid_for(m - me, kBlock)), dim3(kBlock), 0, st, m, me, s->vs.p, s->nu.p, s->slo.p, s->shi.p,
                            s->alpha, 1.0 - s->alpha, s->gamma, s->xs.p, s->xps.p, s->lams.p);
     SLP_HIP(hipGetLastError());
+}
+
+static void rb_project(slp_blocks *s) {
+    rb_project_begin(s);
+    while (!rb_project_round(s)) {}
+    rb_project_end(s);
 }
 
 // ... and after it: xp = clamp((sum of the summands over every block of every rank - c / gamma) / copies), this block's lambda
@@ -710,12 +756,83 @@ int slp_blocks_group_link(slp_blocks **blocks, int count) {
     })
 }
 
+// The blocks' projections of ONE rank side by side (round 6; VERDICT r05 #5: "one grid over the eight blocks' products").  The
+// blocks are independent inside an iteration (ADMMBlocks.py:264-307), but each projection is a chain of ~40 products with a
+// stopping test on the host every `check_every` steps, and a product of config 5's shape is ONE round of 255 workgroups on 256
+// compute units: block after block every launch ends at its slowest workgroup.  Here every block has a stream of its own and the
+// blocks take their rounds of conjugate-gradient steps in turn (begin all; round-robin: read a block's scalars, test, enqueue its
+// next `check_every` steps; end): the queues hold several blocks' products at once and a compute unit that finishes its workgroup
+// of one block starts one of the next -- what a batched grid would do, without rewriting the loop around per-block scalars in
+// device memory.  Every block's arithmetic is what it was (same kernels, same order on its stream): results bit for bit, step
+// counts equal.  Not under a communicator (there the blocks' all-reduces overlap the next block's projection instead), not for
+// launch-bound blocks (their steps replay a graph captured on the library's stream), and not for a group's first iteration
+// (whatever a block builds lazily is built on the library's stream, where the caching allocator's stream order holds).
+// SLP_BLOCKS_STREAMS=0 / 1: never / also for small blocks (tests).
+static std::vector<hipStream_t> g_blk_streams;
+static std::vector<hipEvent_t> g_blk_events;   // [count] = the library's stream at the start of the iteration
+static bool blocks_side_by_side(slp_blocks **blocks, int count) {
+    if (count < 2 || blocks[0]->distributed) return false;
+    for (int g = 0; g < count; ++g)
+        if (!blocks[g]->warmed) return false;
+    const char *e = getenv("SLP_BLOCKS_STREAMS");
+    if (e && e[0]) return e[0] != '0';
+    for (int g = 0; g < count; ++g)
+        if (blocks[g]->a->a.nnz <= 20000000) return false;
+    return true;
+}
+static void blocks_project_side_by_side(slp_blocks **blocks, int count) {
+    hipStream_t main_stream = ctx().stream;
+    while ((int)g_blk_streams.size() < count) {
+        hipStream_t st = nullptr;
+        SLP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        g_blk_streams.push_back(st);
+    }
+    while ((int)g_blk_events.size() < count + 1) {
+        hipEvent_t ev = nullptr;
+        SLP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g_blk_events.push_back(ev);
+    }
+    SLP_HIP(hipEventRecord(g_blk_events[count], main_stream));
+    try {
+        for (int g = 0; g < count; ++g) {
+            ctx().stream = g_blk_streams[g];
+            SLP_HIP(hipStreamWaitEvent(g_blk_streams[g], g_blk_events[count], 0));
+            rb_project_begin(blocks[g]);
+        }
+        std::vector<char> active((size_t)count, 1);
+        for (int left = count; left > 0;)
+            for (int g = 0; g < count; ++g) {
+                if (!active[g]) continue;
+                ctx().stream = g_blk_streams[g];
+                if (!rb_project_round(blocks[g], false)) continue;
+                rb_project_end(blocks[g]);
+                SLP_HIP(hipEventRecord(g_blk_events[g], g_blk_streams[g]));
+                active[g] = 0;
+                --left;
+            }
+    } catch (...) {
+        ctx().stream = main_stream;
+        for (int g = 0; g < count; ++g) (void)hipStreamSynchronize(g_blk_streams[g]);   // nothing of the blocks may still run when the error unwinds
+        throw;
+    }
+    ctx().stream = main_stream;
+    for (int g = 0; g < count; ++g) SLP_HIP(hipStreamWaitEvent(main_stream, g_blk_events[g], 0));
+}
+
 int slp_blocks_group_iterate(slp_blocks **blocks, int count, int64_t k) {
     SLP_API_INT({
         SLP_REQUIRE(blocks && count >= 1 && k >= 0, "slp_blocks_group_iterate: bad arguments");
         slp_blocks *s0 = blocks[0];
         const i64 n = s0->N;
         for (i64 it = 0; it < k; ++it) {
+            if (blocks_side_by_side(blocks, count)) {
+                blocks_project_side_by_side(blocks, count);
+                for (int g = 1; g < count; ++g)  // fixed order: deterministic sums
+                    hipLaunchKernelGGL(k_rb_accumulate, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, ctx().stream, n, blocks[g]->acc.p, s0->acc.p);
+                SLP_HIP(hipGetLastError());
+                for (int g = 0; g < count; ++g) rb_consensus(blocks[g], s0->acc.p);
+                continue;
+            }
             // Asynchronous block updates: as soon as a block's summand exists its all-reduce starts on the second stream and
             // travels over xGMI while the NEXT block's projection computes; only the last block's exchange is exposed.
             // (One rank, or one block: a single all-reduce of the sum, as before.)
@@ -723,6 +840,7 @@ int slp_blocks_group_iterate(slp_blocks **blocks, int count, int64_t k) {
             try {
                 for (int g = 0; g < count; ++g) {
                     rb_project(blocks[g]);
+                    blocks[g]->warmed = true;
                     if (overlap) comm_allreduce_dev_async(blocks[g]->acc.p, n, 0);
                 }
             } catch (...) {

@@ -255,34 +255,57 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
     // rows of two or more entries, per count class k (counts 6 .. 2) and bank class r: lanes of the class without a row of their own
     // in the classes before r (lackx), rows without a lane in the classes before r (sparex; [33 k + 32] = all)
     __shared__ unsigned int lackx[(kTallBuckets - 1) * 32], sparex[(kTallBuckets - 1) * 33];
-    __shared__ i64 s_cell;
+    __shared__ i64 s_cell, s_c0, s_tn;   // the workgroup's next cell, where its keys start, the strip after it (take_next)
+    __shared__ int s_n;
+    __shared__ unsigned int s_dump[kTallT];   // where the touches of the next cell's keys land (never read)
     __shared__ unsigned long long s_before_w, s_before_p;
     auto tile_of = [&](i64 t) -> unsigned int { return t >= 0 ? (unsigned int)(t << cshift) : kNoTile; };
+    // The workgroup's NEXT cell, by one thread: the ticket (a cell without entries takes part in the scan with sizes of zero and
+    // the next ticket is drawn), where the cell's keys lie, and the next strip of its stream with entries in the row block (its
+    // x-tile rides on this cell's first packet).  cell = (row block b, strip t); the stream it belongs to: strip range sr of S
+    // (S > 1: few, tall row blocks whose strips are shared by S workgroups of the product kernel -- see tall_geometry).
+    // Rounds 3-6a: drawn by thread 0 at the top of a cell with 1023 threads waiting, then every thread read cellptr[] itself
+    // (3 dependent round trips to L2 in front of a cell's first key: 2 of its 19 us).  Now thread 64 draws it while wave 0 sums the
+    // sizes of the cells before the current one, and the workgroup touches the next cell's keys (one dword per 128 bytes) while it
+    // stores the current cell's packets: the first real read of a key finds it in L2.
+    // (The ticket itself is drawn two barriers earlier -- `drawn` -- so that its round trip is over when take_next runs; the
+    // three cellptr[] entries a cell usually needs are fetched together.)
+    auto take_next = [&](unsigned long long drawn) {
+        i64 c = (i64)drawn, lo = 0, hi = 0, hi2 = 0;
+        for (;;) {
+            if (c >= ncell) break;
+            lo = cellptr[c];
+            hi = cellptr[c + 1];
+            hi2 = cellptr[c + 1 < ncell ? c + 2 : c + 1];
+            if (hi > lo) break;
+            tall_scan_put(sc, c, 1ull, 0ull, 0ull);
+            c = (i64)atomicAdd(sc.ticket, 1ull);
+        }
+        s_cell = c;
+        if (c < ncell) {
+            const i64 b = c / T, t = c % T;
+            const i64 t_end = S > 1 ? T * (tall_range_of(t, T, S) + 1) / S : T;
+            i64 tn = -1;
+            if (t + 1 < t_end && hi2 > hi) tn = t + 1;   // (cell c + 1 is strip t + 1 of the same row block)
+            else
+                for (i64 u = t + 2; u < t_end; ++u)
+                    if (cellptr[b * T + u + 1] > cellptr[b * T + u]) { tn = u; break; }
+            s_tn = tn;
+            s_c0 = lo;
+            s_n = (int)(hi - lo);
+        }
+    };
+    if (threadIdx.x == kWave) take_next(atomicAdd(sc.ticket, 1ull));
     for (;;) {
         int p = threadIdx.x;
         SLP_OPAQUE(p);   // per cell: see REGISTERS above
-        if (p == 0) {
-            i64 c;
-            for (;;) {  // the next cell with entries; a cell without takes part in the scan with sizes of zero
-                c = (i64)atomicAdd(sc.ticket, 1ull);
-                if (c >= ncell || cellptr[c + 1] > cellptr[c]) break;
-                tall_scan_put(sc, c, 1ull, 0ull, 0ull);
-            }
-            s_cell = c;
-        }
         __syncthreads();
         SLP_TB_PROF(0);
         const i64 cell = s_cell;
         if (cell >= ncell) break;
-        // cell = (row block b, strip t); the packet stream it belongs to: strip range sr of S (S > 1: few, tall row blocks whose
-        // strips are shared by S workgroups of the product kernel -- see tall_geometry)
-        const i64 b = cell / T, t = cell % T;
-        const i64 t_end = S > 1 ? T * (tall_range_of(t, T, S) + 1) / S : T;
-        i64 tn = -1;  // next strip of the stream with entries in the row block: its x-tile rides on this cell's first packet
-        for (i64 u = t + 1; u < t_end; ++u)
-            if (cellptr[b * T + u + 1] > cellptr[b * T + u]) { tn = u; break; }
-        const i64 c0 = cellptr[cell];
-        const int n = (int)(cellptr[cell + 1] - c0);
+        const i64 t = cell % T, tn = s_tn, c0 = s_c0;
+        const int n = s_n;
+        unsigned long long drawn = 0;
         for (int r = p; r < R; r += kTallT) cnt[r] = 0;
         __syncthreads();
         SLP_TB_PROF(1);
@@ -472,6 +495,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
             }
             __syncthreads();
             SLP_TB_PROF(6);
+            if (p == kWave) drawn = atomicAdd(sc.ticket, 1ull);   // the workgroup's next ticket: used by take_next below
             // ... then, for what is still missing, the rows left over in other classes: in lane order
             unsigned long long total;
             left0 = (unsigned int)tall_block_scan(want - nown, wtot, &total);
@@ -587,6 +611,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
             if (g == 0) {
                 // Where the cell's packets go: the sizes of all cells before it, summed backwards by one wave from the cells' own
                 // sizes until a cell with its sums is met (behind the loads above: their latency and the look-back's overlap).
+                if (p == kWave) take_next(drawn);   // (beside wave 0's look-back: after the barrier below everybody has the next cell)
                 if (p < kWave) {
                     unsigned long long bw = 0, bp = 0;
                     for (i64 j = cell - 1; j >= 0; j -= kWave) {
@@ -612,6 +637,16 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
                 }
                 __syncthreads();
                 SLP_TB_PROF(9);
+                // touch the next cell's keys: one dword per 128 bytes, loaded straight into an LDS area nobody reads (no register
+                // waits for it; as a load into a register it had to be waited for at the top of the next cell -- together with
+                // every packet store before it, which nothing waits for otherwise)
+                if (s_cell < ncell && p * 16 < s_n) {
+                    const unsigned int *g = reinterpret_cast<const unsigned int *>(keys + s_c0) + p * 32;
+                    const unsigned int lds = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)(s_dump + (p & ~(kWave - 1))));
+                    unsigned int m0_saved;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(m0_saved) : "s"(lds), "v"(g) : "memory");
+                }
                 fits = (i64)(s_before_w + cell_w) <= cap_w && (i64)(s_before_p + cell_p) <= cap_p;  // uniform
                 pay = spay + s_before_w;
                 payv = DICT ? nullptr : spayv + s_before_w;

@@ -111,6 +111,15 @@ def test_block_solver_properties_on_the_whole_lp_not_an_oracle_comparison(c5):
                 assert rhs > 0 and res <= 1e-12 * rhs, (rep, it, g, res, rhs)   # the CG bar is 1e-13 on the recurrence
         runs.append((grp.x(), grp.cg_steps()))
     assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    # (a run's first iteration goes block after block, the others side by side on the blocks' streams -- round 6; once more with
+    # the streams switched off)
+    os.environ["SLP_BLOCKS_STREAMS"] = "0"
+    try:
+        grp.restart()
+        grp.iterate(3)
+    finally:
+        os.environ.pop("SLP_BLOCKS_STREAMS", None)
+    assert np.array_equal(runs[0][0], grp.x()) and runs[0][1] == grp.cg_steps()
     x = runs[0][0]
     assert np.all(np.isfinite(x)) and np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
     assert runs[0][1] >= 3 * G * 10    # every block ran its conjugate gradients
@@ -207,3 +216,29 @@ def test_eight_blocks_on_one_rank_equal_two_by_four_and_eight_by_one():
     want, steps = oracle.lp_admm_blocks_cg(lp[0], blocks, lp[1], lp[2], nb_iter=RIT)
     err = float(np.max(np.abs(one["x"] - want) / (1 + np.abs(want))))
     assert err <= 1e-9, err
+
+
+def test_blocks_side_by_side_on_streams_change_nothing():
+    """Round 6: from a group's second iteration on the blocks' projections run side by side, every block on a
+    stream of its own, taking their rounds of conjugate-gradient steps in turn (csrc/slp_blocks.hip blocks_project_side_by_side)
+    -- by default only for blocks too large for captured graphs, SLP_BLOCKS_STREAMS=1 forces it on this reduced shape.  Every
+    block's arithmetic is what it was: x, the step counts and the projection residuals bit for bit those of block after block."""
+    from pysparselp_amd.scale import DeviceBlocksGroup
+
+    os.environ["SLP_STRIP_MIN_NNZ"] = "1"
+    try:
+        grp, xf, c, lb, ub, b = DeviceBlocksGroup.from_generator(RN, G * RROWS, RP, RSEED, [RROWS * g for g in range(G + 1)])
+        outs = []
+        for mode in ("0", "1", "1"):
+            os.environ["SLP_BLOCKS_STREAMS"] = mode
+            grp.restart()
+            grp.iterate(1)
+            grp.iterate(RIT - 1)
+            outs.append((grp.x(), grp.cg_steps(), np.array(grp.projection_residuals())))
+        grp.close()
+    finally:
+        os.environ.pop("SLP_STRIP_MIN_NNZ", None)
+        os.environ.pop("SLP_BLOCKS_STREAMS", None)
+    assert outs[0][1] > 0
+    for other in outs[1:]:
+        assert np.array_equal(outs[0][0], other[0]) and outs[0][1] == other[1] and np.array_equal(outs[0][2], other[2])
