@@ -764,10 +764,14 @@ int slp_blocks_group_link(slp_blocks **blocks, int count) {
 // next `check_every` steps; end): the queues hold several blocks' products at once and a compute unit that finishes its workgroup
 // of one block starts one of the next -- what a batched grid would do, without rewriting the loop around per-block scalars in
 // device memory.  Every block's arithmetic is what it was (same kernels, same order on its stream): results bit for bit, step
-// counts equal.  Not under a communicator (there the blocks' all-reduces overlap the next block's projection instead), not for
-// launch-bound blocks (their steps replay a graph captured on the library's stream), and not for a group's first iteration
-// (whatever a block builds lazily is built on the library's stream, where the caching allocator's stream order holds).
-// SLP_BLOCKS_STREAMS=0 / 1: never / also for small blocks (tests).
+// counts equal.  MEASURED at config 5 (tools/lab/c5_streams_ab.sh, profiles/r06_c5_streams_ab.log, interleaved on one box):
+// 0.9602 / 0.9605 it/s block after block, 0.9385 / 0.9383 side by side -- 2.3 % SLOWER, the objective equal to the last bit.  Eight
+// blocks' products in flight multiply eight different 400 MB vectors: the workgroups that share an XCD's L2 no longer share their
+// slice of x (the placement of tall_build), and that costs more than the launch tails give back.  So it is OPT-IN
+// (SLP_BLOCKS_STREAMS=1; the test of the path sets it), block after block is the default, and the batched grid this stands in for
+// would run into the same sharing.  Never under a communicator (there the blocks' all-reduces overlap the next block's projection
+// instead), never captured graphs on the side streams, and not for a group's first iteration (whatever a block builds lazily is
+// built on the library's stream, where the caching allocator's stream order holds).
 static std::vector<hipStream_t> g_blk_streams;
 static std::vector<hipEvent_t> g_blk_events;   // [count] = the library's stream at the start of the iteration
 static bool blocks_side_by_side(slp_blocks **blocks, int count) {
@@ -775,10 +779,7 @@ static bool blocks_side_by_side(slp_blocks **blocks, int count) {
     for (int g = 0; g < count; ++g)
         if (!blocks[g]->warmed) return false;
     const char *e = getenv("SLP_BLOCKS_STREAMS");
-    if (e && e[0]) return e[0] != '0';
-    for (int g = 0; g < count; ++g)
-        if (blocks[g]->a->a.nnz <= 20000000) return false;
-    return true;
+    return e && e[0] == '1';
 }
 static void blocks_project_side_by_side(slp_blocks **blocks, int count) {
     hipStream_t main_stream = ctx().stream;

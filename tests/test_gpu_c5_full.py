@@ -111,9 +111,9 @@ def test_block_solver_properties_on_the_whole_lp_not_an_oracle_comparison(c5):
                 assert rhs > 0 and res <= 1e-12 * rhs, (rep, it, g, res, rhs)   # the CG bar is 1e-13 on the recurrence
         runs.append((grp.x(), grp.cg_steps()))
     assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
-    # (a run's first iteration goes block after block, the others side by side on the blocks' streams -- round 6; once more with
-    # the streams switched off)
-    os.environ["SLP_BLOCKS_STREAMS"] = "0"
+    # once more with the blocks' projections side by side on streams of their own (round 6, opt-in: a run's first iteration goes
+    # block after block, the others side by side)
+    os.environ["SLP_BLOCKS_STREAMS"] = "1"
     try:
         grp.restart()
         grp.iterate(3)
@@ -219,10 +219,10 @@ def test_eight_blocks_on_one_rank_equal_two_by_four_and_eight_by_one():
 
 
 def test_blocks_side_by_side_on_streams_change_nothing():
-    """Round 6: from a group's second iteration on the blocks' projections run side by side, every block on a
-    stream of its own, taking their rounds of conjugate-gradient steps in turn (csrc/slp_blocks.hip blocks_project_side_by_side)
-    -- by default only for blocks too large for captured graphs, SLP_BLOCKS_STREAMS=1 forces it on this reduced shape.  Every
-    block's arithmetic is what it was: x, the step counts and the projection residuals bit for bit those of block after block."""
+    """Round 6: with SLP_BLOCKS_STREAMS=1 the blocks' projections run side by side from a group's second iteration
+    on, every block on a stream of its own, taking their rounds of conjugate-gradient steps in turn (csrc/slp_blocks.hip
+    blocks_project_side_by_side; opt-in: measured 2.3 % slower than block after block at config 5).  Every block's arithmetic is
+    what it was: x, the step counts and the projection residuals bit for bit those of block after block."""
     from pysparselp_amd.scale import DeviceBlocksGroup
 
     os.environ["SLP_STRIP_MIN_NNZ"] = "1"

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round 6: config 5 (bench.py --config c5, block-splitting ADMM, 8 blocks on one GPU) with the blocks' projections block after
-# block (SLP_BLOCKS_STREAMS=0) and side by side on the blocks' streams (default), interleaved on ONE box; the objective after the
+# block (SLP_BLOCKS_STREAMS=0, the default) and side by side on the blocks' streams (=1), interleaved on ONE box; the objective after the
 # run must not change by a bit.      bash tools/lab/c5_streams_ab.sh out.log [reps]
 OUT=${1:-gpurun_out/c5_streams_ab.log}
 REPS=${2:-2}
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
 for rep in $(seq 1 $REPS); do
-  for mode in 0 default; do
-    if [ $mode = default ]; then unset SLP_BLOCKS_STREAMS; else export SLP_BLOCKS_STREAMS=$mode; fi
+  for mode in 0 1; do
+    export SLP_BLOCKS_STREAMS=$mode
     echo "streams=[$mode] $(timeout 900 python bench.py --config c5 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 try:
