@@ -75,21 +75,31 @@ __host__ __device__ inline unsigned long long value_key(unsigned long long bits)
 
 // Insert every stored value's bit pattern into an open-addressing hash set; `count` = distinct values so
 // far.  Gives up (count > limit) as soon as the matrix turns out to have too many.
+// A workgroup remembers in LDS (direct-mapped, 4096 slots) which bit patterns it has already found in the global set: with the few
+// hundred distinct values a dictionary matrix has, all but the first look-ups of a pattern end there instead of in an atomic load
+// from L2 per stored entry (10.8 -> 6.4 ms per 1.25e9 entries).  A slot only ever holds a pattern its writer has seen IN the
+// global set, so a stale or overwritten slot costs a global look-up, never a missed insertion.
 __global__ __launch_bounds__(kBlock) void k_value_set(i64 nnz, const double *__restrict__ val, unsigned long long *table,
                                                       unsigned int *count, unsigned int limit) {
-    i64 it = 0;
-    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (i64)gridDim.x * blockDim.x, ++it) {
-        if ((it & 63) == 0 && __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit) return;
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(val[k]);
-        if (bits == kDictEmpty || val[k] != val[k]) {  // NaN entries (or the sentinel): no dictionary
+    constexpr int kSeen = 4096;
+    __shared__ unsigned long long seen[kSeen];
+    for (int i = threadIdx.x; i < kSeen; i += kBlock) seen[i] = kDictEmpty;
+    __syncthreads();
+    // one pattern: false = no dictionary for this matrix
+    auto take = [&](double v) -> bool {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        if (bits == kDictEmpty || v != v) {  // NaN entries (or the sentinel): no dictionary
             atomicAdd(count, limit + 1);
-            return;
+            return false;
         }
-        unsigned int h = (unsigned int)((bits * 0x9E3779B97F4A7C15ull) >> 40) & (kDictHash - 1);
+        const unsigned long long mixed = bits * 0x9E3779B97F4A7C15ull;
+        const unsigned int slot = (unsigned int)(mixed >> 52) & (kSeen - 1);
+        if (seen[slot] == bits) return true;
+        unsigned int h = (unsigned int)(mixed >> 40) & (kDictHash - 1);
         for (int probes = 0;; ++probes) {
             if (probes >= 64) {  // a set this crowded holds far more than `limit` values: give up (never spins on a full table)
                 atomicAdd(count, limit + 1);
-                return;
+                return false;
             }
             unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == bits) break;
@@ -100,6 +110,20 @@ __global__ __launch_bounds__(kBlock) void k_value_set(i64 nnz, const double *__r
             }
             h = (h + 1) & (kDictHash - 1);
         }
+        seen[slot] = bits;   // (in the global set now)
+        return true;
+    };
+    // four entries of a thread in flight together (one at a time the kernel ran at the latency of its loads: 0.8 TB/s)
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    i64 it = 0;
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += 4 * stride, ++it) {
+        if ((it & 15) == 0 && __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit) return;
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = val[k + j * stride < nnz ? k + j * stride : k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!take(v[j])) return;
     }
 }
 
