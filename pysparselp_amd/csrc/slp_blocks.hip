@@ -779,10 +779,13 @@ static bool blocks_side_by_side(slp_blocks **blocks, int count) {
     for (int g = 0; g < count; ++g)
         if (!blocks[g]->warmed) return false;
     const char *e = getenv("SLP_BLOCKS_STREAMS");
-    return e && e[0] == '1';
+    return e && atoi(e) >= 1;
 }
+// SLP_BLOCKS_STREAMS=1: all blocks side by side; = w >= 2: w at a time (block g on stream g % w, the groups one after the other)
 static void blocks_project_side_by_side(slp_blocks **blocks, int count) {
     hipStream_t main_stream = ctx().stream;
+    const char *e = getenv("SLP_BLOCKS_STREAMS");
+    const int want = e ? atoi(e) : 1, width = want >= 2 && want < count ? want : count;
     while ((int)g_blk_streams.size() < count) {
         hipStream_t st = nullptr;
         SLP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -795,22 +798,25 @@ static void blocks_project_side_by_side(slp_blocks **blocks, int count) {
     }
     SLP_HIP(hipEventRecord(g_blk_events[count], main_stream));
     try {
-        for (int g = 0; g < count; ++g) {
-            ctx().stream = g_blk_streams[g];
-            SLP_HIP(hipStreamWaitEvent(g_blk_streams[g], g_blk_events[count], 0));
-            rb_project_begin(blocks[g]);
-        }
-        std::vector<char> active((size_t)count, 1);
-        for (int left = count; left > 0;)
-            for (int g = 0; g < count; ++g) {
-                if (!active[g]) continue;
-                ctx().stream = g_blk_streams[g];
-                if (!rb_project_round(blocks[g], false)) continue;
-                rb_project_end(blocks[g]);
-                SLP_HIP(hipEventRecord(g_blk_events[g], g_blk_streams[g]));
-                active[g] = 0;
-                --left;
+        for (int g = 0; g < width; ++g) SLP_HIP(hipStreamWaitEvent(g_blk_streams[g], g_blk_events[count], 0));
+        for (int g0 = 0; g0 < count; g0 += width) {
+            const int g1 = std::min(count, g0 + width);
+            for (int g = g0; g < g1; ++g) {
+                ctx().stream = g_blk_streams[g % width];
+                rb_project_begin(blocks[g]);
             }
+            std::vector<char> active((size_t)count, 1);
+            for (int left = g1 - g0; left > 0;)
+                for (int g = g0; g < g1; ++g) {
+                    if (!active[g]) continue;
+                    ctx().stream = g_blk_streams[g % width];
+                    if (!rb_project_round(blocks[g], false)) continue;
+                    rb_project_end(blocks[g]);
+                    SLP_HIP(hipEventRecord(g_blk_events[g], g_blk_streams[g % width]));
+                    active[g] = 0;
+                    --left;
+                }
+        }
     } catch (...) {
         ctx().stream = main_stream;
         for (int g = 0; g < count; ++g) (void)hipStreamSynchronize(g_blk_streams[g]);   // nothing of the blocks may still run when the error unwinds

@@ -7,7 +7,7 @@ REPS=${2:-2}
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
 for rep in $(seq 1 $REPS); do
-  for mode in 0 1; do
+  for mode in ${MODES:-0 1}; do
     export SLP_BLOCKS_STREAMS=$mode
     echo "streams=[$mode] $(timeout 900 python bench.py --config c5 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
