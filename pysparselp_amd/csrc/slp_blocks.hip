@@ -765,11 +765,12 @@ int slp_blocks_group_link(slp_blocks **blocks, int count) {
 // of one block starts one of the next -- what a batched grid would do, without rewriting the loop around per-block scalars in
 // device memory.  Every block's arithmetic is what it was (same kernels, same order on its stream): results bit for bit, step
 // counts equal.  MEASURED at config 5 (tools/lab/c5_streams_ab.sh, profiles/r06_c5_streams_ab.log, interleaved on one box):
-// 0.9602 / 0.9605 it/s block after block, 0.9385 / 0.9383 side by side -- 2.3 % SLOWER, the objective equal to the last bit.  Eight
-// blocks' products in flight multiply eight different 400 MB vectors: the workgroups that share an XCD's L2 no longer share their
-// slice of x (the placement of tall_build), and that costs more than the launch tails give back.  So it is OPT-IN
-// (SLP_BLOCKS_STREAMS=1; the test of the path sets it), block after block is the default, and the batched grid this stands in for
-// would run into the same sharing.  Never under a communicator (there the blocks' all-reduces overlap the next block's projection
+// 0.9602 / 0.9605 it/s block after block, 0.9385 / 0.9383 side by side -- 2.3 % SLOWER (two / four blocks at a time: 1.0 / 1.2 %),
+// the objective equal to the last bit: the more products in flight, the slower -- there is no launch tail to win back (a product's
+// 255 workgroups are balanced by construction), and workgroups of different blocks on one chip get in each other's way.  (Not
+// through x: a lab build whose x-tiles all come from one 4 MB window runs a single product of the shape in 3.02 ms against 3.03.)
+// So it is OPT-IN (SLP_BLOCKS_STREAMS=1 | w; the test of the path sets it), block after block is the default, and the batched grid
+// this stands in for has nothing to gain either.  Never under a communicator (there the blocks' all-reduces overlap the next block's projection
 // instead), never captured graphs on the side streams, and not for a group's first iteration (whatever a block builds lazily is
 // built on the library's stream, where the caching allocator's stream order holds).
 static std::vector<hipStream_t> g_blk_streams;
