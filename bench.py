@@ -43,6 +43,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -186,6 +187,11 @@ def spmv_block(lib, a, transposed, shape, reps=5):
     """Roofline figures of one SpMV orientation of the resident matrix, timed with HIP events on the library's stream.
     Figures are per PRODUCT (y = A x once); a chunked matrix may take several launches for one (``launches_per_product``)."""
     rows, cols = (a.shape[1], a.shape[0]) if transposed else a.shape
+    # Average over >= 0.3 s of back-to-back products behind the library's own ~0.1 s warm-up (slp_matrix_bench_spmv): the duration a
+    # product has inside the iterations.  Five products right after an idle spell (the host fills the vector) read 5-15 % long on a 3 ms
+    # product -- the chip is still coming up to the clocks of a loaded one (config 5's shape: 3.28 ms against 2.80 over 100 products).
+    est = a.bench_spmv(transposed, reps=3)
+    reps = int(min(400, max(reps, math.ceil(300.0 / max(est, 1e-3)))))
     ms = a.bench_spmv(transposed, reps=reps)
     which = int(lib.slp_matrix_spmv_kernel(a._h, int(transposed)))
     copy_bytes = int(lib.slp_matrix_format_bytes(a._h, int(transposed)))
@@ -198,6 +204,7 @@ def spmv_block(lib, a, transposed, shape, reps=5):
         "achieved": moved / (ms * 1e-3) / 1e9,
         "frac": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "ms_per_product": ms,
+        "products_timed": reps,
         "launches_per_product": launches,
         "ms_per_launch": ms / launches,
         "bytes_per_product": moved,
@@ -678,6 +685,7 @@ def run_workload(lib, args, rank, world, distributed):
             "bytes_per_product": ax["bytes_per_product"],
             "matrix_copy_bytes_per_product": ax["matrix_copy_bytes_per_product"],
             "ms_per_product": ax["ms_per_product"],
+            "products_timed": ax["products_timed"],               # back-to-back, behind ~0.1 s of untimed ones (spmv_block)
             "launches_per_product": ax["launches_per_product"],   # a chunked matrix may take one launch per row chunk
             "ms_per_launch": ax["ms_per_launch"],                 # = ms_per_product / launches_per_product
             "csr_equivalent": ax["csr_equivalent"],

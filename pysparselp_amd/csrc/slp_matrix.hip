@@ -813,7 +813,18 @@ int slp_matrix_bench_spmv(slp_matrix *m, int transposed, int order, int reps, do
         std::vector<double> h((size_t)a.ncol);
         for (size_t i = 0; i < h.size(); ++i) h[i] = 1.0 + 1e-3 * (double)(i % 1000);
         vx.upload(h.data(), h.size());
-        matrix_spmv(m, transposed != 0, vx.p, vy.p, order);  // warm-up
+        // warm-up: at least one product, then products until ~100 ms have gone by (at most 64).  The vector above was filled on the
+        // host while the GPU sat idle: the first products after that run below the clocks of a loaded chip -- a 5-product
+        // measurement of a 3 ms product read 3.28 ms where 100 products read 2.80 (config 5's shape; tools/lab, round 6).
+        {
+            matrix_spmv(m, transposed != 0, vx.p, vy.p, order);
+            SLP_HIP(hipStreamSynchronize(ctx().stream));
+            const double t0 = trace_now();
+            for (int w = 0; w < 64 && trace_now() - t0 < 0.1; ++w) {
+                matrix_spmv(m, transposed != 0, vx.p, vy.p, order);
+                SLP_HIP(hipStreamSynchronize(ctx().stream));
+            }
+        }
         const char *two = getenv("SLP_BENCH_TWO_VECTORS");  // time the two-vector pass (strip format only)
         const StripJds *f2 = (two && two[0] == '1') ? fast_format(m, transposed != 0) : nullptr;
         DevBuf<double> vx2, vy2;
