@@ -221,29 +221,13 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
                     row[k] = w[k] >> kTallColBits;
                 }
             }
-#ifndef SLP_TALL_LAB_ATOMIC
 #pragma unroll
             for (int k = 0; k < 4; ++k) ar[k] = acc[row[k]];
-#endif
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-#ifdef SLP_TALL_LAB_ARITH
-                if (DICT) {
-                    const double kd = __hiloint2double(0x43300000, (int)(w[k] & ((1u << kTallIdBits) - 1))) - (4503599627370496.0 + 1024.0);
-                    const double q0 = kd * 0.01;
-                    const double rem = __builtin_fma(-q0, 100.0, kd);
-                    pr[k] = __builtin_fma(rem, 0.01, q0) * tile[(w[k] >> kTallIdBits) & (kTallC - 1)];
-                } else
-#endif
                 pr[k] = DICT ? dv[w[k] & ((1u << kTallIdBits) - 1)] * tile[(w[k] >> kTallIdBits) & (kTallC - 1)]
                              : (POW ? abs_pow(g.val[DICT ? 0 : k0 + k], pw) * 1.0 : g.val[DICT ? 0 : k0 + k]) * tile[w[k] & (kTallC - 1)];
             }
-#ifdef SLP_TALL_LAB_ATOMIC
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&acc[row[k]], pr[k]);
-            (void)ar; (void)t;
-#else
             t[0] = ar[0] + pr[0];
 #pragma unroll
             for (int k = 1; k < 4; ++k) t[k] = ((row[k] == row[k - 1]) ? t[k - 1] : ar[k]) + pr[k];
@@ -252,7 +236,6 @@ __global__ __launch_bounds__(kTallT) void k_tall_spmv(int nseg, const TallWg *__
             // the packets ahead (rounds 3-4: a branch, then a select, per store: 3 vector instructions per item more)
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[row[k]] = t[k];
-#endif
         };
         group(0);   // (a wave without items -- nearly never -- reads cell 0 of the arrays and stores into the scratch cell)
         between();
