@@ -34,8 +34,8 @@ def check_line(d, need_cpu_baseline):
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    if "products_timed" in r:  # round 6 (late): >= 0.3 s of back-to-back products behind a warm-up, never fewer than five
-        assert r["products_timed"] >= 5 and r["products_timed"] * r["ms_per_product"] >= 250.0 or r["products_timed"] == 400
+    if "products_timed" in r:  # round 6 (late): ~0.3 s of back-to-back products (reps from a 3-product estimate) behind a warm-up, never fewer than five
+        assert r["products_timed"] >= 5 and (r["products_timed"] * r["ms_per_product"] >= 150.0 or r["products_timed"] == 400)
     if _per_product(r, "bytes") is not None:  # round 2 on: bytes the kernel has to move / time -- a fraction of the peak, never above it
         assert 0.0 < r["frac"] <= 1.0
         assert _per_product(r, "bytes") >= _per_product(r, "matrix_copy_bytes") > 0
