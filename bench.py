@@ -637,11 +637,15 @@ def run_workload(lib, args, rank, world, distributed):
     _lib.check(lib.slp_comm_barrier())
     coll0 = int(lib.slp_comm_collectives())
     _lib.check(lib.slp_comm_timing(1))   # HIP event pairs around every collective: recorded now, read after the timed region
+    _lib.check(lib.slp_product_timing(1))  # ... and around every product of the solver (the stream it runs on): roofline.timed_region
     t0 = time.perf_counter()
     solver.iterate(args.steps)
     _lib.check(lib.slp_comm_timing(0))   # (the closing barrier's all-reduce is not part of an iteration)
+    _lib.check(lib.slp_product_timing(0))
     _lib.check(lib.slp_comm_barrier())
     dt = time.perf_counter() - t0
+    prod = np.zeros(3)
+    _lib.check(lib.slp_product_timing_read(_lib.ptr(prod)))   # products, sum of their durations (ms), the longest (ms)
     coll = int(lib.slp_comm_collectives()) - coll0 - 1  # the closing barrier is one
     tmax = np.array([dt])
     _lib.check(lib.slp_comm_allreduce_host(_lib.ptr(tmax), 1, 1))
@@ -686,6 +690,15 @@ def run_workload(lib, args, rank, world, distributed):
             "matrix_copy_bytes_per_product": ax["matrix_copy_bytes_per_product"],
             "ms_per_product": ax["ms_per_product"],
             "products_timed": ax["products_timed"],               # back-to-back, behind ~0.1 s of untimed ones (spmv_block)
+            # the products of the K timed steps themselves (HIP event pairs around each, both orientations: the solver's own
+            # launches on the stream they ran on): their number, average duration and what that is in bytes moved per second
+            "timed_region": (None if prod[0] == 0 else {
+                "products": int(prod[0]), "products_per_step": prod[0] / args.steps,
+                "ms_per_product": prod[1] / prod[0], "longest_ms": prod[2],
+                "bytes_per_product": 0.5 * (ax["bytes_per_product"] + aty["bytes_per_product"]),
+                "achieved": 0.5 * (ax["bytes_per_product"] + aty["bytes_per_product"]) / (prod[1] / prod[0] * 1e-3) / 1e9,
+                "frac": 0.5 * (ax["bytes_per_product"] + aty["bytes_per_product"]) / (prod[1] / prod[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "share_of_step": prod[1] / (1e3 * dt)}),
             "launches_per_product": ax["launches_per_product"],   # a chunked matrix may take one launch per row chunk
             "ms_per_launch": ax["ms_per_launch"],                 # = ms_per_product / launches_per_product
             "csr_equivalent": ax["csr_equivalent"],

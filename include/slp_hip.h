@@ -92,6 +92,12 @@ int slp_matrix_download_rows(slp_matrix *a, int transposed, int64_t row0, int64_
 /* Device-resident benchmark kernels: `reps` back-to-back launches on resident
  * vectors, no host traffic; *ms = average GPU time per launch (HIP events). */
 int slp_matrix_bench_spmv(slp_matrix *a, int transposed, int order, int reps, double *ms);
+/* Measurement only (no reference counterpart; bench.py's roofline.timed_region): while on, a pair of HIP events is recorded
+ * around every single-vector product the solvers run through the strip / tall-cell copies (the products of ADMM.py:148,262 and
+ * ChambollePockPPD.py:206,216,235,240), on the stream it runs on.  slp_product_timing(1) resets the record; _read (after
+ * switching off) gives out[0] = products, out[1] = the sum of their durations in ms, out[2] = the longest one. */
+int slp_product_timing(int on);
+int slp_product_timing_read(double out[3]);
 /* New device-resident matrix whose row r is scale[r] * (row rows[r] of a): the one-sided stacking [A[up]; -A[lo]] of
  * ChambollePockPPD.py:74-88 (and any row selection) without a round trip of the CSR through the host.
  * scale 1 copies, -1 negates exactly. */

@@ -47,6 +47,8 @@ _SIGNATURES = {
     "slp_matrix_download": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
     "slp_matrix_download_rows": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "slp_matrix_bench_spmv": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),
+    "slp_product_timing": (c_int, [c_int]),
+    "slp_product_timing_read": (c_int, [c_vp]),
     "slp_matrix_gather_rows": (c_vp, [c_vp, c_i64, c_vp, c_vp]),
     "slp_matrix_spmv_kernel": (c_int, [c_vp, c_int]),
     "slp_matrix_set_format": (c_int, [c_vp, c_int]),

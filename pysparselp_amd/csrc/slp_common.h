@@ -286,6 +286,8 @@ bool value_dictionary(const CsrDev &a, ValueDict &d);
 bool strip_wanted(const CsrDev &a, int variant);   // variant: 0 fp64 entries, 1 dictionary pairs, 2 dictionary quads, 3 wide strips
 bool strip_build(const CsrDev &a, StripJds &f, const ValueDict *dict, int variant);
 void strip_spmv(const StripJds &f, const double *x, double *out);
+void product_timing(bool on);            // HIP events around every strip_spmv product while on (slp_strip.hip)
+void product_timing_read(double out[3]);  // products, sum of their durations (ms), the longest (ms)
 // > 0 while a caller needs every row sum as the single chain of the CSR walk (matrix_spmv in SLP_ORDER_SEQUENTIAL): LDS-strip
 // copies built with a strip-range split (S > 1: few row blocks, e.g. a 1/8 row partition) then run one workgroup per row block
 extern int g_strip_single_chain;

@@ -802,6 +802,20 @@ int64_t slp_matrix_format_bytes(slp_matrix *m, int transposed) {
     }
 }
 
+int slp_product_timing(int on) {
+    SLP_API_INT({
+        (void)ctx();
+        product_timing(on != 0);
+    })
+}
+
+int slp_product_timing_read(double out[3]) {
+    SLP_API_INT({
+        SLP_REQUIRE(out, "slp_product_timing_read: NULL argument");
+        product_timing_read(out);
+    })
+}
+
 int slp_matrix_bench_spmv(slp_matrix *m, int transposed, int order, int reps, double *ms) {
     SLP_API_INT({
         SLP_REQUIRE(m && reps > 0 && ms, "slp_matrix_bench_spmv: bad arguments");

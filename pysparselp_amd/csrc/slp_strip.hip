@@ -1260,7 +1260,58 @@ static void for_parts(const StripJds &f, F call) {
                                                      (f.parts_cols && k > 0) ? 1 : 0);
 }
 
+// ---- products timed where they run (slp_product_timing; bench.py's roofline.timed_region) --------------------------------------
+// A pair of HIP events around every single-vector product that goes through strip_spmv -- the products of the matrix-free ADMM, of
+// Chambolle-Pock on strip copies and of the block projections -- on the stream it is enqueued on, while the switch is on: the
+// durations of the products INSIDE the timed iterations (all launches of a product: a chunk-by-chunk composite, the combine of a
+// strip-range split), read afterwards.  Nothing is recorded while it is off.
+namespace {
+struct ProductTimer {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs: 2 k opens product k, 2 k + 1 closes it
+    size_t used = 0;
+};
+ProductTimer g_product_timer;
+constexpr size_t kProductEventsMax = 1u << 20;
+struct ProductScope {
+    size_t at = (size_t)-1;
+    ProductScope() {
+        ProductTimer &t = g_product_timer;
+        if (!t.on || t.used + 2 > kProductEventsMax) return;
+        while (t.ev.size() < t.used + 2) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            t.ev.push_back(e);
+        }
+        at = t.used;
+        t.used += 2;
+        (void)hipEventRecord(t.ev[at], ctx().stream);
+    }
+    ~ProductScope() {
+        if (at != (size_t)-1) (void)hipEventRecord(g_product_timer.ev[at + 1], ctx().stream);
+    }
+};
+}  // namespace
+void product_timing(bool on) {
+    g_product_timer.on = on;
+    if (on) g_product_timer.used = 0;
+}
+// out[0] = products recorded since the switch went on, out[1] = the sum of their durations (ms), out[2] = the longest one (ms)
+void product_timing_read(double out[3]) {
+    ProductTimer &t = g_product_timer;
+    out[0] = out[1] = out[2] = 0.0;
+    for (size_t k = 0; k + 1 < t.used; k += 2) {
+        SLP_HIP(hipEventSynchronize(t.ev[k + 1]));
+        float ms = 0.f;
+        SLP_HIP(hipEventElapsedTime(&ms, t.ev[k], t.ev[k + 1]));
+        out[0] += 1.0;
+        out[1] += (double)ms;
+        if ((double)ms > out[2]) out[2] = (double)ms;
+    }
+}
+
 void strip_spmv(const StripJds &f, const double *x, double *out) {
+    ProductScope timed;
     if (f.parts.empty()) { strip_spmv_one(f, x, out, 0); return; }
     if (f.fused) { tall_spmv_fused(f, x, out); return; }   // all chunks' tall cells in one launch
     for_parts(f, [&](const StripJds &g, i64 xo, i64 oo, int accum) { strip_spmv_one(g, x + xo, out + oo, accum); });

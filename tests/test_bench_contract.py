@@ -36,6 +36,11 @@ def check_line(d, need_cpu_baseline):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     if "products_timed" in r:  # round 6 (late): ~0.3 s of back-to-back products (reps from a 3-product estimate) behind a warm-up, never fewer than five
         assert r["products_timed"] >= 5 and (r["products_timed"] * r["ms_per_product"] >= 150.0 or r["products_timed"] == 400)
+    if r.get("timed_region"):  # round 6 (late): HIP event pairs around every product of the K timed steps themselves
+        t = r["timed_region"]
+        assert t["products"] == round(t["products_per_step"] * d["steps"]) and t["products"] > 0
+        assert 0.0 < t["ms_per_product"] <= t["longest_ms"] and 0.0 < t["share_of_step"] <= 1.0
+        assert abs(t["frac"] - t["achieved"] / r["peak"]) < 1e-12 and 0.0 < t["frac"] <= 1.0
     if _per_product(r, "bytes") is not None:  # round 2 on: bytes the kernel has to move / time -- a fraction of the peak, never above it
         assert 0.0 < r["frac"] <= 1.0
         assert _per_product(r, "bytes") >= _per_product(r, "matrix_copy_bytes") > 0
