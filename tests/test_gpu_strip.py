@@ -234,3 +234,35 @@ def test_cp_preconditioners_through_the_strip_copies_match_the_oracle(monkeypatc
         assert np.array_equal(t, t_ref) if alpha == 1.0 else np.allclose(t, t_ref, rtol=1e-14, atol=0), alpha
         assert np.array_equal(sig, np.concatenate((se_ref, si_ref)) if m_eq else si_ref), alpha
     a.close()
+
+
+def test_product_timing_counts_the_products_while_it_is_on():
+    """slp_product_timing (bench.py's roofline.timed_region): HIP event pairs around every product that runs through a strip copy
+    while the switch is on -- the count is exact, the durations are positive, nothing is recorded while it is off, and switching it
+    on again starts a new record."""
+    from pysparselp_amd import _lib
+    from pysparselp_amd.problems import random_lp_on_device
+
+    os.environ["SLP_STRIP_MIN_NNZ"] = "1"
+    try:
+        a, xf, c, lb, ub, b = random_lp_on_device(30000, 40000, 0.001, seed=3)
+        lib = _lib.lib()
+        assert a.spmv_kernel(False) != 0 and a.spmv_kernel(True) != 0     # strip copies in both orientations
+        out = np.zeros(3)
+        a.matvec(xf)                                                        # off: not recorded
+        _lib.check(lib.slp_product_timing(1))
+        for _ in range(3):
+            a.matvec(xf)
+        a.rmatvec(b)
+        _lib.check(lib.slp_product_timing(0))
+        a.matvec(xf)                                                        # off again
+        _lib.check(lib.slp_product_timing_read(_lib.ptr(out)))
+        assert out[0] == 4 and 0.0 < out[2] <= out[1]
+        _lib.check(lib.slp_product_timing(1))
+        a.rmatvec(b)
+        _lib.check(lib.slp_product_timing(0))
+        _lib.check(lib.slp_product_timing_read(_lib.ptr(out)))
+        assert out[0] == 1 and out[1] > 0.0
+        a.close()
+    finally:
+        del os.environ["SLP_STRIP_MIN_NNZ"]
