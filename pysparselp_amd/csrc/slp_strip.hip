@@ -1278,6 +1278,10 @@ struct ProductScope {
     ProductScope() {
         ProductTimer &t = g_product_timer;
         if (!t.on || t.used + 2 > kProductEventsMax) return;
+        // not inside a stream capture (launch-bound LPs replay captured iterations: an event recorded there would be a graph node,
+        // not a time stamp -- such products go uncounted)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ctx().stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
         while (t.ev.size() < t.used + 2) {
             hipEvent_t e = nullptr;
             if (hipEventCreate(&e) != hipSuccess) return;
