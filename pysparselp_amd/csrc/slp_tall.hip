@@ -295,6 +295,7 @@ __global__ __launch_bounds__(kTallT) void k_tall_build(int R, i64 T, int S, int 
             s_n = (int)(hi - lo);
         }
     };
+    static_assert(kTallT >= 2 * kWave, "take_next runs on the first lane of the second wave, beside wave 0's look-back");
     if (threadIdx.x == kWave) take_next(atomicAdd(sc.ticket, 1ull));
     for (;;) {
         int p = threadIdx.x;
